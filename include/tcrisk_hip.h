@@ -1,0 +1,185 @@
+/*
+ * tcrisk_hip.h — C ABI of libtcrisk_hip.so, the MI355X (gfx950) implementation of
+ * the per-storm hot path of linjonathan/tropical_cyclone_risk.
+ *
+ * The reference has no FFI: the seam it exposes is the Python method boundary
+ *     Coupled_FAST.init_fields / .gen_track / ._env_winds   (intensity/coupled_fast.py:217-267,
+ *                                                            track/bam_track.py:116-128)
+ * driven once per candidate seed by util/compute.py:run_tracks (compute.py:134-209).
+ * This ABI is the *batched* form of that seam: fields are staged once per
+ * (month) slot, then whole batches of storms are integrated per call.  Every
+ * entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C types only; the caller owns every buffer it passes;
+ *   - functions return 0 on success, <0 on error (tcr_last_error() has the text);
+ *   - "host" pointers are ordinary memory, "dev" pointers are HIP device memory
+ *     (e.g. torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as void*
+ *     (NULL = the context's own stream);
+ *   - all floating point is IEEE fp64 (the reference computes in fp64 throughout);
+ *   - 2-D planes are [lat][lon] row-major with lat ascending, already cropped to
+ *     the basin box exactly as TC_Basin.transform_global_field does
+ *     (util/basins.py:57-75): lookups clamp to the cropped grid's edge like
+ *     RectBivariateSpline(kx=1,ky=1).ev.
+ */
+#ifndef TCRISK_HIP_H
+#define TCRISK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TCR_ABI_VERSION 1
+#define TCR_NW 4            /* ua250, va250, ua850, va850  (track/env_wind.py:22-26) */
+#define TCR_NCOV 10         /* packed lower triangle (0,0),(1,0),(1,1),(2,0)..(3,3) (env_wind.py:31-42) */
+#define TCR_MAX_SERIES 32
+#define TCR_N_BASINS 7      /* sorted ids AU,EP,NA,NI,SI,SP,WP (util/compute.py:87) */
+
+/* per-storm status (gen_track's return, intensity/coupled_fast.py:229-267) */
+#define TCR_STATUS_GATED (-1)      /* ventilation gate: gen_track returned None (coupled_fast.py:238-244) */
+#define TCR_STATUS_FINISHED 0      /* solve_ivp status 0: reached total_time */
+#define TCR_STATUS_EVENT 1         /* solve_ivp status 1: tc_dissipates fired (coupled_fast.py:246-256) */
+#define TCR_STATUS_STEP_FAIL (-2)  /* solve_ivp status -1: step size underflow */
+
+/* flags bit field written by the post-step (util/compute.py:185-209) */
+#define TCR_FLAG_IS_TC 1           /* any(v >= 15) and v(2 d) >= 6.5        (compute.py:185-189) */
+#define TCR_FLAG_ACCEPTED 2        /* ... and nanmax(vmax) >= 18            (compute.py:205)     */
+
+typedef struct tcr_ctx tcr_ctx;
+
+/* 1-D coordinate pair of a rectilinear grid (strictly increasing, may be non-uniform) */
+typedef struct {
+    int32_t nlon, nlat;
+    const double *lon;      /* host, [nlon] */
+    const double *lat;      /* host, [nlat] */
+} tcr_grid;
+
+/* namelist scalars the path reads (namelist.py:56-94) + solve_ivp options
+ * (coupled_fast.py:264-266) + Coupled_FAST constants (coupled_fast.py:23-27). */
+typedef struct {
+    double Ck, epsilon, kappa;              /* namelist.py:57; coupled_fast.py:25-26 */
+    double u_beta, v_beta;                  /* namelist.py:77-78 */
+    double T_Fs;                            /* namelist.T_days * 86400 (bam_track.py:56) */
+    double y_alpha[2], m_alpha[2], alpha_max[2], alpha_min[2];   /* namelist.py:73-76 */
+    double steering_coefs[2];               /* namelist.py:71 (used when !coupled_track) */
+    double dt_out, total_time;              /* namelist.py:48-49 */
+    double rtol, atol, max_step;            /* solve_ivp defaults + coupled_fast.py:266 */
+    double v_thresh, v_2d_thresh, vmax_thresh;   /* namelist.py:81-83 */
+    double v_dissipate;                     /* 4 m/s (coupled_fast.py:255) */
+    double earth_R;                         /* util/constants.py:7 */
+    double box[4];                          /* basin lon_min, lat_min, lon_max, lat_max (basins.py:42-50) */
+    double fs_amp;                          /* sqrt(2 / sum(n^-3)), computed by the host with NumPy */
+    double fs_wgt[TCR_MAX_SERIES];          /* n^-1.5 */
+    int32_t n_series;                       /* 15 (bam_track.py:112) */
+    int32_t n_steps;                        /* int(total_time/dt_out)+1 (bam_track.py:54) */
+    int32_t coupled_track;                  /* namelist.py:72 */
+    int32_t reserved;
+    /* seeding (util/compute.py:134-175) */
+    double seed_v_init;                     /* namelist.py:80 */
+    double pi_gate;                         /* 35 m/s (compute.py:168) */
+    double lat_vort_fac;                    /* namelist.py:88 */
+    double lat_vort_power[TCR_N_BASINS];    /* namelist.py:89-92, sorted-id order */
+    double atm_bl_depth[TCR_N_BASINS];      /* namelist.py:85-86, sorted-id order */
+    double minit_a, minit_b, minit_c, minit_d;   /* f_mInit = a/(1+exp(-(rh-b)*c))+d (namelist.py:94) */
+} tcr_params;
+
+/* A batch of storms; every pointer is [n] unless noted.  Used with host or
+ * device memory depending on the entry point. */
+typedef struct {
+    int64_t n;
+    const double *lon0, *lat0, *v0, *m0;    /* gen_track(clon, clat, v, m)  (coupled_fast.py:229) */
+    const double *h_bl;                     /* fast.h_bl = atm_bl_depth[basin] (compute.py:175) */
+    const int32_t *slot;                    /* field slot = genesis month - 1 (compute.py:151-152) */
+    const double *phases;                   /* [n][4][n_series] uniforms of gen_f (bam_track.py:27) */
+} tcr_storms;
+
+/* Outputs: the per-storm part of run_tracks' 9-tuple (compute.py:124-133, 210) */
+typedef struct {
+    double *lon, *lat, *v, *m, *vmax;       /* [n][n_steps], NaN after the track end */
+    double *envw;                           /* [n][n_steps][4] (tc_env_wnds) */
+    int32_t *n_valid;                       /* emitted samples (len(res.t)) */
+    int32_t *status;                        /* TCR_STATUS_* */
+    int32_t *flags;                         /* TCR_FLAG_* */
+    int32_t *nfev;                          /* RHS evaluations (res.nfev) */
+    int32_t *n_accept, *n_reject;           /* accepted steps / rejected attempts */
+} tcr_tracks;
+
+/* ---- lifecycle ----------------------------------------------------------- */
+int tcr_abi_version(void);
+/* replaces: constructing the 12 Coupled_FAST objects of a year (compute.py:119) */
+int tcr_ctx_create(int device, tcr_ctx **out);
+int tcr_ctx_destroy(tcr_ctx *ctx);
+/* last error text of a context (ctx == NULL: of the last failed tcr_ctx_create) */
+const char *tcr_last_error(const tcr_ctx *ctx);
+
+/* replaces: `import namelist` reads scattered through the path */
+int tcr_params_set(tcr_ctx *ctx, const tcr_params *p);
+
+/* ---- field staging (once per experiment / year) --------------------------- */
+/* replaces: geo.read_bathy / geo.read_land (intensity/geo.py:9-34, coupled_fast.py:30-31) */
+int tcr_static_upload(tcr_ctx *ctx, const tcr_grid *hg, const double *land, const double *bathy);
+/* replaces: BetaAdvectionTrack._load_wnd_stat (bam_track.py:76-91) +
+ *           Coupled_FAST.init_fields (coupled_fast.py:217-225) for one month slot.
+ * rh_mid feeds the initial m (compute.py:111,173); may be NULL if seeding is host-side. */
+int tcr_fields_upload(tcr_ctx *ctx, int slot,
+                      const tcr_grid *wg, const double *const mean[TCR_NW], const double *const cov[TCR_NCOV],
+                      const tcr_grid *tg, const double *vpot, const double *chi,
+                      const double *mld, const double *strat, const double *rh_mid);
+/* replaces: the land/<B>.nc interpolators f_b and f_basins (compute.py:87-97).
+ * masks are uint8 0/1 planes on one global grid; run_mask is the run basin's. */
+int tcr_masks_upload(tcr_ctx *ctx, const tcr_grid *mg, const uint8_t *run_mask,
+                     const uint8_t *const basin_masks[TCR_N_BASINS]);
+
+/* ---- the hot path ---------------------------------------------------------- */
+/* replaces: the per-candidate body of run_tracks — gen_track (compute.py:176),
+ * accept test 1 (:185-189), env-wind recompute (:201-202), axi_to_max_wind
+ * (:203-204), accept test 2 (:205) — for a whole batch.  Host buffers. */
+int tcr_integrate_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out);
+/* same with device buffers, asynchronous on `stream` */
+int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in_dev, const tcr_tracks *out_dev, void *stream);
+
+/* replaces: the rejection-sampling seed loop (compute.py:134-175) for candidates
+ * [cand0, cand0+n) of `year`, drawn from Philox4x32-10 keyed by
+ * (experiment_seed, year, candidate index).  Device buffers (all [n]):
+ * lon0, lat0, v0, m0, h_bl, slot, phases as tcr_storms; basin_idx (sorted-id
+ * index), seed_flags bit0 = counts toward n_seeds (compute.py:165-167),
+ * bit1 = passed the PI gate (compute.py:168). */
+typedef struct {
+    int64_t n;
+    double *lon0, *lat0, *v0, *m0, *h_bl;
+    int32_t *slot;
+    double *phases;
+    int32_t *basin_idx;
+    int32_t *seed_flags;
+} tcr_seeds;
+int tcr_seed_dev(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t cand0,
+                 const tcr_seeds *out_dev, void *stream);
+int tcr_seed_host(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t cand0,
+                  const tcr_seeds *out_host);
+
+/* ---- single-point probes (parity tests of the seam's leaf methods) -------- */
+/* replaces: Coupled_FAST.dydt (coupled_fast.py:196-207), ._env_winds
+ * (bam_track.py:116-128) and ._calc_alpha (coupled_fast.py:65-94) at n points
+ * of one slot with one forcing table Fs[4][n_steps] (host buffers). */
+int tcr_probe_rhs_host(tcr_ctx *ctx, int slot, double h_bl, const double *Fs, int64_t n,
+                       const double *t, const double *lon, const double *lat,
+                       const double *v, const double *m,
+                       double *dydt /*[n][4]*/, double *envw /*[n][4]*/, double *alpha /*[n]*/);
+/* replaces: gen_f (bam_track.py:23-31): Fs[n][4][n_steps] from phases[n][4][n_series] */
+int tcr_fourier_table_host(tcr_ctx *ctx, int64_t n, const double *phases, double *Fs);
+
+/* ---- measurement ----------------------------------------------------------- */
+/* HIP-event durations (ms) of the kernels of the last tcr_integrate_dev/_host
+ * call on this context: [0] fourier table, [1] integrate, [2] post/unpack.
+ * Enabled by tcr_timing_enable(ctx, 1); reading synchronises the stream. */
+int tcr_timing_enable(tcr_ctx *ctx, int on);
+int tcr_timing_last(tcr_ctx *ctx, double ms[3]);
+int tcr_sync(tcr_ctx *ctx, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCRISK_HIP_H */

@@ -1,0 +1,173 @@
+"""ORACLE (test infrastructure) — ctypes front-end of ``oracle/liborc.so``
+(the plain-C restatement in ``tc_oracle.c``).  Build with ``make -C oracle``.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this.  Field cropping reuses ``scipy_port.crop_to_box`` (the
+oracle's own restatement of util/basins.py:57-75); nothing here imports the
+product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .scipy_port import BASIN_BOUNDS, Params, crop_to_box
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_DP = C.POINTER(C.c_double)
+_IP = C.POINTER(C.c_int)
+
+
+class _Grid(C.Structure):
+    _fields_ = [('nlon', C.c_int), ('nlat', C.c_int), ('lon', _DP), ('lat', _DP)]
+
+
+class _Env(C.Structure):
+    _fields_ = [('wg', _Grid), ('tg', _Grid), ('hg', _Grid),
+                ('mean', _DP * 4), ('cov', _DP * 10),
+                ('vpot', _DP), ('chi', _DP), ('mld', _DP), ('strat', _DP),
+                ('land', _DP), ('bathy', _DP), ('box', C.c_double * 4)]
+
+
+class _Params(C.Structure):
+    _fields_ = [('Ck', C.c_double), ('epsilon', C.c_double), ('kappa', C.c_double),
+                ('u_beta', C.c_double), ('v_beta', C.c_double), ('T_Fs', C.c_double),
+                ('y_alpha', C.c_double * 2), ('m_alpha', C.c_double * 2),
+                ('alpha_max', C.c_double * 2), ('alpha_min', C.c_double * 2),
+                ('dt_out', C.c_double), ('total_time', C.c_double), ('rtol', C.c_double),
+                ('atol', C.c_double), ('max_step', C.c_double),
+                ('v_thresh', C.c_double), ('v_2d_thresh', C.c_double),
+                ('vmax_thresh', C.c_double), ('earth_R', C.c_double),
+                ('n_series', C.c_int), ('n_steps', C.c_int)]
+
+
+def build(force=False):
+    so = os.path.join(HERE, 'liborc.so')
+    src = os.path.join(HERE, 'tc_oracle.c')
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-C', HERE, '-s', 'liborc.so'])
+    return so
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_bilinear.restype = C.c_double
+        _lib.orc_bilinear.argtypes = [C.POINTER(_Grid), _DP, C.c_double, C.c_double]
+        _lib.orc_integrate.restype = C.c_int
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(_DP)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_IP)
+
+
+def c_params(prm=None):
+    prm = prm or Params()
+    p = _Params()
+    for k in ('Ck', 'epsilon', 'kappa', 'u_beta', 'v_beta', 'T_Fs', 'dt_out', 'total_time',
+              'rtol', 'atol', 'max_step', 'v_thresh', 'v_2d_thresh', 'vmax_thresh'):
+        setattr(p, k, float(getattr(prm, k)))
+    for k in ('y_alpha', 'm_alpha', 'alpha_max', 'alpha_min'):
+        setattr(p, k, (C.c_double * 2)(*getattr(prm, k)))
+    p.earth_R = 6.3781e6
+    p.n_series = prm.N_series
+    p.n_steps = prm.n_steps
+    return p
+
+
+class CMonthEnv:
+    """Cropped [lat][lon] planes of one (basin, month) + the C struct pointing at them."""
+
+    def __init__(self, env, basin, month0, bounds=None):
+        b = BASIN_BOUNDS[basin] if bounds is None else bounds
+        keep = []
+
+        def crop(lon, lat, X, nan0=False):
+            lo, la, Xb = crop_to_box(b, lon, lat, X)
+            Xb = np.ascontiguousarray(np.nan_to_num(Xb) if nan0 else Xb, dtype=np.float64)
+            keep.append(Xb)
+            return np.ascontiguousarray(lo, dtype=np.float64), np.ascontiguousarray(la, dtype=np.float64), Xb
+
+        e = _Env()
+        wl, wa, _ = crop(env.wlon, env.wlat, env.wnd_mean[month0, 0])
+        for i in range(4):
+            e.mean[i] = _dp(crop(env.wlon, env.wlat, env.wnd_mean[month0, i], True)[2])
+        for k in range(10):
+            e.cov[k] = _dp(crop(env.wlon, env.wlat, env.wnd_cov[month0, k], True)[2])
+        tl, ta, _ = crop(env.lon, env.lat, env.vpot[month0])
+        for name in ('vpot', 'chi', 'mld', 'strat'):
+            setattr(e, name, _dp(crop(env.lon, env.lat, getattr(env, name)[month0])[2]))
+        hl, ha, _ = crop(env.hlon, env.hlat, env.land)
+        e.land = _dp(crop(env.hlon, env.hlat, env.land)[2])
+        e.bathy = _dp(crop(env.hlon, env.hlat, env.bathy)[2])
+        for g, (lo, la) in zip((e.wg, e.tg, e.hg), ((wl, wa), (tl, ta), (hl, ha))):
+            g.nlon, g.nlat, g.lon, g.lat = lo.size, la.size, _dp(lo), _dp(la)
+        keep += [wl, wa, tl, ta, hl, ha]
+        e.box = (C.c_double * 4)(*b)
+        self.c = e
+        self._keep = keep
+        self.grids = dict(w=(wl, wa), t=(tl, ta), h=(hl, ha))
+
+
+def fourier_table(phases, prm=None):
+    p = c_params(prm)
+    Fs = np.zeros((4, p.n_steps))
+    ph = np.ascontiguousarray(phases, dtype=np.float64)
+    lib().orc_fourier_table(C.byref(p), _dp(ph), _dp(Fs))
+    return Fs
+
+
+def rhs_points(cme, Fs, h_bl, t, lon, lat, v, m, prm=None):
+    p = c_params(prm)
+    n = len(t)
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (t, lon, lat, v, m)]
+    Fs = np.ascontiguousarray(Fs, dtype=np.float64)
+    dydt = np.zeros((n, 4)); envw = np.zeros((n, 4)); alpha = np.zeros(n)
+    lib().orc_rhs_points(C.byref(cme.c), C.byref(p), _dp(Fs), C.c_double(h_bl), C.c_int(n),
+                         *[_dp(a) for a in arrs], _dp(dydt), _dp(envw), _dp(alpha))
+    return dydt, envw, alpha
+
+
+def bilinear(cme, which, plane_name, lon, lat):
+    g = {'w': cme.c.wg, 't': cme.c.tg, 'h': cme.c.hg}[which]
+    plane = getattr(cme.c, plane_name)
+    return np.array([lib().orc_bilinear(C.byref(g), plane, float(a), float(b)) for a, b in zip(lon, lat)])
+
+
+def run_ensemble(env, basin, storms, prm=None, post=True, bounds=None):
+    """Same contract as scipy_port.run_ensemble, plus per-storm step counters."""
+    prm = prm or Params()
+    p = c_params(prm)
+    n = len(storms['lon'])
+    ns = p.n_steps
+    months = np.ascontiguousarray(storms['month'], dtype=np.int32)
+    cmes = {}
+    envs = (C.POINTER(_Env) * 12)()
+    for mo in np.unique(months):
+        cmes[int(mo)] = CMonthEnv(env, basin, int(mo) - 1, bounds)
+        envs[int(mo) - 1] = C.pointer(cmes[int(mo)].c)
+    f64 = lambda k: np.ascontiguousarray(storms[k], dtype=np.float64)
+    lon0, lat0, v0, m0, h_bl, ph = f64('lon'), f64('lat'), f64('v0'), f64('m0'), f64('h_bl'), f64('phases')
+    traj = np.empty((n, 4, ns)); envw = np.empty((n, ns, 4)); vmax = np.empty((n, ns))
+    n_valid = np.zeros(n, np.int32); status = np.zeros(n, np.int32)
+    counters = np.zeros((n, 5), np.int32); flags = np.zeros((n, 2), np.int32)
+    lib().orc_run_ensemble(envs, C.byref(p), C.c_int(n), _dp(lon0), _dp(lat0), _dp(v0), _dp(m0),
+                           _dp(h_bl), _ip(months), _dp(ph), _dp(traj), _dp(envw), _dp(vmax),
+                           _ip(n_valid), _ip(status), _ip(counters), _ip(flags), C.c_int(1 if post else 0))
+    if not post:
+        envw[:] = np.nan; vmax[:] = np.nan
+    return dict(traj=traj, envw=envw, vmax=vmax, n_valid=n_valid, status=status,
+                nfev=counters[:, 0].copy(), n_accept=counters[:, 1].copy(),
+                n_reject=counters[:, 2].copy(), anomaly=counters[:, 3].copy(),
+                flicker=counters[:, 4].copy(),
+                is_tc=flags[:, 0].astype(bool), accepted=flags[:, 1].astype(bool))

@@ -1,0 +1,612 @@
+/*
+ * ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C, scalar, one-storm-at-a-time restatement of the reference hot path,
+ * including the arithmetic that lives in SciPy 1.15.3 / NumPy 2.2.6 (the
+ * reference pins neither; this project pins those versions):
+ *
+ *   bilinear lookup   FITPACK bispeu -> fpbisp/fpbspl with kx=ky=1
+ *                     (scipy/interpolate/fitpack/fpbisp.f, fpbspl.f), i.e. what
+ *                     RectBivariateSpline(kx=1,ky=1).ev does at
+ *                     intensity/coupled_fast.py:37,42,46,51,57,126 and
+ *                     track/bam_track.py:100-103
+ *   Fourier forcing   track/bam_track.py:23-31 (gen_f), 111-113
+ *   linear-in-time    scipy/interpolate/_interpolate.py:457-486 (_call_linear),
+ *                     used at intensity/coupled_fast.py:235
+ *   env winds         track/bam_track.py:93-128 (+ LAPACK dpotrf 'L', unblocked)
+ *   beta advection    track/bam_track.py:131-144, coupled_fast.py:183-192
+ *   intensity RHS     coupled_fast.py:35-58,65-94,115-131,141-150,175-180,196-207
+ *   RK45 + driver     scipy/integrate/_ivp/rk.py:14-181,293-420,552-574;
+ *                     common.py:63-134; base.py step(); ivp.py:654-725;
+ *                     coupled_fast.py:229-267 (gate, event, solve_ivp call)
+ *   post-step         util/compute.py:178-209; wind/tc_wind.py:6-21;
+ *                     util/sphere.py:15-30,58-83
+ *
+ * Parity pin: tests/test_oracle_golden.py checks this file against
+ * tests/golden/*.npz, which hold outputs of the reference's own code.
+ * Build: oracle/Makefile (gcc -O2 -ffp-contract=off; no -ffast-math).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load the resulting liborc.so.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NW 4
+#define NCOV 10
+#define PI_ 3.141592653589793
+
+typedef struct {
+    int nlon, nlat;
+    const double *lon, *lat;
+} orc_grid;
+
+/* One (basin, month) field set, already cropped to the basin box.
+ * Planes are [lat][lon] row-major (the reference's [lat, lon] arrays). */
+typedef struct {
+    orc_grid wg, tg, hg;
+    const double *mean[NW];
+    const double *cov[NCOV];          /* packed lower triangle (0,0),(1,0),(1,1),... */
+    const double *vpot, *chi, *mld, *strat;
+    const double *land, *bathy;
+    double box[4];                    /* lon_min, lat_min, lon_max, lat_max */
+} orc_env;
+
+typedef struct {
+    double Ck, epsilon, kappa, u_beta, v_beta, T_Fs;
+    double y_alpha[2], m_alpha[2], alpha_max[2], alpha_min[2];
+    double dt_out, total_time, rtol, atol, max_step;
+    double v_thresh, v_2d_thresh, vmax_thresh, earth_R;
+    int n_series, n_steps;
+} orc_params;
+
+/* ------------------------------------------------------------------ bilinear */
+static int find_cell(const double *t, int n, double arg)
+{
+    /* fpbisp.f: l such that t(l) <= arg < t(l+1), last cell owns the end knot */
+    int lo = 0, hi = n - 2;
+    if (!(arg >= t[1])) return (arg != arg) ? n - 2 : 0;   /* NaN walks to the last cell */
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (arg >= t[mid]) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+double orc_bilinear(const orc_grid *g, const double *plane, double x, double y)
+{
+    double ax = x, ay = y;
+    if (ax < g->lon[0]) ax = g->lon[0];
+    if (ax > g->lon[g->nlon - 1]) ax = g->lon[g->nlon - 1];
+    if (ay < g->lat[0]) ay = g->lat[0];
+    if (ay > g->lat[g->nlat - 1]) ay = g->lat[g->nlat - 1];
+    int ix = find_cell(g->lon, g->nlon, ax);
+    int iy = find_cell(g->lat, g->nlat, ay);
+    /* fpbspl.f with k = 1 */
+    double fx = 1.0 / (g->lon[ix + 1] - g->lon[ix]);
+    double hx0 = 0.0 + fx * (g->lon[ix + 1] - ax);
+    double hx1 = fx * (ax - g->lon[ix]);
+    double fy = 1.0 / (g->lat[iy + 1] - g->lat[iy]);
+    double hy0 = 0.0 + fy * (g->lat[iy + 1] - ay);
+    double hy1 = fy * (ay - g->lat[iy]);
+    /* fpbisp.f accumulation order: x-outer, y-inner, (c*hx)*hy */
+    const double *r0 = plane + (size_t)iy * g->nlon, *r1 = r0 + g->nlon;
+    double sp = 0.0;
+    sp = sp + r0[ix] * hx0 * hy0;
+    sp = sp + r1[ix] * hx0 * hy1;
+    sp = sp + r0[ix + 1] * hx1 * hy0;
+    sp = sp + r1[ix + 1] * hx1 * hy1;
+    return sp;
+}
+
+/* ----------------------------------------------------------- Fourier forcing */
+static double np_pairwise_sum(const double *a, int n)
+{
+    /* numpy pairwise_sum for n < 128 (numpy/_core/src/umath/loops_utils.h.src) */
+    if (n < 8) {
+        double r = 0.;       /* numpy starts from -0.0; identical for nonzero data */
+        for (int i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    double r[8];
+    for (int j = 0; j < 8; j++) r[j] = a[j];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+/* Fs[4][n_steps] from phases[4][N] (bam_track.py:23-31) */
+void orc_fourier_table(const orc_params *p, const double *phases, double *Fs)
+{
+    int N = p->n_series, ns = p->n_steps;
+    double wgt[64], cub[64];
+    for (int k = 0; k < N; k++) {
+        double n = (double)(k + 1);
+        wgt[k] = pow(n, -1.5);
+        cub[k] = pow(n, -3.0);
+    }
+    double amp = sqrt(2.0 / np_pairwise_sum(cub, N));
+    double two_pi = 2. * PI_;
+    for (int s = 0; s < NW; s++) {
+        for (int i = 0; i < ns; i++) {
+            /* np.linspace(0, T, ns)[i] = i*step (+0); last sample is set to stop */
+            double t = (i == ns - 1) ? p->total_time : (double)i * (p->total_time / (double)(ns - 1));  /* = ts_at */
+            double acc = 0.0;
+            for (int k = 0; k < N; k++) {
+                double n = (double)(k + 1);
+                double arg = two_pi * ((n * t) / p->T_Fs + phases[s * N + k]);
+                double term = wgt[k] * sin(arg);
+                acc = (k == 0) ? term : acc + term;
+            }
+            Fs[s * ns + i] = amp * acc;
+        }
+    }
+}
+
+/* np.linspace(0, total_time, n_steps)[i] */
+static double ts_at(const orc_params *p, int i)
+{
+    if (i == p->n_steps - 1) return p->total_time;
+    return (double)i * (p->total_time / (double)(p->n_steps - 1));
+}
+
+/* interp1d(kind='linear', axis=1) at one time (scipy _call_linear) */
+static void fs_at(const orc_params *p, const double *Fs, double t, double *F)
+{
+    int ns = p->n_steps;
+    double step = p->total_time / (double)(ns - 1);
+    /* searchsorted(t_s, t, side='left'): first idx with t_s[idx] >= t */
+    int idx = (int)ceil(t / step);
+    if (idx < 0) idx = 0;
+    if (idx > ns - 1) idx = ns - 1;
+    while (idx > 0 && ts_at(p, idx - 1) >= t) idx--;
+    while (idx < ns - 1 && ts_at(p, idx) < t) idx++;
+    if (idx < 1) idx = 1;
+    if (idx > ns - 1) idx = ns - 1;
+    int lo = idx - 1, hi = idx;
+    double x_lo = ts_at(p, lo), x_hi = ts_at(p, hi);
+    for (int s = 0; s < NW; s++) {
+        double y_lo = Fs[s * ns + lo], y_hi = Fs[s * ns + hi];
+        double slope = (y_hi - y_lo) / (x_hi - x_lo);
+        F[s] = slope * (t - x_lo) + y_lo;
+    }
+}
+
+/* ------------------------------------------------------------------ env winds */
+/* returns 0 on success, 1 if the Cholesky factorisation failed */
+int orc_env_winds(const orc_env *e, const orc_params *p, const double *Fs,
+                  double lon, double lat, double t, double *w)
+{
+    if (lon != lon || t != t) { w[0] = w[1] = w[2] = w[3] = 0.0; return 0; }
+    double mu[NW], a[NW][NW];
+    int k = 0;
+    for (int i = 0; i < NW; i++) {
+        mu[i] = orc_bilinear(&e->wg, e->mean[i], lon, lat);
+        for (int j = 0; j <= i; j++) a[i][j] = orc_bilinear(&e->wg, e->cov[k++], lon, lat);
+    }
+    /* dpotrf 'L', unblocked, reciprocal scaling of the sub-column */
+    for (int j = 0; j < NW; j++) {
+        double dot = 0.0;
+        for (int q = 0; q < j; q++) dot += a[j][q] * a[j][q];
+        double ajj = a[j][j] - dot;
+        if (ajj <= 0.0 || ajj != ajj) { w[0] = w[1] = w[2] = w[3] = 0.0; return 1; }
+        ajj = sqrt(ajj);
+        a[j][j] = ajj;
+        double rinv = 1.0 / ajj;
+        for (int i = j + 1; i < NW; i++) {
+            double s = 0.0;
+            for (int q = 0; q < j; q++) s += a[i][q] * a[j][q];
+            a[i][j] = (a[i][j] - s) * rinv;
+        }
+    }
+    double F[NW];
+    fs_at(p, Fs, t, F);
+    for (int i = 0; i < NW; i++) {
+        double s = 0.0;
+        for (int j = 0; j < NW; j++) s += (j <= i ? a[i][j] : 0.0) * F[j];
+        w[i] = mu[i] + s;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ RHS */
+typedef struct {
+    const orc_env *e;
+    const orc_params *p;
+    const double *Fs;
+    double h_bl;
+    long nfev;
+    long flicker;   /* diagnostics only: RHS evaluations whose `land == 1` test is decided by rounding */
+} orc_storm;
+
+static void steering(const orc_params *p, double v, double *c)
+{
+    int bad = 0;
+    for (int k = 0; k < 2; k++) {
+        double a = (v * 1.94384) * p->m_alpha[k] + p->y_alpha[k];
+        a = (a != a) ? a : (a < p->alpha_max[k] ? a : p->alpha_max[k]);
+        a = (a != a) ? a : (a > p->alpha_min[k] ? a : p->alpha_min[k]);
+        if (a != a) bad = 1;
+        c[k] = a;
+    }
+    if (bad) { c[0] = p->y_alpha[0]; c[1] = p->y_alpha[1]; }
+}
+
+static double sgn(double x) { return (x > 0) - (x < 0) + (x != x ? x : 0.0); }
+
+static double vpot_here(const orc_env *e, double lon, double lat)
+{
+    if (orc_bilinear(&e->hg, e->land, lon, lat) == 1.0) return 0.0;
+    return orc_bilinear(&e->tg, e->vpot, lon, lat);
+}
+
+/* Diagnostics (not part of the restated algorithm): the reference's over-land test
+ * `f_land.ev(lon, lat) == 1` (coupled_fast.py:35-38) is evaluated on a bilinear sum
+ * whose weights only add up to 1 within rounding, so in the interior of land it is
+ * True or False depending on the last bits of lon/lat (about 1.5 % False).  When the
+ * interpolated PI is non-zero there, the RHS is discontinuous in those last bits and
+ * no two libm/BLAS builds can be expected to agree.  Tests use this counter to give
+ * such storms the looser tolerance. */
+static int flicker_exposed(const orc_env *e, double lon, double lat)
+{
+    double l = orc_bilinear(&e->hg, e->land, lon, lat);
+    if (fabs(l - 1.0) > 1e-12) return 0;
+    return orc_bilinear(&e->tg, e->vpot, lon, lat) != 0.0;
+}
+
+static double ocean_alpha(const orc_storm *s, double lon, double lat, const double *vb, double v)
+{
+    const orc_env *e = s->e;
+    double h_m = orc_bilinear(&e->tg, e->mld, lon, lat);
+    double gam = orc_bilinear(&e->tg, e->strat, lon, lat);
+    double vp = vpot_here(e, lon, lat);
+    double uT = sqrt(vb[0] * vb[0] + vb[1] * vb[1]);
+    double bathy = orc_bilinear(&e->hg, e->bathy, lon, lat);
+    if (bathy >= 0 || -h_m <= bathy || gam == 0) return 1.0;
+    double z = 0.01 * pow(gam, -0.4) * h_m * uT * vp / v;
+    double zc = (z != z) ? z : (z > 0 ? z : 0.0);
+    zc = (zc != zc) ? zc : (zc < 100 ? zc : 100.0);
+    return 1 - 0.87 * exp(-zc);
+}
+
+void orc_rhs(orc_storm *s, double t, const double *y, double *dy, double *w_out)
+{
+    const orc_params *p = s->p;
+    const orc_env *e = s->e;
+    s->nfev++;
+    double lon = y[0], lat = y[1], v = y[2], m = y[3];
+    double c[2], vb[2], w[NW];
+    s->flicker += flicker_exposed(e, lon, lat);
+    steering(p, v, c);
+    if (fabs(lat) >= 80) {
+        vb[0] = vb[1] = 0.0; w[0] = w[1] = w[2] = w[3] = 0.0;
+    } else {
+        orc_env_winds(e, p, s->Fs, lon, lat, t, w);
+        double cl = cos(lat * (PI_ / 180.0));                    /* np.deg2rad */
+        vb[0] = (w[0] * c[0] + w[2] * c[1]) + p->u_beta * cl;
+        vb[1] = (w[1] * c[0] + w[3] * c[1]) + (sgn(lat) * p->v_beta) * cl;
+    }
+    dy[0] = vb[0] / p->earth_R * 180. / PI_ / cos(lat * PI_ / 180.);
+    dy[1] = vb[1] / p->earth_R * 180. / PI_;
+    double vp = vpot_here(e, lon, lat);
+    double al = ocean_alpha(s, lon, lat, vb, v);
+    double beta = 1 - p->epsilon - p->kappa;
+    double gamma = p->epsilon + al * p->kappa;
+    double m3 = pow(m, 3.0);
+    double dv = 0.5 * p->Ck / s->h_bl * (al * beta * pow(vp, 2.0) * m3 - (1 - gamma * m3) * pow(v, 2.0));
+    if (dv != dv) dv = 0.0;
+    double du = w[0] - w[2], dvv = w[1] - w[3];
+    double S = sqrt(du * du + dvv * dvv);
+    double venti = S * orc_bilinear(&e->tg, e->chi, lon, lat);
+    dy[2] = dv;
+    dy[3] = 0.5 * p->Ck / s->h_bl * ((1 - m) * v - venti * m);
+    if (w_out) memcpy(w_out, w, sizeof w);
+}
+
+/* standalone entry points for RHS-level parity tests */
+void orc_rhs_points(const orc_env *e, const orc_params *p, const double *Fs, double h_bl, int n,
+                    const double *t, const double *lon, const double *lat, const double *v,
+                    const double *m, double *dydt, double *envw, double *alpha)
+{
+    orc_storm s = { e, p, Fs, h_bl, 0, 0 };
+    for (int i = 0; i < n; i++) {
+        double y[4] = { lon[i], lat[i], v[i], m[i] };
+        orc_rhs(&s, t[i], y, dydt + 4 * i, NULL);
+        orc_env_winds(e, p, Fs, lon[i], lat[i], t[i], envw + 4 * i);
+        double c[2], vb[2] = { 0, 0 }, w[NW];
+        steering(p, v[i], c);
+        if (fabs(lat[i]) < 80) {
+            orc_env_winds(e, p, Fs, lon[i], lat[i], t[i], w);
+            double cl = cos(lat[i] * (PI_ / 180.0));
+            vb[0] = (w[0] * c[0] + w[2] * c[1]) + p->u_beta * cl;
+            vb[1] = (w[1] * c[0] + w[3] * c[1]) + (sgn(lat[i]) * p->v_beta) * cl;
+        }
+        alpha[i] = ocean_alpha(&s, lon[i], lat[i], vb, v[i]);
+    }
+}
+
+/* -------------------------------------------------------------------- RK45 */
+static const double RK_C[6] = { 0, 1. / 5, 3. / 10, 4. / 5, 8. / 9, 1 };
+static const double RK_A[6][5] = {
+    { 0, 0, 0, 0, 0 },
+    { 1. / 5, 0, 0, 0, 0 },
+    { 3. / 40, 9. / 40, 0, 0, 0 },
+    { 44. / 45, -56. / 15, 32. / 9, 0, 0 },
+    { 19372. / 6561, -25360. / 2187, 64448. / 6561, -212. / 729, 0 },
+    { 9017. / 3168, -355. / 33, 46732. / 5247, 49. / 176, -5103. / 18656 } };
+static const double RK_B[6] = { 35. / 384, 0, 500. / 1113, 125. / 192, -2187. / 6784, 11. / 84 };
+static const double RK_E[7] = { -71. / 57600, 0, 71. / 16695, -71. / 1920, 17253. / 339200, -22. / 525, 1. / 40 };
+static const double RK_P[7][4] = {
+    { 1, -8048581381. / 2820520608, 8663915743. / 2820520608, -12715105075. / 11282082432 },
+    { 0, 0, 0, 0 },
+    { 0, 131558114200. / 32700410799, -68118460800. / 10900136933, 87487479700. / 32700410799 },
+    { 0, -1754552775. / 470086768, 14199869525. / 1410260304, -10690763975. / 1880347072 },
+    { 0, 127303824393. / 49829197408, -318862633887. / 49829197408, 701980252875. / 199316789632 },
+    { 0, -282668133. / 205662961, 2019193451. / 616988883, -1453857185. / 822651844 },
+    { 0, 40617522. / 29380423, -110615467. / 29380423, 69997945. / 29380423 } };
+
+static double rms4(const double *x)
+{
+    /* np.linalg.norm(x) / x.size ** 0.5 */
+    return sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]) / 2.0;
+}
+
+static double event_fn(const orc_env *e, const double *y)
+{
+    /* coupled_fast.py:246-256 with util/basins.py:32-37 (dx = 1) */
+    int inside = (e->box[0] + 1 < y[0]) && (y[0] < e->box[2] - 1) &&
+                 (e->box[1] + 1 < y[1]) && (y[1] < e->box[3] - 1);
+    if (!inside) return 0.0;
+    if (fabs(y[1]) <= 2) return 0.0;
+    double g = y[2] - 4;
+    return g > 0 ? g : 0.0;
+}
+
+/*
+ * Integrate one storm.  Outputs traj[4][n_steps] (NaN beyond n_valid).
+ * status: -1 gated (gen_track returned None), 0 reached 15 d, 1 terminal event,
+ *         -2 step size underflow (solve_ivp status -1).
+ * counters[0]=nfev, [1]=accepted steps, [2]=rejected attempts, [3]=brentq sign
+ *          anomaly (dense output at the step end disagrees with y_new about the event),
+ *          [4]=RHS evaluations exposed to the `land == 1` rounding flicker (diagnostic).
+ */
+int orc_integrate(const orc_env *e, const orc_params *p, double lon0, double lat0, double v0,
+                  double m0, double h_bl, const double *phases, double *traj, int *n_valid,
+                  int *counters, double *Fs_out)
+{
+    int ns = p->n_steps;
+    double *Fs = Fs_out ? Fs_out : (double *)malloc(sizeof(double) * NW * ns);
+    orc_fourier_table(p, phases, Fs);
+    orc_storm s = { e, p, Fs, h_bl, 0, 0 };
+    int status;
+    long nacc = 0, nrej = 0, anomaly = 0;
+    *n_valid = 0;
+    for (int i = 0; i < 4 * ns; i++) traj[i] = NAN;
+
+    /* ventilation gate (coupled_fast.py:238-244) */
+    {
+        double w[NW];
+        orc_env_winds(e, p, Fs, lon0, lat0, 0.0, w);
+        double du = w[0] - w[2], dv = w[1] - w[3];
+        double S = sqrt(du * du + dv * dv);
+        double vp = vpot_here(e, lon0, lat0);
+        double chi = orc_bilinear(&e->tg, e->chi, lon0, lat0);
+        if (vp > 0 && S * chi / vp >= 1) { status = -1; goto done; }
+    }
+    {
+        double t = 0.0, tb = p->total_time, y[4] = { lon0, lat0, v0, m0 }, f[4], K[7][4];
+        /* RungeKutta.__init__: f0 and select_initial_step (common.py:68-134) */
+        orc_rhs(&s, t, y, f, NULL);
+        double h_abs;
+        {
+            double sc[4], a[4], b[4];
+            for (int i = 0; i < 4; i++) { sc[i] = p->atol + fabs(y[i]) * p->rtol; a[i] = y[i] / sc[i]; b[i] = f[i] / sc[i]; }
+            double d0 = rms4(a), d1 = rms4(b), h0;
+            if (d0 < 1e-5 || d1 < 1e-5) h0 = 1e-6; else h0 = 0.01 * d0 / d1;
+            if (h0 > tb) h0 = tb;
+            double y1[4], f1[4], c[4];
+            for (int i = 0; i < 4; i++) y1[i] = y[i] + h0 * 1.0 * f[i];
+            orc_rhs(&s, t + h0 * 1.0, y1, f1, NULL);
+            for (int i = 0; i < 4; i++) c[i] = (f1[i] - f[i]) / sc[i];
+            double d2 = rms4(c) / h0, h1;
+            if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
+            else h1 = pow(0.01 / fmax(d1, d2), 1.0 / 5.0);
+            h_abs = fmin(fmin(100 * h0, h1), fmin(tb, p->max_step));
+        }
+        double g = event_fn(e, y);
+        int next_out = 0;                    /* t_eval_i */
+        status = 99;
+        while (status == 99) {
+            /* OdeSolver.step(): t == t_bound cannot happen before 'finished' */
+            double min_step = 10 * fabs(nextafter(t, INFINITY) - t);
+            double ha = h_abs;
+            if (ha > p->max_step) ha = p->max_step; else if (ha < min_step) ha = min_step;
+            int accepted = 0, rejected = 0, failed = 0;
+            double h = 0, t_new = 0, y_new[4], f_new[4];
+            while (!accepted) {
+                if (ha < min_step) { failed = 1; break; }
+                h = ha;
+                t_new = t + h;
+                if (t_new - tb > 0) t_new = tb;
+                h = t_new - t;
+                ha = fabs(h);
+                /* rk_step (rk.py:14-79) */
+                memcpy(K[0], f, sizeof f);
+                for (int st = 1; st < 6; st++) {
+                    double ys[4];
+                    for (int i = 0; i < 4; i++) {
+                        double dy = 0.0;
+                        for (int j = 0; j < st; j++) dy += K[j][i] * RK_A[st][j];
+                        ys[i] = y[i] + dy * h;
+                    }
+                    orc_rhs(&s, t + RK_C[st] * h, ys, K[st], NULL);
+                }
+                for (int i = 0; i < 4; i++) {
+                    double acc = 0.0;
+                    for (int j = 0; j < 6; j++) acc += K[j][i] * RK_B[j];
+                    y_new[i] = y[i] + h * acc;
+                }
+                orc_rhs(&s, t + h, y_new, f_new, NULL);
+                memcpy(K[6], f_new, sizeof f_new);
+                double er[4];
+                for (int i = 0; i < 4; i++) {
+                    double sc = p->atol + fmax(fabs(y[i]), fabs(y_new[i])) * p->rtol;
+                    double acc = 0.0;
+                    for (int j = 0; j < 7; j++) acc += K[j][i] * RK_E[j];
+                    er[i] = (acc * h) / sc;
+                }
+                double err = rms4(er);
+                if (err < 1) {
+                    double fac = (err == 0) ? 10.0 : fmin(10.0, 0.9 * pow(err, -0.2));
+                    if (rejected && fac > 1) fac = 1;
+                    ha *= fac;
+                    accepted = 1;
+                } else {
+                    ha *= fmax(0.2, 0.9 * pow(err, -0.2));
+                    rejected = 1;
+                    nrej++;
+                }
+            }
+            if (failed) { status = -2; break; }
+            nacc++;
+            double t_old = t, y_old[4];
+            memcpy(y_old, y, sizeof y);
+            t = t_new; memcpy(y, y_new, sizeof y); memcpy(f, f_new, sizeof f);
+            h_abs = ha;
+            if (t - tb >= 0) status = 0;
+            /* dense output Q = K^T P (rk.py:179-181) */
+            double Q[4][4];
+            for (int i = 0; i < 4; i++)
+                for (int k = 0; k < 4; k++) {
+                    double acc = 0.0;
+                    for (int j = 0; j < 7; j++) acc += K[j][i] * RK_P[j][k];
+                    Q[i][k] = acc;
+                }
+            /* events (ivp.py:673-693); g >= 0 always */
+            double g_new = event_fn(e, y);
+            double t_emit = t;
+            int terminate = 0;
+            if (g == 0.0) { terminate = 1; t_emit = t_old; }       /* brentq: f(a)==0 -> a */
+            else if (g_new == 0.0) {
+                terminate = 1;                                       /* brentq: f(b)==0 -> b */
+                double ye[4];
+                for (int i = 0; i < 4; i++) ye[i] = y_old[i] + h * (Q[i][0] + Q[i][1] + Q[i][2] + Q[i][3]);
+                if (event_fn(e, ye) != 0.0) anomaly++;
+            }
+            g = g_new;
+            if (terminate) status = 1;
+            /* t_eval emission (ivp.py:706-723): all samples <= t_emit not yet written */
+            while (next_out < ns) {
+                double te = ts_at(p, next_out);
+                if (te > t_emit) break;
+                double x = (te - t_old) / h;
+                double pw[4] = { x, 0, 0, 0 };
+                pw[1] = pw[0] * x; pw[2] = pw[1] * x; pw[3] = pw[2] * x;
+                for (int i = 0; i < 4; i++) {
+                    double acc = 0.0;
+                    for (int k = 0; k < 4; k++) acc += Q[i][k] * pw[k];
+                    traj[i * ns + next_out] = h * acc + y_old[i];
+                }
+                next_out++;
+            }
+        }
+        *n_valid = next_out;
+    }
+done:
+    if (counters) { counters[0] = (int)s.nfev; counters[1] = (int)nacc; counters[2] = (int)nrej; counters[3] = (int)anomaly; counters[4] = (int)s.flicker; }
+    if (status == -1) { if (counters) counters[0] = 0; }
+    if (!Fs_out) free(Fs);
+    return status;
+}
+
+/* ---------------------------------------------------------------- post-step */
+static double haversine_km(const orc_params *p, double lon1, double lat1, double lon2, double lat2)
+{
+    double d = PI_ / 180.0;
+    lon1 *= d; lat1 *= d; lon2 *= d; lat2 *= d;
+    double sa = sin((lat2 - lat1) / 2), sb = sin((lon2 - lon1) / 2);
+    double a = sa * sa + cos(lat1) * cos(lat2) * (sb * sb);
+    return (p->earth_R / 1000.) * (2 * asin(sqrt(a)));
+}
+
+/* env winds at the emitted samples, vmax, accept flags (compute.py:185-209) */
+void orc_post(const orc_env *e, const orc_params *p, const double *Fs, int status, int n,
+              const double *traj, double *envw, double *vmax, int *flags)
+{
+    int ns = p->n_steps;
+    const double *lon = traj, *lat = traj + ns, *v = traj + 2 * ns;
+    flags[0] = flags[1] = 0;
+    for (int i = 0; i < ns; i++) { vmax[i] = NAN; for (int k = 0; k < 4; k++) envw[4 * i + k] = NAN; }
+    if (status < 0 && status != -2) return;
+    if (n <= 0) return;
+    int any15 = 0;
+    for (int i = 0; i < n; i++) if (v[i] >= p->v_thresh) any15 = 1;
+    /* np.interp(172800, res.t, v): clamps to the last sample of a short track */
+    double t2d = 2 * 86400.0, v2d;
+    if (t2d >= ts_at(p, n - 1)) v2d = v[n - 1];
+    else {
+        int j = (int)floor(t2d / (p->total_time / (double)(ns - 1)));
+        while (j > 0 && ts_at(p, j) > t2d) j--;
+        while (j < n - 2 && ts_at(p, j + 1) <= t2d) j++;
+        double sl = (v[j + 1] - v[j]) / (ts_at(p, j + 1) - ts_at(p, j));
+        v2d = sl * (t2d - ts_at(p, j)) + v[j];
+    }
+    flags[0] = any15 && (v2d >= p->v_2d_thresh);
+    for (int i = 0; i < n; i++) {
+        double te = ts_at(p, i);
+        orc_env_winds(e, p, Fs, lon[i], lat[i], te, envw + 4 * i);
+    }
+    if (n == 1) return;                    /* translation speed undefined -> NaN vmax */
+    double best = -INFINITY;
+    for (int i = 0; i < n; i++) {
+        /* util/sphere.py:58-83: linear extrapolation at both ends, centred differences */
+        double lom = (i == 0) ? 2 * lon[0] - lon[1] : lon[i - 1];
+        double lam = (i == 0) ? 2 * lat[0] - lat[1] : lat[i - 1];
+        double lop = (i == n - 1) ? 2 * lon[n - 1] - lon[n - 2] : lon[i + 1];
+        double lap = (i == n - 1) ? 2 * lat[n - 1] - lat[n - 2] : lat[i + 1];
+        double dlon = 0.5 * (sgn(lop - lom) * haversine_km(p, lop, lat[i], lom, lat[i]));
+        double dlat = 0.5 * (sgn(lap - lam) * haversine_km(p, lon[i], lap, lon[i], lam));
+        double ut = dlon * 1000. / p->dt_out, vt = dlat * 1000. / p->dt_out;
+        /* wind/tc_wind.py:6-21 */
+        double G = fmin(1., 0.8 + 0.35 * (1. + tanh((lat[i] - 35.) / 10.)));
+        const double *w = envw + 4 * i;
+        double Ui = G * ut + 0.1 * (w[0] - w[2]) * v[i] / 15.;
+        double Vi = G * vt + 0.1 * (w[1] - w[3]) * v[i] / 15.;
+        double mag = sqrt(Ui * Ui + Vi * Vi);
+        double q = (v[i] * 0.50) / mag;
+        double fac = (q != q) ? q : (q < 1 ? q : 1.0);          /* np.minimum propagates NaN */
+        double th = atan2(-Ui, Vi);
+        double ug = v[i] * -sin(th) + Ui * fac;
+        double vg = v[i] * cos(th) + Vi * fac;
+        vmax[i] = sqrt(ug * ug + vg * vg);
+        if (vmax[i] > best) best = vmax[i];
+    }
+    flags[1] = flags[0] && (best >= p->vmax_thresh);
+}
+
+/* Whole ensemble, storm-major outputs.  env_of_month[12] may contain NULLs for unused months. */
+void orc_run_ensemble(const orc_env *const *env_of_month, const orc_params *p, int n,
+                      const double *lon0, const double *lat0, const double *v0, const double *m0,
+                      const double *h_bl, const int *month, const double *phases,
+                      double *traj, double *envw, double *vmax, int *n_valid, int *status,
+                      int *counters, int *flags, int do_post)
+{
+    int ns = p->n_steps;
+    double *Fs = (double *)malloc(sizeof(double) * NW * ns);
+    for (int i = 0; i < n; i++) {
+        const orc_env *e = env_of_month[month[i] - 1];
+        double *tr = traj + (size_t)i * 4 * ns;
+        status[i] = orc_integrate(e, p, lon0[i], lat0[i], v0[i], m0[i], h_bl[i],
+                                  phases + (size_t)i * NW * p->n_series, tr, n_valid + i,
+                                  counters + 5 * i, Fs);
+        if (do_post)
+            orc_post(e, p, Fs, status[i], n_valid[i], tr, envw + (size_t)i * ns * 4,
+                     vmax + (size_t)i * ns, flags + 2 * i);
+    }
+    free(Fs);
+}

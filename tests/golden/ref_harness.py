@@ -1,0 +1,153 @@
+"""Drive the *actual* reference hot path in the build container.
+
+Only usable where /root/reference exists (never on the GPU box, never imported
+by tests): `make_golden.py` uses it to produce the committed .npz fixtures.
+
+The reference imports xarray/dask/cftime at module level but only *uses* them in
+constructors/readers, so empty stub modules are enough to import it; the object
+is then assembled attribute-by-attribute exactly as `BetaAdvectionTrack.__init__`
+(`track/bam_track.py:49-69`) and `Coupled_FAST.__init__`
+(`intensity/coupled_fast.py:19-32`) would, and the reference's own
+`init_fields`, `gen_track`, `dydt`, `_env_winds`, `axi_to_max_wind` run unmodified.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = '/root/reference'
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+    for name in ('xarray', 'dask', 'cftime', 'global_land_mask'):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import namelist                      # noqa: F401  (the reference's)
+    from intensity import coupled_fast
+    from track import bam_track, env_wind
+    from util import basins, mat, sphere
+    from wind import tc_wind
+    # neutralise the wall-clock reseed (bam_track.py:37-42); the call site
+    # resolves it through the module attribute (coupled_fast.py:231)
+    bam_track.random_seed = lambda: None
+    return types.SimpleNamespace(namelist=namelist, coupled_fast=coupled_fast,
+                                 bam_track=bam_track, env_wind=env_wind,
+                                 basins=basins, mat=mat, sphere=sphere,
+                                 tc_wind=tc_wind)
+
+
+def build_coupled_fast(ref, env, basin_id, month, dt_s=3600, total_time_s=15 * 86400):
+    """Assemble a reference Coupled_FAST for one month of a SyntheticEnv."""
+    from scipy.interpolate import RectBivariateSpline
+    nl = ref.namelist
+    f = ref.coupled_fast.Coupled_FAST.__new__(ref.coupled_fast.Coupled_FAST)
+    b = ref.basins.TC_Basin(basin_id)
+    # --- BetaAdvectionTrack.__init__ state
+    f.fn_wnd_stat = None
+    f.dt_track = dt_s
+    f.total_time = total_time_s
+    f.total_steps = int(total_time_s / dt_s) + 1
+    f.t_s = np.linspace(0, total_time_s, f.total_steps)
+    f.T_Fs = nl.T_days * 24 * 60 * 60
+    f.u_beta = nl.u_beta
+    f.v_beta = nl.v_beta
+    f.nLvl = len(nl.steering_levels)
+    f.nWLvl = f.nLvl * 2
+    f.dt_start = None
+    f.basin = b
+    f.var_names = ref.env_wind.wind_mean_vector_names()
+    f.u_Mean_idxs = np.array([f.var_names.index('ua%d_Mean' % p) for p in nl.steering_levels])
+    f.v_Mean_idxs = np.array([f.var_names.index('va%d_Mean' % p) for p in nl.steering_levels])
+    import datetime
+    f.datetime_start = datetime.datetime(2000, month + 1, 15)
+    f.wnd_lon = env.wlon
+    f.wnd_lat = env.wlat
+    cov = env.cov_matrix(month)
+    f.wnd_Mean_Fxs = [f._interp_basin_field(env.wnd_mean[month, i]) for i in range(4)]
+    f.wnd_Cov_Fxs = [['' for _ in range(4)] for _ in range(4)]
+    for i in range(4):
+        for j in range(i + 1):
+            f.wnd_Cov_Fxs[i][j] = f._interp_basin_field(cov[i, j])
+    # --- Coupled_FAST.__init__ state
+    f.Ck = nl.Ck
+    f.h_bl = nl.atm_bl_depth
+    f.epsilon = 0.33
+    f.kappa = 0.1
+    f.beta = 1 - f.epsilon - f.kappa
+    f.debug = False
+    lon_b, lat_b, bath_b = b.transform_global_field(env.hlon, env.hlat, env.bathy)
+    f.f_bath = RectBivariateSpline(lon_b, lat_b, bath_b.T, kx=1, ky=1)      # geo.py:18-19
+    lon_b, lat_b, land_b = b.transform_global_field(env.hlon, env.hlat, env.land)
+    f.f_land = RectBivariateSpline(lon_b, lat_b, land_b.T, kx=1, ky=1)      # geo.py:32-33
+    f.init_fields(env.lon, env.lat, env.chi[month], env.vpot[month],
+                  env.mld[month], env.strat[month])
+    return f
+
+
+def phases_to_uniform_stream(phases):
+    """gen_f draws N uniforms per series in order (bam_track.py:27): series-major."""
+    return np.asarray(phases, dtype=np.float64).reshape(-1)
+
+
+class InjectedRandom:
+    """Context manager that makes np.random.rand(N,1) return injected phases."""
+
+    def __init__(self, phases):
+        self.stream = list(np.asarray(phases, dtype=np.float64))   # [4][15]
+        self.i = 0
+
+    def __enter__(self):
+        self._orig = np.random.rand
+        def fake_rand(*shape):
+            out = np.asarray(self.stream[self.i]).reshape(shape)
+            self.i += 1
+            return out
+        np.random.rand = fake_rand
+        return self
+
+    def __exit__(self, *a):
+        np.random.rand = self._orig
+
+
+def gen_track(ref, f, lon, lat, v0, m0, h_bl, phases):
+    """Run the reference gen_track with injected Fourier phases.
+
+    Returns dict(status, n, t, y[4,n], nfev) with status -1 for a gated seed.
+    """
+    f.h_bl = h_bl
+    with InjectedRandom(phases):
+        res = f.gen_track(lon, lat, v0, m0)
+    if res is None:
+        return dict(status=-1, n=0, t=np.zeros(0), y=np.zeros((4, 0)), nfev=0)
+    return dict(status=int(res.status), n=int(res.t.size), t=res.t, y=res.y,
+                nfev=int(res.nfev))
+
+
+def post_track(ref, f, res):
+    """compute.py:185-209 for one candidate: accept tests, env winds, vmax."""
+    nl = ref.namelist
+    n = res['n']
+    out = dict(is_tc=False, accepted=False, envw=np.zeros((n, 4)), vmax=np.full(n, np.nan))
+    if res['status'] < 0:
+        return out
+    v = res['y'][2]
+    v2d = np.interp(2 * 24 * 60 * 60, res['t'], v.flatten())
+    out['is_tc'] = bool(np.logical_and(np.any(v >= nl.seed_v_threshold_ms),
+                                       v2d >= nl.seed_v_2d_threshold_ms))
+    envw = np.zeros((n, 4))
+    for i in range(n):
+        envw[i] = f._env_winds(res['y'][0][i], res['y'][1][i], f.t_s[i])
+    out['envw'] = envw
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        vmax = ref.tc_wind.axi_to_max_wind(res['y'][0], res['y'][1], f.dt_track, v, envw)
+        out['vmax'] = np.asarray(vmax).reshape(-1)
+        out['accepted'] = bool(out['is_tc'] and n > 0 and
+                               np.nanmax(out['vmax']) >= nl.seed_vmax_threshold_ms)
+    return out

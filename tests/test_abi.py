@@ -1,0 +1,65 @@
+"""The C-ABI library builds for gfx950, loads, and exports every symbol that
+include/tcrisk_hip.h declares.  No compute calls (CPU-only container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, 'include', 'tcrisk_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(tcr_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_header_and_binding_agree():
+    from tropical_cyclone_risk_amd import _lib
+    assert sorted(_lib.EXPORTS) == _declared()
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    L = ctypes.CDLL(built_lib)
+    for name in _declared():
+        assert hasattr(L, name), name
+    assert L.tcr_abi_version() == 1
+
+
+def test_struct_layout_matches_header(built_lib):
+    """sizeof(tcr_params) as compiled by a C compiler == ctypes mirror."""
+    import subprocess
+    import tempfile
+    from tropical_cyclone_risk_amd import _lib
+    src = ('#include <stdio.h>\n#include "tcrisk_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n",'
+           'sizeof(tcr_params),sizeof(tcr_storms),sizeof(tcr_tracks),sizeof(tcr_seeds),sizeof(tcr_grid));return 0;}\n')
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, 'sz.c')
+        open(c, 'w').write(src)
+        exe = os.path.join(d, 'sz')
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe])
+        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    mine = [ctypes.sizeof(t) for t in (_lib.Params, _lib.Storms, _lib.Tracks, _lib.Seeds, _lib.Grid)]
+    assert sizes == mine
+
+
+def test_no_gpu_fails_loudly(built_lib):
+    """Without a HIP device the product path must raise, not fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    from tropical_cyclone_risk_amd import _lib
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    with pytest.raises(_lib.TcrError) as e:
+        TCEngine('NA')
+    assert 'no CPU fallback' in str(e.value) or 'HIP' in str(e.value)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'tropical_cyclone_risk_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.h', '.cpp')):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert 'oracle' not in re.sub(r'#.*|//.*', '', text).replace('"oracle"', ''), (dirpath, fn)

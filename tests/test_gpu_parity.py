@@ -1,0 +1,130 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against
+(a) the committed golden vectors produced by the reference's own code and
+(b) the C oracle on larger seeded ensembles.
+
+Stated fp64 tolerance.  The reference integrates adaptively, so ulp-level libm /
+summation-order differences are amplified along a trajectory, and its over-land
+test ``f_land.ev(lon, lat) == 1`` (intensity/coupled_fast.py:35-38) is decided by
+rounding in the interior of land ("flicker", see oracle/tc_oracle.c).  The bar:
+  * storms never exposed to the flicker: discrete results (status, n_valid, nfev,
+    accepted / rejected step counts, accept flags) identical, |Δ| <= 1e-8 on
+    lon/lat/v/m/env winds/vmax for all and <= 1e-10 for 95 % of them;
+  * exposed storms (their RHS jumps between PI and 0 with the last bit of lon/lat,
+    so no two libm builds can agree once a flip happens): only a statistical bar —
+    at least 65 % of them still agree to 1e-6 (a flip needs one of the ~1.5 %
+    rounding cases to land differently), and they must stay a minority.
+"""
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+pytestmark = pytest.mark.gpu
+
+TOL_CLEAN = 1e-8
+TOL_CLEAN_95 = 1e-10
+TOL_EXPOSED = 1e-6
+MIN_EXPOSED_OK = 0.65
+
+
+def _storms(g):
+    return dict(lon=g['lon0'], lat=g['lat0'], v0=g['v0'], m0=g['m0'], h_bl=g['h_bl'],
+                month=g['month'], phases=g['phases'])
+
+
+def _maxdiff_per_storm(a, b):
+    n = a.shape[0]
+    assert np.array_equal(np.isnan(a), np.isnan(b)), 'NaN padding differs'
+    d = np.abs(np.nan_to_num(a) - np.nan_to_num(b)).reshape(n, -1)
+    return d.max(axis=1) if d.size else np.zeros(n)
+
+
+def _check(tag, got, want, exposed):
+    clean = ~exposed
+    for key in ('status', 'n_valid', 'nfev'):
+        assert np.array_equal(got[key][clean], want[key][clean]), (tag, key)
+    for key in ('is_tc', 'accepted'):
+        assert np.array_equal(got[key][clean], want[key][clean]), (tag, key)
+    for name in ('traj', 'envw', 'vmax'):
+        d = _maxdiff_per_storm(got[name][clean], want[name][clean])
+        print('%s %-5s clean: max %.3g  p95 %.3g   (n=%d)' % (tag, name, d.max(), np.percentile(d, 95), d.size))
+        assert d.max() <= TOL_CLEAN, (tag, name, d.max())
+        assert np.percentile(d, 95) <= TOL_CLEAN_95, (tag, name)
+        if exposed.any():
+            ok = (got['n_valid'] == want['n_valid']) & exposed
+            de = _maxdiff_per_storm(got[name][ok], want[name][ok])
+            print('%s %-5s exposed: max %.3g (n=%d)' % (tag, name, de.max() if de.size else 0, ok.sum()))
+            frac_ok = ((de <= TOL_EXPOSED).sum() + 0.0) / max(1, exposed.sum())
+            print('%s %-5s exposed: %.1f %% within %g' % (tag, name, 100 * frac_ok, TOL_EXPOSED))
+            assert frac_ok >= MIN_EXPOSED_OK or exposed.sum() < 8, (tag, name, frac_ok)
+
+
+@pytest.fixture(scope='module')
+def engines(golden_env, built_lib):
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    cache = {}
+
+    def get(basin):
+        if basin not in cache:
+            cache[basin] = TCEngine(basin, device=0).stage_env(golden_env)
+        return cache[basin]
+    yield get
+    for e in cache.values():
+        e.close()
+
+
+@pytest.mark.parametrize('basin', ['NA', 'AU', 'GL'])
+def test_tracks_vs_reference_golden(engines, golden_env, basin):
+    from oracle import c_oracle
+    g = np.load(os.path.join(GOLDEN, 'tracks_%s.npz' % basin))
+    out = engines(basin).integrate(_storms(g))
+    exposed = c_oracle.run_ensemble(golden_env, basin, _storms(g), post=False)['flicker'] > 0
+    assert exposed.mean() < 0.5
+    _check('golden-' + basin, out, g, exposed)
+
+
+@pytest.mark.parametrize('name,slot', [('NA', 8), ('SI', 1)])
+def test_rhs_vs_reference_golden(engines, name, slot):
+    g = np.load(os.path.join(GOLDEN, 'rhs_%s.npz' % name))
+    eng = engines(name)
+    dydt, envw, alpha = eng.probe_rhs(slot, float(g['h_bl']), g['Fs'], g['t'], g['lon'], g['lat'], g['v'], g['m'])
+    scale = np.abs(g['dydt']).max(axis=0)
+    assert (np.abs(dydt - g['dydt']) / scale).max() < 1e-13
+    assert np.abs(envw - g['envw']).max() < 1e-12
+    assert np.abs(alpha - g['alpha']).max() < 1e-13
+    Fs = eng.fourier_table(g['phases'][None])[0]
+    assert np.abs(Fs - g['Fs']).max() < 5e-15
+
+
+@pytest.mark.parametrize('basin,n,seed', [('NA', 4000, 77), ('GL', 2000, 78), ('SI', 1000, 79)])
+def test_ensemble_vs_c_oracle(engines, golden_env, basin, n, seed):
+    """Seeded ensembles: GPU vs the C restatement, including step counters."""
+    from oracle import c_oracle
+    from tropical_cyclone_risk_amd import synthetic
+    storms = synthetic.draw_storm_inputs(n, basin, seed=seed)
+    got = engines(basin).integrate(storms)
+    ref = c_oracle.run_ensemble(golden_env, basin, storms)
+    exposed = ref['flicker'] > 0
+    print('%s: %d storms, %d flicker-exposed, %d samples' % (basin, n, exposed.sum(), ref['n_valid'].sum()))
+    assert exposed.mean() < 0.5
+    clean = ~exposed
+    for key in ('n_accept', 'n_reject'):
+        assert np.array_equal(got[key][clean], ref[key][clean]), key
+    _check('oracle-' + basin, got, ref, exposed)
+
+
+def test_empty_and_single(engines):
+    """Edge cases: n = 0 and n = 1 batches, a v0 <= 4 seed (1-sample track), a gated seed."""
+    from tropical_cyclone_risk_amd import synthetic
+    eng = engines('NA')
+    s = synthetic.draw_storm_inputs(1, 'NA', seed=3)
+    empty = {k: v[:0] for k, v in s.items()}
+    out = eng.integrate(empty)
+    assert out['lon'].shape == (0, eng.n_steps)
+    s['lon'][:] = 310.0; s['lat'][:] = 18.0; s['v0'][:] = 3.5; s['month'][:] = 9
+    out = eng.integrate(s)
+    assert out['status'][0] == 1 and out['n_valid'][0] == 1
+    assert out['lon'][0, 0] == 310.0 and np.isnan(out['lon'][0, 1:]).all()
+    assert np.isnan(out['vmax'][0]).all() and not out['accepted'][0]

@@ -1,0 +1,114 @@
+"""ctypes binding of ``libtcrisk_hip.so`` (C ABI declared in ``include/tcrisk_hip.h``).
+
+There is deliberately no CPU fallback: if the shared library is missing the import
+of :func:`lib` raises with build instructions, and if no HIP device is visible
+``tcr_ctx_create`` fails with the driver's message.
+"""
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, 'libtcrisk_hip.so')
+
+TCR_ABI_VERSION = 1
+TCR_NW, TCR_NCOV, TCR_MAX_SERIES, TCR_N_BASINS = 4, 10, 32, 7
+STATUS_GATED, STATUS_FINISHED, STATUS_EVENT, STATUS_STEP_FAIL = -1, 0, 1, -2
+FLAG_IS_TC, FLAG_ACCEPTED = 1, 2
+
+DP = C.POINTER(C.c_double)
+IP = C.POINTER(C.c_int32)
+U8P = C.POINTER(C.c_uint8)
+
+# every symbol include/tcrisk_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = ('tcr_abi_version', 'tcr_ctx_create', 'tcr_ctx_destroy', 'tcr_last_error',
+           'tcr_params_set', 'tcr_static_upload', 'tcr_fields_upload', 'tcr_masks_upload',
+           'tcr_integrate_host', 'tcr_integrate_dev', 'tcr_seed_dev', 'tcr_seed_host',
+           'tcr_probe_rhs_host', 'tcr_fourier_table_host', 'tcr_timing_enable',
+           'tcr_timing_last', 'tcr_sync')
+
+
+class Grid(C.Structure):
+    _fields_ = [('nlon', C.c_int32), ('nlat', C.c_int32), ('lon', DP), ('lat', DP)]
+
+
+class Params(C.Structure):
+    _fields_ = [('Ck', C.c_double), ('epsilon', C.c_double), ('kappa', C.c_double),
+                ('u_beta', C.c_double), ('v_beta', C.c_double), ('T_Fs', C.c_double),
+                ('y_alpha', C.c_double * 2), ('m_alpha', C.c_double * 2),
+                ('alpha_max', C.c_double * 2), ('alpha_min', C.c_double * 2),
+                ('steering_coefs', C.c_double * 2),
+                ('dt_out', C.c_double), ('total_time', C.c_double),
+                ('rtol', C.c_double), ('atol', C.c_double), ('max_step', C.c_double),
+                ('v_thresh', C.c_double), ('v_2d_thresh', C.c_double), ('vmax_thresh', C.c_double),
+                ('v_dissipate', C.c_double), ('earth_R', C.c_double), ('box', C.c_double * 4),
+                ('fs_amp', C.c_double), ('fs_wgt', C.c_double * TCR_MAX_SERIES),
+                ('n_series', C.c_int32), ('n_steps', C.c_int32),
+                ('coupled_track', C.c_int32), ('reserved', C.c_int32),
+                ('seed_v_init', C.c_double), ('pi_gate', C.c_double), ('lat_vort_fac', C.c_double),
+                ('lat_vort_power', C.c_double * TCR_N_BASINS),
+                ('atm_bl_depth', C.c_double * TCR_N_BASINS),
+                ('minit_a', C.c_double), ('minit_b', C.c_double),
+                ('minit_c', C.c_double), ('minit_d', C.c_double)]
+
+
+class Storms(C.Structure):
+    _fields_ = [('n', C.c_int64), ('lon0', C.c_void_p), ('lat0', C.c_void_p), ('v0', C.c_void_p),
+                ('m0', C.c_void_p), ('h_bl', C.c_void_p), ('slot', C.c_void_p), ('phases', C.c_void_p)]
+
+
+class Tracks(C.Structure):
+    _fields_ = [('lon', C.c_void_p), ('lat', C.c_void_p), ('v', C.c_void_p), ('m', C.c_void_p),
+                ('vmax', C.c_void_p), ('envw', C.c_void_p), ('n_valid', C.c_void_p),
+                ('status', C.c_void_p), ('flags', C.c_void_p), ('nfev', C.c_void_p),
+                ('n_accept', C.c_void_p), ('n_reject', C.c_void_p)]
+
+
+class Seeds(C.Structure):
+    _fields_ = [('n', C.c_int64), ('lon0', C.c_void_p), ('lat0', C.c_void_p), ('v0', C.c_void_p),
+                ('m0', C.c_void_p), ('h_bl', C.c_void_p), ('slot', C.c_void_p),
+                ('phases', C.c_void_p), ('basin_idx', C.c_void_p), ('seed_flags', C.c_void_p)]
+
+
+class TcrError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Fails loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TcrError(
+            'libtcrisk_hip.so not found at %s — build it with '
+            '`python -c "import __graft_entry__ as g; g.build()"` or '
+            '`python -m tropical_cyclone_risk_amd.build`; there is no CPU fallback.' % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.tcr_abi_version.restype = C.c_int
+    L.tcr_last_error.restype = C.c_char_p
+    L.tcr_last_error.argtypes = [C.c_void_p]
+    L.tcr_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.tcr_ctx_destroy.argtypes = [C.c_void_p]
+    L.tcr_params_set.argtypes = [C.c_void_p, C.POINTER(Params)]
+    L.tcr_static_upload.argtypes = [C.c_void_p, C.POINTER(Grid), DP, DP]
+    L.tcr_fields_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Grid), C.POINTER(DP), C.POINTER(DP),
+                                    C.POINTER(Grid), DP, DP, DP, DP, DP]
+    L.tcr_masks_upload.argtypes = [C.c_void_p, C.POINTER(Grid), U8P, C.POINTER(U8P)]
+    L.tcr_integrate_host.argtypes = [C.c_void_p, C.POINTER(Storms), C.POINTER(Tracks)]
+    L.tcr_integrate_dev.argtypes = [C.c_void_p, C.POINTER(Storms), C.POINTER(Tracks), C.c_void_p]
+    L.tcr_seed_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_int64, C.POINTER(Seeds), C.c_void_p]
+    L.tcr_seed_host.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_int64, C.POINTER(Seeds)]
+    L.tcr_probe_rhs_host.argtypes = [C.c_void_p, C.c_int, C.c_double, DP, C.c_int64,
+                                     DP, DP, DP, DP, DP, DP, DP, DP]
+    L.tcr_fourier_table_host.argtypes = [C.c_void_p, C.c_int64, DP, DP]
+    L.tcr_timing_enable.argtypes = [C.c_void_p, C.c_int]
+    L.tcr_timing_last.argtypes = [C.c_void_p, DP]
+    L.tcr_sync.argtypes = [C.c_void_p, C.c_void_p]
+    if L.tcr_abi_version() != TCR_ABI_VERSION:
+        raise TcrError('libtcrisk_hip.so ABI version %d != binding version %d'
+                       % (L.tcr_abi_version(), TCR_ABI_VERSION))
+    _lib = L
+    return L

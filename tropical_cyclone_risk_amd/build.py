@@ -1,0 +1,46 @@
+"""Build libtcrisk_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+
+    python -m tropical_cyclone_risk_amd.build [--force]
+
+-ffp-contract=off: bilinear weights/sums and the `land == 1` test must keep
+FITPACK's operation order without fused multiply-adds (tcr_device.h).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, 'csrc')
+OUT = os.path.join(PKG, 'libtcrisk_hip.so')
+SOURCES = ['tcr_abi.hip', 'tcr_kernels.hip', 'tcr_seed.hip', 'tcr_device.h',
+           os.path.join('..', '..', 'include', 'tcrisk_hip.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared']
+
+
+def hipcc():
+    for cand in (shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found; libtcrisk_hip.so cannot be built (no CPU fallback exists)')
+
+
+def stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
+
+
+def build(force=False, verbose=False):
+    if not (force or stale()):
+        return OUT
+    cmd = [hipcc()] + FLAGS + ['-o', OUT, os.path.join(CSRC, 'tcr_abi.hip')]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

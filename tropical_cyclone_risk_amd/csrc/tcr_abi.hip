@@ -1,0 +1,524 @@
+// C-ABI host side of libtcrisk_hip.so (see include/tcrisk_hip.h for the contract
+// and the reference interface each entry point replaces).  Owns: the HIP stream,
+// the staged field sets in HBM (interleaved layouts of tcr_device.h), grow-only
+// workspaces (forcing tables, track records), and kernel launches.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tcr_kernels.hip"
+#include "tcr_seed.hip"
+
+using namespace tcr;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct GridStore {
+    std::vector<double> lon, lat;
+    double *d_lon = nullptr, *d_lat = nullptr, *d_rlon = nullptr, *d_rlat = nullptr;
+    bool set = false;
+};
+
+struct SlotStore {
+    double *wind = nullptr, *thermo = nullptr, *rh = nullptr;
+};
+
+}  // namespace
+
+struct tcr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    tcr_params prm;
+    bool have_prm = false;
+    GridStore wg, tg, hg, mg;
+    std::vector<SlotStore> slots;
+    DevSlot *d_slots = nullptr;
+    size_t d_slots_cap = 0;
+    bool slots_dirty = true;
+    double *d_stat = nullptr;
+    uint8_t *d_run_mask = nullptr, *d_basin_masks = nullptr;
+    // workspaces
+    double *d_fs = nullptr, *d_rec = nullptr;
+    size_t fs_cap = 0, rec_cap = 0;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+    hipStream_t ev_stream = nullptr;
+};
+
+namespace {
+
+int fail(tcr_ctx *ctx, const char *fmt, const char *a = "", const char *b = "")
+{
+    char buf[512];
+    snprintf(buf, sizeof buf, fmt, a, b);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return -1;
+}
+
+#define HIPCHK(ctx, call)                                                              \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) return fail(ctx, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(tcr_ctx *ctx, T **p, size_t count)
+{
+    HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T) + 256));
+    return 0;
+}
+
+bool same(const std::vector<double> &a, const double *b, int n)
+{
+    return (int)a.size() == n && memcmp(a.data(), b, sizeof(double) * n) == 0;
+}
+
+// Upload a grid (or check that it equals the one already staged): all month slots
+// of one experiment share one wind grid and one thermo grid, as in the reference
+// where every Coupled_FAST of a year reads the same env_wnd/thermo datasets.
+int stage_grid(tcr_ctx *ctx, GridStore &g, const tcr_grid *in, const char *what)
+{
+    if (!in || in->nlon < 2 || in->nlat < 2 || !in->lon || !in->lat)
+        return fail(ctx, "%s grid: need >= 2 points per axis", what);
+    for (int i = 1; i < in->nlon; ++i)
+        if (!(in->lon[i] > in->lon[i - 1])) return fail(ctx, "%s grid: lon not strictly increasing", what);
+    for (int i = 1; i < in->nlat; ++i)
+        if (!(in->lat[i] > in->lat[i - 1])) return fail(ctx, "%s grid: lat not strictly increasing", what);
+    if (g.set) {
+        if (same(g.lon, in->lon, in->nlon) && same(g.lat, in->lat, in->nlat)) return 0;
+        return fail(ctx, "%s grid differs from the grid already staged in this context", what);
+    }
+    g.lon.assign(in->lon, in->lon + in->nlon);
+    g.lat.assign(in->lat, in->lat + in->nlat);
+    std::vector<double> rlon(in->nlon - 1), rlat(in->nlat - 1);
+    for (int i = 0; i + 1 < in->nlon; ++i) rlon[i] = 1.0 / (in->lon[i + 1] - in->lon[i]);   // fpbspl.f
+    for (int i = 0; i + 1 < in->nlat; ++i) rlat[i] = 1.0 / (in->lat[i + 1] - in->lat[i]);
+    if (dev_alloc(ctx, &g.d_lon, in->nlon) || dev_alloc(ctx, &g.d_lat, in->nlat) ||
+        dev_alloc(ctx, &g.d_rlon, in->nlon) || dev_alloc(ctx, &g.d_rlat, in->nlat)) return -1;
+    HIPCHK(ctx, hipMemcpy(g.d_lon, g.lon.data(), sizeof(double) * in->nlon, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(g.d_lat, g.lat.data(), sizeof(double) * in->nlat, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(g.d_rlon, rlon.data(), sizeof(double) * (in->nlon - 1), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(g.d_rlat, rlat.data(), sizeof(double) * (in->nlat - 1), hipMemcpyHostToDevice));
+    g.set = true;
+    return 0;
+}
+
+DevGrid dev_grid(const GridStore &g)
+{
+    DevGrid d{};
+    if (!g.set) return d;
+    d.nlon = (int)g.lon.size(); d.nlat = (int)g.lat.size();
+    d.lon = g.d_lon; d.lat = g.d_lat; d.rlon = g.d_rlon; d.rlat = g.d_rlat;
+    d.lon_inv_step = (d.nlon - 1) / (g.lon.back() - g.lon.front());
+    d.lat_inv_step = (d.nlat - 1) / (g.lat.back() - g.lat.front());
+    return d;
+}
+
+int sync_slots(tcr_ctx *ctx)
+{
+    if (!ctx->slots_dirty) return 0;
+    const size_t n = ctx->slots.size();
+    if (n > ctx->d_slots_cap) {
+        if (ctx->d_slots) HIPCHK(ctx, hipFree(ctx->d_slots));
+        if (dev_alloc(ctx, &ctx->d_slots, n)) return -1;
+        ctx->d_slots_cap = n;
+    }
+    std::vector<DevSlot> h(n);
+    for (size_t i = 0; i < n; ++i) { h[i].wind = ctx->slots[i].wind; h[i].thermo = ctx->slots[i].thermo; h[i].rh = ctx->slots[i].rh; }
+    if (n) HIPCHK(ctx, hipMemcpy(ctx->d_slots, h.data(), sizeof(DevSlot) * n, hipMemcpyHostToDevice));
+    ctx->slots_dirty = false;
+    return 0;
+}
+
+DevFields dev_fields(const tcr_ctx *ctx)
+{
+    DevFields D{};
+    D.wg = dev_grid(ctx->wg); D.tg = dev_grid(ctx->tg); D.hg = dev_grid(ctx->hg); D.mg = dev_grid(ctx->mg);
+    D.slots = ctx->d_slots; D.stat = ctx->d_stat;
+    D.run_mask = ctx->d_run_mask; D.basin_masks = ctx->d_basin_masks;
+    return D;
+}
+
+int ready(tcr_ctx *ctx, bool need_masks)
+{
+    if (!ctx) return -1;
+    if (!ctx->have_prm) return fail(ctx, "tcr_params_set has not been called");
+    if (!ctx->wg.set || !ctx->tg.set || ctx->slots.empty()) return fail(ctx, "no field slot staged (tcr_fields_upload)");
+    if (!ctx->hg.set) return fail(ctx, "static fields not staged (tcr_static_upload)");
+    if (need_masks && !ctx->mg.set) return fail(ctx, "basin masks not staged (tcr_masks_upload)");
+    return sync_slots(ctx);
+}
+
+int grow(tcr_ctx *ctx, double **p, size_t *cap, size_t need)
+{
+    if (need <= *cap) return 0;
+    if (*p) HIPCHK(ctx, hipFree(*p));
+    *p = nullptr; *cap = 0;
+    if (dev_alloc(ctx, p, need)) return -1;
+    *cap = need;
+    return 0;
+}
+
+}  // namespace
+
+namespace {
+struct DevBuf {
+    std::vector<void *> ptrs;
+    ~DevBuf() { for (void *p : ptrs) (void)hipFree(p); }
+    template <typename T>
+    T *get(size_t count)
+    {
+        void *p = nullptr;
+        if (hipMalloc(&p, count * sizeof(T) + 256) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return static_cast<T *>(p);
+    }
+    template <typename T>
+    T *put(const T *host, size_t count)
+    {
+        T *d = get<T>(count);
+        if (d && hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return d;
+    }
+};
+}  // namespace
+
+extern "C" {
+
+int tcr_abi_version(void) { return TCR_ABI_VERSION; }
+
+const char *tcr_last_error(const tcr_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int tcr_ctx_create(int device, tcr_ctx **out)
+{
+    if (!out) return fail(nullptr, "tcr_ctx_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, "no HIP device available (%s); this library has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= count) return fail(nullptr, "tcr_ctx_create: device index out of range");
+    tcr_ctx *ctx = new tcr_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, "tcr_ctx_create: hipSetDevice/hipStreamCreate failed");
+    }
+    for (auto &ev : ctx->ev) (void)hipEventCreate(&ev);
+    *out = ctx;
+    return 0;
+}
+
+int tcr_ctx_destroy(tcr_ctx *ctx)
+{
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (GridStore *g : {&ctx->wg, &ctx->tg, &ctx->hg, &ctx->mg}) {
+        (void)hipFree(g->d_lon); (void)hipFree(g->d_lat); (void)hipFree(g->d_rlon); (void)hipFree(g->d_rlat);
+    }
+    for (auto &s : ctx->slots) { (void)hipFree(s.wind); (void)hipFree(s.thermo); (void)hipFree(s.rh); }
+    (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_run_mask); (void)hipFree(ctx->d_basin_masks);
+    (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_rec);
+    for (auto &ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+int tcr_params_set(tcr_ctx *ctx, const tcr_params *p)
+{
+    if (!ctx || !p) return -1;
+    if (p->n_series < 1 || p->n_series > TCR_MAX_SERIES) return fail(ctx, "n_series out of range");
+    if (p->n_steps < 2) return fail(ctx, "n_steps must be >= 2");
+    if (!(p->total_time > 0) || !(p->dt_out > 0)) return fail(ctx, "total_time and dt_out must be positive");
+    ctx->prm = *p;
+    ctx->have_prm = true;
+    return 0;
+}
+
+int tcr_static_upload(tcr_ctx *ctx, const tcr_grid *hg, const double *land, const double *bathy)
+{
+    if (!ctx) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!land || !bathy) return fail(ctx, "tcr_static_upload: NULL plane");
+    if (stage_grid(ctx, ctx->hg, hg, "static")) return -1;
+    const size_t np = (size_t)hg->nlon * hg->nlat;
+    std::vector<double> h(np * kStaticStride);
+    for (size_t i = 0; i < np; ++i) { h[i * 2] = land[i]; h[i * 2 + 1] = bathy[i]; }
+    if (!ctx->d_stat && dev_alloc(ctx, &ctx->d_stat, h.size())) return -1;
+    HIPCHK(ctx, hipMemcpy(ctx->d_stat, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int tcr_fields_upload(tcr_ctx *ctx, int slot, const tcr_grid *wg, const double *const mean[TCR_NW],
+                      const double *const cov[TCR_NCOV], const tcr_grid *tg, const double *vpot,
+                      const double *chi, const double *mld, const double *strat, const double *rh_mid)
+{
+    if (!ctx) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (slot < 0 || slot >= 4096) return fail(ctx, "tcr_fields_upload: slot out of range");
+    if (!mean || !cov || !vpot || !chi || !mld || !strat) return fail(ctx, "tcr_fields_upload: NULL plane");
+    if (stage_grid(ctx, ctx->wg, wg, "wind") || stage_grid(ctx, ctx->tg, tg, "thermo")) return -1;
+    if ((size_t)slot >= ctx->slots.size()) ctx->slots.resize(slot + 1);
+    SlotStore &s = ctx->slots[slot];
+    const size_t nw = (size_t)wg->nlon * wg->nlat, nt = (size_t)tg->nlon * tg->nlat;
+    {   // interleave the 14 wind planes; NaN -> 0 as _interp_basin_field does (bam_track.py:72-74)
+        std::vector<double> h(nw * kWindStride, 0.0);
+        for (int f = 0; f < 14; ++f) {
+            const double *src = f < 4 ? mean[f] : cov[f - 4];
+            if (!src) return fail(ctx, "tcr_fields_upload: NULL wind plane");
+            for (size_t i = 0; i < nw; ++i) { const double x = src[i]; h[i * kWindStride + f] = (x != x) ? 0.0 : x; }
+        }
+        if (!s.wind && dev_alloc(ctx, &s.wind, h.size())) return -1;
+        HIPCHK(ctx, hipMemcpy(s.wind, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    }
+    {
+        std::vector<double> h(nt * kThermoStride);
+        for (size_t i = 0; i < nt; ++i) { h[i * 4] = vpot[i]; h[i * 4 + 1] = chi[i]; h[i * 4 + 2] = mld[i]; h[i * 4 + 3] = strat[i]; }
+        if (!s.thermo && dev_alloc(ctx, &s.thermo, h.size())) return -1;
+        HIPCHK(ctx, hipMemcpy(s.thermo, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    }
+    if (rh_mid) {
+        if (!s.rh && dev_alloc(ctx, &s.rh, nt)) return -1;
+        HIPCHK(ctx, hipMemcpy(s.rh, rh_mid, sizeof(double) * nt, hipMemcpyHostToDevice));
+    }
+    ctx->slots_dirty = true;
+    return 0;
+}
+
+int tcr_masks_upload(tcr_ctx *ctx, const tcr_grid *mg, const uint8_t *run_mask,
+                     const uint8_t *const basin_masks[TCR_N_BASINS])
+{
+    if (!ctx) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!run_mask || !basin_masks) return fail(ctx, "tcr_masks_upload: NULL mask");
+    if (stage_grid(ctx, ctx->mg, mg, "mask")) return -1;
+    const size_t np = (size_t)mg->nlon * mg->nlat;
+    if (!ctx->d_run_mask && dev_alloc(ctx, &ctx->d_run_mask, np)) return -1;
+    if (!ctx->d_basin_masks && dev_alloc(ctx, &ctx->d_basin_masks, np * TCR_N_BASINS)) return -1;
+    HIPCHK(ctx, hipMemcpy(ctx->d_run_mask, run_mask, np, hipMemcpyHostToDevice));
+    for (int b = 0; b < TCR_N_BASINS; ++b) {
+        if (!basin_masks[b]) return fail(ctx, "tcr_masks_upload: NULL basin mask");
+        HIPCHK(ctx, hipMemcpy(ctx->d_basin_masks + np * b, basin_masks[b], np, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+int tcr_timing_enable(tcr_ctx *ctx, int on)
+{
+    if (!ctx) return -1;
+    ctx->timing = on != 0;
+    ctx->ev_valid = false;
+    return 0;
+}
+
+int tcr_timing_last(tcr_ctx *ctx, double ms[3])
+{
+    if (!ctx || !ms) return -1;
+    if (!ctx->ev_valid) return fail(ctx, "no timed launch recorded (tcr_timing_enable + tcr_integrate_*)");
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev[3]));
+    for (int i = 0; i < 3; ++i) {
+        float f = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&f, ctx->ev[i], ctx->ev[i + 1]));
+        ms[i] = f;
+    }
+    return 0;
+}
+
+int tcr_sync(tcr_ctx *ctx, void *stream)
+{
+    if (!ctx) return -1;
+    HIPCHK(ctx, hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
+    return 0;
+}
+
+int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out, void *stream_)
+{
+    if (ready(ctx, false)) return -1;
+    if (!in || !out) return fail(ctx, "tcr_integrate_dev: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int64_t n = in->n;
+    if (n < 0) return fail(ctx, "tcr_integrate_dev: negative n");
+    if (n == 0) return 0;
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    const tcr_params &P = ctx->prm;
+    const size_t ns = (size_t)P.n_steps;
+    if (grow(ctx, &ctx->d_fs, &ctx->fs_cap, (size_t)n * ns * 4)) return -1;
+    if (grow(ctx, &ctx->d_rec, &ctx->rec_cap, (size_t)n * ns * kRec)) return -1;
+
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[0], st));
+    {
+        const int64_t total = n * (int64_t)ns;
+        const unsigned blocks = (unsigned)((total + 255) / 256);
+        hipLaunchKernelGGL(k_fourier_table, dim3(blocks), dim3(256), 0, st, P, n, in->phases, ctx->d_fs);
+    }
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
+    {
+        KArgs a{};
+        a.P = P; a.D = dev_fields(ctx); a.n = n;
+        a.lon0 = in->lon0; a.lat0 = in->lat0; a.v0 = in->v0; a.m0 = in->m0; a.h_bl = in->h_bl;
+        a.slot = in->slot; a.phases = in->phases; a.fs = ctx->d_fs; a.rec = ctx->d_rec;
+        a.n_valid = out->n_valid; a.status = out->status; a.nfev = out->nfev;
+        a.n_accept = out->n_accept; a.n_reject = out->n_reject;
+        const unsigned blocks = (unsigned)((n + kWave - 1) / kWave);
+        hipLaunchKernelGGL(k_integrate, dim3(blocks), dim3(kWave), 0, st, a);
+    }
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
+    {
+        PArgs a{};
+        a.P = P; a.n = n; a.rec = ctx->d_rec; a.n_valid = out->n_valid; a.status = out->status;
+        a.lon = out->lon; a.lat = out->lat; a.v = out->v; a.m = out->m; a.vmax = out->vmax;
+        a.envw = out->envw; a.flags = out->flags;
+        hipLaunchKernelGGL(k_post_unpack, dim3((unsigned)n), dim3(kPostThreads), 0, st, a);
+    }
+    if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[3], st)); ctx->ev_valid = true; }
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+
+int tcr_integrate_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out)
+{
+    if (ready(ctx, false)) return -1;
+    if (!in || !out) return fail(ctx, "tcr_integrate_host: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)in->n, ns = (size_t)ctx->prm.n_steps, N = (size_t)ctx->prm.n_series;
+    if (n == 0) return 0;
+    for (size_t i = 0; i < n; ++i)
+        if (in->slot[i] < 0 || (size_t)in->slot[i] >= ctx->slots.size() || !ctx->slots[in->slot[i]].wind)
+            return fail(ctx, "tcr_integrate_host: storm references a slot that is not staged");
+    DevBuf B;
+    tcr_storms di{};
+    di.n = in->n;
+    di.lon0 = B.put(in->lon0, n); di.lat0 = B.put(in->lat0, n); di.v0 = B.put(in->v0, n);
+    di.m0 = B.put(in->m0, n); di.h_bl = B.put(in->h_bl, n); di.slot = B.put(in->slot, n);
+    di.phases = B.put(in->phases, n * 4 * N);
+    tcr_tracks dout{};
+    dout.lon = B.get<double>(n * ns); dout.lat = B.get<double>(n * ns); dout.v = B.get<double>(n * ns);
+    dout.m = B.get<double>(n * ns); dout.vmax = B.get<double>(n * ns); dout.envw = B.get<double>(n * ns * 4);
+    dout.n_valid = B.get<int32_t>(n); dout.status = B.get<int32_t>(n); dout.flags = B.get<int32_t>(n);
+    dout.nfev = B.get<int32_t>(n); dout.n_accept = B.get<int32_t>(n); dout.n_reject = B.get<int32_t>(n);
+    if (!di.lon0 || !di.lat0 || !di.v0 || !di.m0 || !di.h_bl || !di.slot || !di.phases || !dout.lon ||
+        !dout.lat || !dout.v || !dout.m || !dout.vmax || !dout.envw || !dout.n_valid || !dout.status ||
+        !dout.flags || !dout.nfev || !dout.n_accept || !dout.n_reject)
+        return fail(ctx, "tcr_integrate_host: device allocation / upload failed");
+    if (tcr_integrate_dev(ctx, &di, &dout, ctx->stream)) return -1;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+#define D2H(field, count, T) \
+    if (out->field) HIPCHK(ctx, hipMemcpy(out->field, dout.field, (count) * sizeof(T), hipMemcpyDeviceToHost))
+    D2H(lon, n * ns, double); D2H(lat, n * ns, double); D2H(v, n * ns, double); D2H(m, n * ns, double);
+    D2H(vmax, n * ns, double); D2H(envw, n * ns * 4, double);
+    D2H(n_valid, n, int32_t); D2H(status, n, int32_t); D2H(flags, n, int32_t); D2H(nfev, n, int32_t);
+    D2H(n_accept, n, int32_t); D2H(n_reject, n, int32_t);
+#undef D2H
+    return 0;
+}
+
+int tcr_fourier_table_host(tcr_ctx *ctx, int64_t n, const double *phases, double *Fs)
+{
+    if (!ctx) return -1;
+    if (!ctx->have_prm) return fail(ctx, "tcr_params_set has not been called");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n <= 0) return 0;
+    const size_t ns = (size_t)ctx->prm.n_steps, N = (size_t)ctx->prm.n_series;
+    DevBuf B;
+    const double *d_ph = B.put(phases, (size_t)n * 4 * N);
+    double *d_fs = B.get<double>((size_t)n * ns * 4);
+    if (!d_ph || !d_fs) return fail(ctx, "tcr_fourier_table_host: device allocation failed");
+    const int64_t total = n * (int64_t)ns;
+    hipLaunchKernelGGL(k_fourier_table, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       ctx->prm, n, d_ph, d_fs);
+    HIPCHK(ctx, hipGetLastError());
+    std::vector<double> h((size_t)n * ns * 4);
+    HIPCHK(ctx, hipMemcpyAsync(h.data(), d_fs, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // device layout [n][n_steps][4] -> reference layout [n][4][n_steps]
+    for (int64_t s = 0; s < n; ++s)
+        for (size_t i = 0; i < ns; ++i)
+            for (int k = 0; k < 4; ++k) Fs[((size_t)s * 4 + k) * ns + i] = h[((size_t)s * ns + i) * 4 + k];
+    return 0;
+}
+
+int tcr_probe_rhs_host(tcr_ctx *ctx, int slot, double h_bl, const double *Fs, int64_t n, const double *t,
+                       const double *lon, const double *lat, const double *v, const double *m,
+                       double *dydt, double *envw, double *alpha)
+{
+    if (ready(ctx, false)) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (slot < 0 || (size_t)slot >= ctx->slots.size() || !ctx->slots[slot].wind)
+        return fail(ctx, "tcr_probe_rhs_host: slot not staged");
+    if (n <= 0) return 0;
+    const size_t ns = (size_t)ctx->prm.n_steps;
+    std::vector<double> fs(ns * 4);
+    for (size_t i = 0; i < ns; ++i)
+        for (int k = 0; k < 4; ++k) fs[i * 4 + k] = Fs[(size_t)k * ns + i];
+    DevBuf B;
+    const double *d_fs = B.put(fs.data(), fs.size());
+    const double *d_t = B.put(t, n), *d_lon = B.put(lon, n), *d_lat = B.put(lat, n), *d_v = B.put(v, n), *d_m = B.put(m, n);
+    double *d_dy = B.get<double>(n * 4), *d_w = B.get<double>(n * 4), *d_al = B.get<double>(n);
+    if (!d_fs || !d_t || !d_lon || !d_lat || !d_v || !d_m || !d_dy || !d_w || !d_al)
+        return fail(ctx, "tcr_probe_rhs_host: device allocation failed");
+    hipLaunchKernelGGL(k_probe_rhs, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, ctx->prm,
+                       dev_fields(ctx), slot, h_bl, d_fs, n, d_t, d_lon, d_lat, d_v, d_m, d_dy, d_w, d_al);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(dydt, d_dy, sizeof(double) * n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(envw, d_w, sizeof(double) * n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(alpha, d_al, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tcr_seed_dev(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t cand0,
+                 const tcr_seeds *out, void *stream_)
+{
+    if (ready(ctx, true)) return -1;
+    if (!out) return fail(ctx, "tcr_seed_dev: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (out->n <= 0) return 0;
+    for (auto &s : ctx->slots) if (!s.rh) return fail(ctx, "tcr_seed_dev: a slot was staged without rh_mid");
+    if (ctx->slots.size() < 12) return fail(ctx, "tcr_seed_dev: needs the 12 month slots staged");
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    SeedArgs a{};
+    a.P = ctx->prm; a.D = dev_fields(ctx); a.seed = experiment_seed; a.year = year; a.cand0 = cand0; a.out = *out;
+    hipLaunchKernelGGL(k_seed, dim3((unsigned)((out->n + 255) / 256)), dim3(256), 0, st, a);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+int tcr_seed_host(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t cand0, const tcr_seeds *out)
+{
+    if (ready(ctx, true)) return -1;
+    if (!out) return fail(ctx, "tcr_seed_host: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)out->n, N = (size_t)ctx->prm.n_series;
+    if (n == 0) return 0;
+    DevBuf B;
+    tcr_seeds d{};
+    d.n = out->n;
+    d.lon0 = B.get<double>(n); d.lat0 = B.get<double>(n); d.v0 = B.get<double>(n); d.m0 = B.get<double>(n);
+    d.h_bl = B.get<double>(n); d.slot = B.get<int32_t>(n); d.phases = B.get<double>(n * 4 * N);
+    d.basin_idx = B.get<int32_t>(n); d.seed_flags = B.get<int32_t>(n);
+    if (!d.lon0 || !d.lat0 || !d.v0 || !d.m0 || !d.h_bl || !d.slot || !d.phases || !d.basin_idx || !d.seed_flags)
+        return fail(ctx, "tcr_seed_host: device allocation failed");
+    if (tcr_seed_dev(ctx, experiment_seed, year, cand0, &d, ctx->stream)) return -1;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+#define D2H(field, count, T) \
+    if (out->field) HIPCHK(ctx, hipMemcpy(out->field, d.field, (count) * sizeof(T), hipMemcpyDeviceToHost))
+    D2H(lon0, n, double); D2H(lat0, n, double); D2H(v0, n, double); D2H(m0, n, double); D2H(h_bl, n, double);
+    D2H(slot, n, int32_t); D2H(phases, n * 4 * N, double); D2H(basin_idx, n, int32_t); D2H(seed_flags, n, int32_t);
+#undef D2H
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,247 @@
+"""Host driver of the HIP storm integrator: one :class:`TCEngine` per (GPU, basin).
+
+It plays the role the list of twelve ``Coupled_FAST`` objects plays in the
+reference's ``run_tracks`` (`util/compute.py:101-121`): fields are cropped to the
+basin exactly as ``TC_Basin.transform_global_field`` does, staged once into HBM
+month slots, and whole batches of storms are then integrated per call through
+the C ABI of ``include/tcrisk_hip.h``.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, constants
+from . import namelist as default_namelist
+from .basins import BASIN_IDS, TC_Basin
+
+TRACK_F64 = ('lon', 'lat', 'v', 'm', 'vmax')
+TRACK_I32 = ('n_valid', 'status', 'flags', 'nfev', 'n_accept', 'n_reject')
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _dp(a):
+    return a.ctypes.data_as(_lib.DP)
+
+
+def params_from_namelist(nl, basin, n_series=None):
+    """Collect the scalars the kernels read from a namelist module (namelist.py:56-94)."""
+    p = _lib.Params()
+    p.Ck, p.epsilon, p.kappa = nl.Ck, 0.33, 0.1                   # coupled_fast.py:23-27
+    p.u_beta, p.v_beta = nl.u_beta, nl.v_beta
+    p.T_Fs = nl.T_days * 24 * 60 * 60                             # bam_track.py:56
+    for k in ('y_alpha', 'm_alpha', 'alpha_max', 'alpha_min', 'steering_coefs'):
+        setattr(p, k, (C.c_double * 2)(*getattr(nl, k)))
+    p.dt_out = float(nl.output_interval_s)
+    p.total_time = float(nl.total_track_time_days * 24 * 60 * 60)
+    p.rtol = getattr(nl, 'gpu_rtol', 1e-3)
+    p.atol = getattr(nl, 'gpu_atol', 1e-6)
+    p.max_step = getattr(nl, 'gpu_max_step_s', 86400.0)           # coupled_fast.py:266
+    p.v_thresh = nl.seed_v_threshold_ms
+    p.v_2d_thresh = nl.seed_v_2d_threshold_ms
+    p.vmax_thresh = nl.seed_vmax_threshold_ms
+    p.v_dissipate = 4.0                                           # coupled_fast.py:255
+    p.earth_R = constants.earth_R
+    p.box = (C.c_double * 4)(*TC_Basin(basin).get_bounds())
+    N = int(n_series or getattr(nl, 'gpu_N_series', 15))          # bam_track.py:112
+    n = np.linspace(1, N, N)
+    p.fs_amp = float(np.sqrt(2 / np.sum(np.power(n, -3))))        # bam_track.py:28
+    wgt = np.zeros(_lib.TCR_MAX_SERIES)
+    wgt[:N] = np.power(n, -1.5)
+    p.fs_wgt = (C.c_double * _lib.TCR_MAX_SERIES)(*wgt)
+    p.n_series = N
+    p.n_steps = int(p.total_time / p.dt_out) + 1                  # bam_track.py:54
+    p.coupled_track = 1 if nl.coupled_track else 0
+    p.seed_v_init = nl.seed_v_init_ms
+    p.pi_gate = 35.0                                              # compute.py:168
+    p.lat_vort_fac = nl.lat_vort_fac
+    p.lat_vort_power = (C.c_double * 7)(*[nl.lat_vort_power[b] for b in BASIN_IDS])
+    p.atm_bl_depth = (C.c_double * 7)(*[nl.atm_bl_depth[b] for b in BASIN_IDS])
+    # f_mInit = a / (1 + exp(-(rh - b) * c)) + d; verified against nl.f_mInit below
+    p.minit_a, p.minit_b, p.minit_c, p.minit_d = 0.20, 0.55, 10.0, 0.125
+    rh = np.linspace(0, 1, 11)
+    mine = p.minit_a / (1 + np.exp(-(rh - p.minit_b) * p.minit_c)) + p.minit_d
+    if not np.allclose(mine, nl.f_mInit(rh), rtol=0, atol=1e-14):
+        raise ValueError('namelist.f_mInit is not the logistic form the device seeding implements; '
+                         'seed on the host and call integrate() instead')
+    return p
+
+
+class TCEngine:
+    """Owns one library context: staged fields + parameters for one basin on one GPU."""
+
+    def __init__(self, basin, device=0, nl=None):
+        self.nl = nl or default_namelist
+        self.basin = TC_Basin(basin)
+        self.L = _lib.lib()
+        h = C.c_void_p()
+        if self.L.tcr_ctx_create(int(device), C.byref(h)) != 0:
+            raise _lib.TcrError(self.L.tcr_last_error(None).decode())
+        self.h = h
+        self.device = int(device)
+        self.params = params_from_namelist(self.nl, basin)
+        self._ck(self.L.tcr_params_set(self.h, C.byref(self.params)))
+        self.n_steps = int(self.params.n_steps)
+        self.n_series = int(self.params.n_series)
+        self.t_s = np.linspace(0, self.params.total_time, self.n_steps)
+        self._keep = []
+
+    # ------------------------------------------------------------------ utils
+    def _ck(self, rc):
+        if rc != 0:
+            raise _lib.TcrError(self.L.tcr_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.tcr_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _grid(self, lon, lat):
+        lon, lat = _f64(lon), _f64(lat)
+        g = _lib.Grid(lon.size, lat.size, _dp(lon), _dp(lat))
+        g._keep = (lon, lat)
+        return g
+
+    # --------------------------------------------------------------- staging
+    def stage_static(self, hlon, hlat, land, bathy):
+        """geo.read_land / read_bathy (intensity/geo.py:9-34): crop to the basin, stage."""
+        lo, la, land_b = self.basin.transform_global_field(hlon, hlat, land)
+        _, _, bathy_b = self.basin.transform_global_field(hlon, hlat, bathy)
+        g = self._grid(lo, la)
+        land_b, bathy_b = _f64(land_b), _f64(bathy_b)
+        self._ck(self.L.tcr_static_upload(self.h, C.byref(g), _dp(land_b), _dp(bathy_b)))
+
+    def stage_month(self, slot, wlon, wlat, wnd_mean, wnd_cov, lon, lat, vpot, chi, mld, strat, rh_mid=None):
+        """One month's field set: `_load_wnd_stat` (bam_track.py:76-91) + `init_fields`
+        (coupled_fast.py:217-225).  wnd_mean [4,nlat,nlon]; wnd_cov packed lower triangle
+        [10,nlat,nlon]; thermo planes [nlat,nlon] on the global grid."""
+        tf = self.basin.transform_global_field
+        planes = []
+        wlo = wla = None
+        for k in range(4):
+            wlo, wla, x = tf(wlon, wlat, wnd_mean[k]); planes.append(_f64(x))
+        for k in range(10):
+            _, _, x = tf(wlon, wlat, wnd_cov[k]); planes.append(_f64(x))
+        mean_p = (_lib.DP * 4)(*[_dp(x) for x in planes[:4]])
+        cov_p = (_lib.DP * 10)(*[_dp(x) for x in planes[4:]])
+        tlo, tla, vp = tf(lon, lat, vpot)
+        th = [_f64(vp)] + [_f64(tf(lon, lat, x)[2]) for x in (chi, mld, strat)]
+        rh = _f64(tf(lon, lat, rh_mid)[2]) if rh_mid is not None else None
+        wg, tg = self._grid(wlo, wla), self._grid(tlo, tla)
+        self._ck(self.L.tcr_fields_upload(self.h, int(slot), C.byref(wg), mean_p, cov_p, C.byref(tg),
+                                          _dp(th[0]), _dp(th[1]), _dp(th[2]), _dp(th[3]),
+                                          _dp(rh) if rh is not None else None))
+
+    def stage_masks(self, mlon, mlat, run_mask, basin_masks):
+        """land/<B>.nc indicator grids (compute.py:87-97); basin_masks: dict id -> plane."""
+        run = np.ascontiguousarray(np.asarray(run_mask) > 0.5, dtype=np.uint8)
+        ms = [np.ascontiguousarray(np.asarray(basin_masks[b]) > 0.5, dtype=np.uint8) for b in BASIN_IDS]
+        g = self._grid(mlon, mlat)
+        arr = (_lib.U8P * 7)(*[m.ctypes.data_as(_lib.U8P) for m in ms])
+        self._ck(self.L.tcr_masks_upload(self.h, C.byref(g), run.ctypes.data_as(_lib.U8P), arr))
+
+    def stage_env(self, env, months=range(12)):
+        """Stage a ``synthetic.SyntheticEnv``-shaped object (12 monthly field sets)."""
+        self.stage_static(env.hlon, env.hlat, env.land, env.bathy)
+        for mo in months:
+            self.stage_month(mo, env.wlon, env.wlat, env.wnd_mean[mo], env.wnd_cov[mo], env.lon, env.lat,
+                             env.vpot[mo], env.chi[mo], env.mld[mo], env.strat[mo], env.rh_mid[mo])
+        if getattr(env, 'basin_masks', None):
+            self.stage_masks(env.hlon, env.hlat, env.basin_masks[self.basin.basin_id], env.basin_masks)
+        return self
+
+    # -------------------------------------------------------------- hot path
+    def integrate(self, storms):
+        """Integrate + post-process a batch given as host arrays (dict with lon, lat, v0,
+        m0, h_bl, month (1..12), phases [n,4,N]); returns a dict of NumPy arrays."""
+        n = len(storms['lon'])
+        ns = self.n_steps
+        lon0, lat0, v0, m0, h_bl = (_f64(storms[k]) for k in ('lon', 'lat', 'v0', 'm0', 'h_bl'))
+        slot = np.ascontiguousarray(np.asarray(storms['month']) - 1, dtype=np.int32)
+        ph = _f64(storms['phases']).reshape(n, 4 * self.n_series)
+        out = {k: np.empty((n, ns)) for k in TRACK_F64}
+        out['envw'] = np.empty((n, ns, 4))
+        out.update({k: np.zeros(n, np.int32) for k in TRACK_I32})
+        if n == 0:
+            return self._finish(out)
+        si = _lib.Storms(n, *[a.ctypes.data for a in (lon0, lat0, v0, m0, h_bl, slot, ph)])
+        so = _lib.Tracks(*[out[k].ctypes.data for k in ('lon', 'lat', 'v', 'm', 'vmax', 'envw',
+                                                         'n_valid', 'status', 'flags', 'nfev',
+                                                         'n_accept', 'n_reject')])
+        self._ck(self.L.tcr_integrate_host(self.h, C.byref(si), C.byref(so)))
+        return self._finish(out)
+
+    @staticmethod
+    def _finish(out):
+        out['is_tc'] = (out['flags'] & _lib.FLAG_IS_TC) != 0
+        out['accepted'] = (out['flags'] & _lib.FLAG_ACCEPTED) != 0
+        out['traj'] = np.stack([out['lon'], out['lat'], out['v'], out['m']], axis=1)
+        return out
+
+    def integrate_dev(self, storms, tracks, stream=None):
+        """Device-buffer variant: ``storms`` / ``tracks`` map field name -> device pointer
+        (e.g. ``tensor.data_ptr()``); asynchronous on ``stream`` (a hipStream_t as int)."""
+        si = _lib.Storms(int(storms['n']), *[int(storms[k]) for k in
+                                              ('lon0', 'lat0', 'v0', 'm0', 'h_bl', 'slot', 'phases')])
+        so = _lib.Tracks(*[int(tracks[k]) for k in ('lon', 'lat', 'v', 'm', 'vmax', 'envw', 'n_valid',
+                                                     'status', 'flags', 'nfev', 'n_accept', 'n_reject')])
+        self._ck(self.L.tcr_integrate_dev(self.h, C.byref(si), C.byref(so), C.c_void_p(stream or 0)))
+
+    def seed(self, year, cand0, n, experiment_seed=None):
+        """Device-side genesis seeding of candidates [cand0, cand0+n) (compute.py:134-175)."""
+        seed = int(self.nl.gpu_experiment_seed if experiment_seed is None else experiment_seed)
+        out = dict(lon=np.empty(n), lat=np.empty(n), v0=np.empty(n), m0=np.empty(n), h_bl=np.empty(n),
+                   slot=np.zeros(n, np.int32), phases=np.empty((n, 4, self.n_series)),
+                   basin_idx=np.zeros(n, np.int32), seed_flags=np.zeros(n, np.int32))
+        s = _lib.Seeds(n, *[out[k].ctypes.data for k in ('lon', 'lat', 'v0', 'm0', 'h_bl', 'slot',
+                                                          'phases', 'basin_idx', 'seed_flags')])
+        self._ck(self.L.tcr_seed_host(self.h, C.c_uint64(seed), int(year), int(cand0), C.byref(s)))
+        out['month'] = out['slot'] + 1
+        out['counted'] = (out['seed_flags'] & 1) != 0
+        out['passed'] = (out['seed_flags'] & 2) != 0
+        return out
+
+    def seed_dev(self, year, cand0, seeds, stream=None, experiment_seed=None):
+        seed = int(self.nl.gpu_experiment_seed if experiment_seed is None else experiment_seed)
+        s = _lib.Seeds(int(seeds['n']), *[int(seeds[k]) for k in ('lon0', 'lat0', 'v0', 'm0', 'h_bl', 'slot',
+                                                                   'phases', 'basin_idx', 'seed_flags')])
+        self._ck(self.L.tcr_seed_dev(self.h, C.c_uint64(seed), int(year), int(cand0), C.byref(s),
+                                     C.c_void_p(stream or 0)))
+
+    # ---------------------------------------------------------------- probes
+    def fourier_table(self, phases):
+        """gen_f (bam_track.py:23-31): phases [n,4,N] -> Fs [n,4,n_steps]."""
+        ph = _f64(phases).reshape(-1, 4 * self.n_series)
+        Fs = np.empty((ph.shape[0], 4, self.n_steps))
+        self._ck(self.L.tcr_fourier_table_host(self.h, ph.shape[0], _dp(ph), _dp(Fs)))
+        return Fs
+
+    def probe_rhs(self, slot, h_bl, Fs, t, lon, lat, v, m):
+        """dydt / _env_winds / _calc_alpha at points (coupled_fast.py:196-207, 65-94)."""
+        t, lon, lat, v, m = (_f64(x) for x in (t, lon, lat, v, m))
+        Fs = _f64(Fs)
+        n = t.size
+        dydt = np.empty((n, 4)); envw = np.empty((n, 4)); alpha = np.empty(n)
+        self._ck(self.L.tcr_probe_rhs_host(self.h, int(slot), float(h_bl), _dp(Fs), n, _dp(t), _dp(lon),
+                                           _dp(lat), _dp(v), _dp(m), _dp(dydt), _dp(envw), _dp(alpha)))
+        return dydt, envw, alpha
+
+    # ----------------------------------------------------------- measurement
+    def timing_enable(self, on=True):
+        self._ck(self.L.tcr_timing_enable(self.h, 1 if on else 0))
+
+    def timing_last(self):
+        ms = (C.c_double * 3)()
+        self._ck(self.L.tcr_timing_last(self.h, ms))
+        return dict(fourier_ms=ms[0], integrate_ms=ms[1], post_ms=ms[2])
+
+    def sync(self, stream=None):
+        self._ck(self.L.tcr_sync(self.h, C.c_void_p(stream or 0)))

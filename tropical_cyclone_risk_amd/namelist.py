@@ -1,0 +1,110 @@
+"""Experiment configuration ("namelist") for the MI355X ensemble integrator.
+
+Mirrors the attribute surface of the reference's module-as-config
+(`/root/reference/namelist.py:9-119`): every name a reference user sets there
+exists here with the same meaning and default, so a user namelist can be
+dropped in via ``tropical_cyclone_risk_amd.namelist.load(path)``.  Values that
+feed the device kernels are collected by ``engine.params_from_namelist``.
+
+Extra (MI355X-only) knobs are grouped at the bottom and prefixed ``gpu_``.
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+# ----------------------------- file system ---------------------------------
+src_directory = os.path.dirname(os.path.abspath(__file__))
+base_directory = '%s/data/era5' % src_directory
+output_directory = '%s/data/era5' % src_directory
+exp_name = 'test'
+dataset_type = 'ERA5'
+exp_prefix = 'era5'
+
+var_keys = {'ERA5': {'sst': 'sst', 'mslp': 'sp', 'temp': 't',
+                     'sp_hum': 'q', 'u': 'u', 'v': 'v',
+                     'lvl': 'level', 'lon': 'longitude', 'lat': 'latitude'},
+            'GCM': {'sst': 'tos', 'mslp': 'psl', 'temp': 'ta',
+                    'sp_hum': 'hus', 'u': 'ua', 'v': 'va',
+                    'lvl': 'plev', 'lon': 'lon', 'lat': 'lat'}}
+
+# ----------------------------- parallelism ---------------------------------
+n_procs = 16              # kept for surface parity; the GPU path ignores it
+
+# ----------------------------- dates / output ------------------------------
+start_year = 2016
+start_month = 1
+end_year = 2021
+end_month = 12
+
+output_interval_s = 3600
+total_track_time_days = 15
+tracks_per_year = 20
+
+# ----------------------------- thermodynamics ------------------------------
+p_midlevel = 60000
+PI_reduc = 0.80
+Ck = 1.2e-3
+Cd = 1.2e-3
+select_thermo = 1
+select_interp = 2
+
+# ----------------------------- track / intensity ---------------------------
+steering_levels = [250, 850]
+steering_coefs = [0.2, 0.8]
+coupled_track = True
+y_alpha = [0.17, 0.83]
+m_alpha = [0.0025, -0.0025]
+alpha_max = [0.41, 0.78]
+alpha_min = [0.22, 0.59]
+u_beta = -1.0
+v_beta = 2.5
+T_days = 20
+seed_v_init_ms = 5
+seed_v_2d_threshold_ms = 6.5
+seed_v_threshold_ms = 15
+seed_vmax_threshold_ms = 18
+atm_bl_depth = {'NA': 1400.0, 'EP': 1400.0, 'WP': 1800.0, 'AU': 1800.0,
+                'SI': 1600.0, 'SP': 2000.0, 'NI': 1500.0}
+log_chi_fac = 0.5
+chi_fac = 1.3
+lat_vort_fac = 2
+lat_vort_power = {'NA': 6, 'EP': 6,
+                  'WP': 3.5, 'AU': 6,
+                  'SI': 3, 'SP': 7, 'NI': 2.5}
+
+
+def f_mInit(rh):
+    """Initial inner-core moisture from mid-level RH (reference namelist.py:94)."""
+    return 0.20 / (1 + np.exp(-(rh - 0.55) * 10)) + 0.125
+
+
+basin_bounds = {'EP': ['180E', '0N', '290E', '60N'],
+                'NA': ['260E', '0N', '360E', '60N'],
+                'NI': ['30E', '0N', '100E', '50N'],
+                'SI': ['20E', '45S', '100E', '0S'],
+                'AU': ['100E', '45S', '180E', '0S'],
+                'SP': ['180E', '45S', '250E', '0S'],
+                'WP': ['100E', '0N', '180E', '60N'],
+                'GL': ['0E', '90S', '360E', '90N']}
+
+# ----------------------------- MI355X-only knobs ---------------------------
+gpu_experiment_seed = 20250614   # Philox key word 0 (replaces wall-clock reseeding)
+gpu_candidate_round = 65536      # candidates seeded+integrated per device round
+gpu_rtol = 1e-3                  # solve_ivp defaults used by the reference
+gpu_atol = 1e-6
+gpu_max_step_s = 86400.0
+gpu_N_series = 15                # bam_track.py:112
+
+
+def load(path):
+    """Overlay a user namelist file (reference format) on this module."""
+    spec = importlib.util.spec_from_file_location('_user_namelist', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    me = sys.modules[__name__]
+    for k, v in vars(mod).items():
+        if not k.startswith('_') and k not in ('os', 'np'):
+            setattr(me, k, v)
+    return me
