@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: storm-steps/s of the seed → integrate → post hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--storms B]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One *step* = one pass of the hot path over one batch on every rank: device-side
+seeding of a round of candidates (compute.py:134-175), order-preserving selection
+of the first B that pass, the fused DP5(4) integration with env-wind recompute,
+vmax and accept flags (compute.py:176-209), and — for N > 1 — the RCCL all-gather
+of the accepted tracks of that batch.  Per-GPU work is fixed (B storms per rank),
+so scaling is weak; `value` is storm-steps of all ranks / wall time of the K steps.
+
+A storm-step is one hourly output interval of one live storm.
+Inputs (fields) are resident in HBM before the timed region; candidates are drawn
+on the device inside it.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+BYTES_PER_RHS = 704.0            # 20 lookups x 4 corners x 8 B + Fs 64 B
+BYTES_PER_SAMPLE = 520.0         # 14 lookups x 32 B + 9 outputs x 8 B
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--storms', type=int, default=100_000, help='storms integrated per GPU per step')
+    ap.add_argument('--basin', default='GL')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-budget', type=float, default=12.0)
+    ap.add_argument('--traffic', type=float, default=None,
+                    help='HBM bytes per integrate launch from a separate rocprofv3 --pmc pass (see profiles/)')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from tropical_cyclone_risk_amd import distributed as D
+    from tropical_cyclone_risk_amd import synthetic
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    from tropical_cyclone_risk_amd.pipeline import DevicePipeline
+
+    rank, world, local = D.init_from_env()
+    if world != args.gpus and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    year = 2000
+
+    env = synthetic.make_env('era5')
+    eng = TCEngine(args.basin, device=local).stage_env(env)
+    B = args.storms
+    ns = eng.n_steps
+
+    # ---- calibrate the seed pass rate once (untimed) so that a round of C candidates
+    # contains at least B passing seeds with a wide margin
+    probe = DevicePipeline(eng, 1 << 18, 1024)
+    probe.seed_round(year, 10**12)
+    torch.cuda.synchronize()
+    p_pass = float(((probe.cand['seed_flags'] & 2) != 0).double().mean().item())
+    del probe
+    C = int(B / max(p_pass, 1e-3) * 1.15) + 4096
+    pipe = DevicePipeline(eng, C, B)
+
+    acc = torch.zeros(3, dtype=torch.float64, device=dev)     # storm-steps, nfev, samples
+    short = torch.zeros(1, dtype=torch.int64, device=dev)     # rounds that had < B passing seeds
+    n_acc_total = torch.zeros(1, dtype=torch.int64, device=dev)
+    row = 9 * ns
+    cap = B
+    packed = [torch.empty(cap, row, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    pending = [None, None]
+    gathered_rows = 0
+
+    def step(k, timed):
+        nonlocal gathered_rows
+        pipe.seed_round(year, D.round_block(k, C, rank, world))
+        pipe.select_passed(B)
+        pipe.integrate(B)
+        if timed:
+            nv = pipe.tracks['n_valid'][:B]
+            acc[0] += (nv - 1).clamp_min(0).sum()
+            acc[1] += pipe.tracks['nfev'][:B].sum()
+            acc[2] += nv.sum()
+            short.add_((pipe.n_passed < B).long())
+        if world > 1:
+            # all-gather of this batch's final (accepted) tracks, overlapped with the next
+            # batch's compute: packing goes to a double buffer, RCCL runs on its own stream
+            slot = k & 1
+            if pending[slot] is not None:
+                rows, _ = pending[slot]()
+                gathered_rows += rows.shape[0]
+                pending[slot] = None
+            pipe.select_accepted()
+            pipe.pack_accepted(packed[slot], cap)
+            counts = D.allgather_counts(pipe.n_accepted)
+            _, fin = D.allgather_rows(packed[slot], None, counts=[min(c, cap) for c in counts], async_op=True)
+            pending[slot] = fin
+        elif timed:
+            pipe.select_accepted()
+            n_acc_total.add_(pipe.n_accepted)
+
+    def drain():
+        nonlocal gathered_rows
+        for s in (0, 1):
+            if pending[s] is not None:
+                rows, _ = pending[s]()
+                gathered_rows += rows.shape[0]
+                pending[s] = None
+
+    for k in range(args.warmup):
+        step(k, False)
+    drain()
+    D.barrier(); torch.cuda.synchronize()
+    eng.timing_enable(True)
+    gathered_rows = 0
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        step(k, True)
+    drain()
+    torch.cuda.synchronize(); D.barrier()
+    dt = time.perf_counter() - t0
+    dt = D.max_over_ranks(dt, dev)
+
+    ms = (eng.L and eng.timing_sum())
+    if world > 1:
+        D.allreduce_sum_(acc)
+    steps_total, nfev_total, samples_total = (float(x) for x in acc.tolist())
+    n_short = int(short.item())
+    value = steps_total / dt
+
+    # ---- roofline of the dominant kernel (k_integrate): algorithmic bytes per launch
+    # over its HIP-event duration (events recorded on the launch stream by the library)
+    launches = ms['calls']
+    per_launch_bytes = (BYTES_PER_RHS * nfev_total + BYTES_PER_SAMPLE * samples_total) / (launches * world)
+    k_ms = ms['integrate_ms'] / launches
+    achieved = per_launch_bytes / (k_ms * 1e-3) / 1e9
+    roof = dict(bound='hbm', kernel='k_integrate', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
+                frac=achieved / HBM_PEAK_GBS, traffic=args.traffic,
+                kernel_ms=dict(fourier=ms['fourier_ms'] / launches, integrate=k_ms, post=ms['post_ms'] / launches),
+                algorithmic_bytes_per_launch=per_launch_bytes)
+
+    out = None
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(pipe, args, B)
+        out = {
+            'metric': 'storm-steps/sec (100k-storm ensemble)', 'value': value, 'unit': 'storm-steps/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': '%s basin, %d storms per GPU per step, synthetic ERA5-shaped monthly fields '
+                                   '(1 deg thermo/wind, 0.25 deg land/bathymetry), 15-day tracks, hourly output, '
+                                   'device-side seeding, fp64' % (args.basin, B),
+                       'storms_per_gpu': B, 'candidates_per_round': C, 'seed_pass_rate': p_pass,
+                       'n_steps_out': ns, 'rounds_short_of_storms': n_short,
+                       'storm_steps_per_storm': steps_total / (B * args.steps * world),
+                       'rhs_per_storm_step': nfev_total / max(steps_total, 1),
+                       'accepted_fraction': (float(n_acc_total.item()) / (B * args.steps)) if world == 1 else None,
+                       'allgather_rows': gathered_rows if world > 1 else None},
+            'roofline': roof,
+            'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        D.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(pipe, args, B):
+    """Time oracle/scipy_port.py on a bounded sample of the last batch's storms (rank 0, N=1)."""
+    import numpy as np
+    n = min(B, 16384)
+    s = pipe.storms
+    host = dict(lon=s['lon0'][:n].cpu().numpy(), lat=s['lat0'][:n].cpu().numpy(), v0=s['v0'][:n].cpu().numpy(),
+                m0=s['m0'][:n].cpu().numpy(), h_bl=s['h_bl'][:n].cpu().numpy(),
+                month=(s['slot'][:n].cpu().numpy() + 1).astype(np.int32),
+                phases=s['phases'][:n].cpu().numpy().reshape(n, 4, -1))
+    with tempfile.TemporaryDirectory() as d:
+        fn = os.path.join(d, 'storms.npz')
+        np.savez(fn, **host)
+        try:
+            r = subprocess.run([sys.executable, '-m', 'oracle.cpu_baseline', '--inputs', fn, '--basin', args.basin,
+                                '--budget', str(args.cpu_budget)], cwd=ROOT, capture_output=True, text=True,
+                               timeout=600)
+            res = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:                                        # report, never hide
+            return {'value': None, 'unit': 'storm-steps/s', 'cores': 0, 'kind': 'port',
+                    'sample': 'failed: %r' % (e,)}
+    best = res.get('all_cores', res['one_core'])
+    return {'value': best['value'], 'unit': 'storm-steps/s', 'cores': best.get('procs', 1), 'kind': 'port',
+            'sample': 'oracle/scipy_port.py (solve_ivp RK45 + RectBivariateSpline.ev + numpy cholesky, integration + '
+                      'env-wind recompute + vmax) on the first %d storms of the last GPU batch, %d worker '
+                      'processes, %.1f s' % (best['storms'], best.get('procs', 1), best['seconds']),
+            'value_1core': res['one_core']['value'], 'storms_1core': res['one_core']['storms']}
+
+
+if __name__ == '__main__':
+    main()

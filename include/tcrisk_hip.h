@@ -160,6 +160,21 @@ int tcr_seed_dev(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t c
 int tcr_seed_host(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t cand0,
                   const tcr_seeds *out_host);
 
+/* ---- order-preserving filters (the batched form of the sequential accept loop) -- */
+/* replaces: `while not seed_passed` / `if is_tc` / `nt += 1` control flow of run_tracks
+ * (compute.py:135-209): indices i in [0,n) with (flags[i] & mask) != 0, in increasing
+ * order, first max_out of them -> idx; *count = how many matched (device scalar). */
+int tcr_compact_dev(tcr_ctx *ctx, int64_t n, const int32_t *flags_dev, int32_t mask, int64_t max_out,
+                    int32_t *idx_dev, int64_t *count_dev, void *stream);
+/* dense storm batch dst[r] = src[idx[r]], r < n_out (seed rows incl. their 4*n_series phases) */
+int tcr_gather_seeds_dev(tcr_ctx *ctx, const tcr_seeds *src_dev, const int32_t *idx_dev, int64_t n_out,
+                         const tcr_seeds *dst_dev, void *stream);
+/* survivor records for the all-gather of final tracks (compute.py:233-242 concatenation):
+ * packed[r] = { lon[ns], lat[ns], v[ns], m[ns], vmax[ns], envw[ns][4] } of track idx[r],
+ * r < min(*count_dev, cap). */
+int tcr_pack_tracks_dev(tcr_ctx *ctx, const tcr_tracks *src_dev, const int32_t *idx_dev,
+                        const int64_t *count_dev, int64_t cap, double *packed_dev, void *stream);
+
 /* ---- single-point probes (parity tests of the seam's leaf methods) -------- */
 /* replaces: Coupled_FAST.dydt (coupled_fast.py:196-207), ._env_winds
  * (bam_track.py:116-128) and ._calc_alpha (coupled_fast.py:65-94) at n points
@@ -174,9 +189,12 @@ int tcr_fourier_table_host(tcr_ctx *ctx, int64_t n, const double *phases, double
 /* ---- measurement ----------------------------------------------------------- */
 /* HIP-event durations (ms) of the kernels of the last tcr_integrate_dev/_host
  * call on this context: [0] fourier table, [1] integrate, [2] post/unpack.
- * Enabled by tcr_timing_enable(ctx, 1); reading synchronises the stream. */
+ * Enabled by tcr_timing_enable(ctx, 1) (which also resets the record); reading
+ * waits for the recorded events.  Events are recorded on the launch stream. */
 int tcr_timing_enable(tcr_ctx *ctx, int on);
 int tcr_timing_last(tcr_ctx *ctx, double ms[3]);
+/* sums over every timed call since tcr_timing_enable(ctx, 1); *n_calls = how many */
+int tcr_timing_sum(tcr_ctx *ctx, double ms[3], int64_t *n_calls);
 int tcr_sync(tcr_ctx *ctx, void *stream);
 
 #ifdef __cplusplus

@@ -1,0 +1,71 @@
+"""ORACLE-side timed CPU baseline (bench.py's ``cpu_baseline`` leg only).
+
+Runs ``oracle/scipy_port.py`` — the same SciPy/NumPy calls the reference makes,
+one storm at a time — over a bounded sample of the bench's own storm inputs, on
+1 core and on P worker processes (the reference's own parallel model is one dask
+process per year, `util/compute.py:223-230`).  Executed as a subprocess so that
+forking workers never happens in a process that has initialised HIP.
+
+    python -m oracle.cpu_baseline --inputs storms.npz --basin GL --procs 8 --budget 12
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+_ENV = None
+_BASIN = None
+_STORMS = None
+
+
+def _work(idx):
+    from oracle import scipy_port as P
+    o = P.run_ensemble(_ENV, _BASIN, _STORMS, index=idx)
+    return int(np.clip(o['n_valid'] - 1, 0, None).sum()), int(o['nfev'].sum()), len(idx)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--inputs', required=True)
+    ap.add_argument('--basin', default='GL')
+    ap.add_argument('--shape', default='era5')
+    ap.add_argument('--env-seed', type=int, default=20250614)
+    ap.add_argument('--procs', type=int, default=0)
+    ap.add_argument('--budget', type=float, default=12.0, help='target seconds per leg')
+    a = ap.parse_args()
+    global _ENV, _BASIN, _STORMS
+    from tropical_cyclone_risk_amd import synthetic
+    _ENV = synthetic.make_env(a.shape, seed=a.env_seed)
+    _BASIN = a.basin
+    z = np.load(a.inputs)
+    _STORMS = {k: z[k] for k in z.files}
+    n_avail = len(_STORMS['lon'])
+    procs = a.procs or len(os.sched_getaffinity(0))
+
+    # calibrate on a handful of storms, then size both legs to the time budget
+    t0 = time.perf_counter(); s0, _, _ = _work(list(range(min(8, n_avail)))); per = (time.perf_counter() - t0) / min(8, n_avail)
+    n1 = int(max(8, min(n_avail, a.budget / per)))
+    t0 = time.perf_counter(); steps1, nfev1, _ = _work(list(range(n1))); dt1 = time.perf_counter() - t0
+    out = dict(one_core=dict(storm_steps=steps1, seconds=dt1, storms=n1, value=steps1 / dt1, nfev=nfev1))
+    if procs > 1:
+        nP = int(max(procs, min(n_avail, procs * a.budget / per)))
+        chunks = [list(range(i, nP, procs)) for i in range(procs)]
+        ctx = mp.get_context('fork')
+        with ctx.Pool(procs) as pool:
+            pool.map(_work, [[0]] * procs)                  # warm the workers (imports, caches)
+            t0 = time.perf_counter(); res = pool.map(_work, chunks); dtP = time.perf_counter() - t0
+        stepsP = sum(r[0] for r in res)
+        out['all_cores'] = dict(storm_steps=stepsP, seconds=dtP, storms=nP, value=stepsP / dtP, procs=procs)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -12,6 +12,7 @@
 
 #include "tcr_kernels.hip"
 #include "tcr_seed.hip"
+#include "tcr_compact.hip"
 
 using namespace tcr;
 
@@ -47,11 +48,12 @@ struct tcr_ctx {
     // workspaces
     double *d_fs = nullptr, *d_rec = nullptr;
     size_t fs_cap = 0, rec_cap = 0;
-    // timing
+    int32_t *d_tiles = nullptr;
+    size_t tiles_cap = 0;
+    // timing: four events per timed tcr_integrate_dev call since tcr_timing_enable(ctx, 1)
     bool timing = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool ev_valid = false;
-    hipStream_t ev_stream = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
 };
 
 namespace {
@@ -214,7 +216,6 @@ int tcr_ctx_create(int device, tcr_ctx **out)
         delete ctx;
         return fail(nullptr, "tcr_ctx_create: hipSetDevice/hipStreamCreate failed");
     }
-    for (auto &ev : ctx->ev) (void)hipEventCreate(&ev);
     *out = ctx;
     return 0;
 }
@@ -230,7 +231,8 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     for (auto &s : ctx->slots) { (void)hipFree(s.wind); (void)hipFree(s.thermo); (void)hipFree(s.rh); }
     (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_run_mask); (void)hipFree(ctx->d_basin_masks);
     (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_rec);
-    for (auto &ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
+    (void)hipFree(ctx->d_tiles);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -319,18 +321,48 @@ int tcr_timing_enable(tcr_ctx *ctx, int on)
 {
     if (!ctx) return -1;
     ctx->timing = on != 0;
-    ctx->ev_valid = false;
+    ctx->ev_used = 0;
+    return 0;
+}
+
+static int timing_events(tcr_ctx *ctx, hipEvent_t **quad)
+{
+    if (ctx->ev_used + 4 > ctx->ev_pool.size()) {
+        const size_t old = ctx->ev_pool.size();
+        ctx->ev_pool.resize(old + 64, nullptr);
+        for (size_t i = old; i < ctx->ev_pool.size(); ++i) HIPCHK(ctx, hipEventCreate(&ctx->ev_pool[i]));
+    }
+    *quad = &ctx->ev_pool[ctx->ev_used];
+    ctx->ev_used += 4;
+    return 0;
+}
+
+int tcr_timing_sum(tcr_ctx *ctx, double ms[3], int64_t *n_calls)
+{
+    if (!ctx || !ms) return -1;
+    ms[0] = ms[1] = ms[2] = 0.0;
+    const size_t calls = ctx->ev_used / 4;
+    if (n_calls) *n_calls = (int64_t)calls;
+    if (!calls) return fail(ctx, "no timed launch recorded (tcr_timing_enable + tcr_integrate_*)");
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev_pool[ctx->ev_used - 1]));
+    for (size_t c = 0; c < calls; ++c)
+        for (int i = 0; i < 3; ++i) {
+            float f = 0.f;
+            HIPCHK(ctx, hipEventElapsedTime(&f, ctx->ev_pool[c * 4 + i], ctx->ev_pool[c * 4 + i + 1]));
+            ms[i] += f;
+        }
     return 0;
 }
 
 int tcr_timing_last(tcr_ctx *ctx, double ms[3])
 {
     if (!ctx || !ms) return -1;
-    if (!ctx->ev_valid) return fail(ctx, "no timed launch recorded (tcr_timing_enable + tcr_integrate_*)");
-    HIPCHK(ctx, hipEventSynchronize(ctx->ev[3]));
+    if (ctx->ev_used < 4) return fail(ctx, "no timed launch recorded (tcr_timing_enable + tcr_integrate_*)");
+    hipEvent_t *q = &ctx->ev_pool[ctx->ev_used - 4];
+    HIPCHK(ctx, hipEventSynchronize(q[3]));
     for (int i = 0; i < 3; ++i) {
         float f = 0.f;
-        HIPCHK(ctx, hipEventElapsedTime(&f, ctx->ev[i], ctx->ev[i + 1]));
+        HIPCHK(ctx, hipEventElapsedTime(&f, q[i], q[i + 1]));
         ms[i] = f;
     }
     return 0;
@@ -357,13 +389,15 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
     if (grow(ctx, &ctx->d_fs, &ctx->fs_cap, (size_t)n * ns * 4)) return -1;
     if (grow(ctx, &ctx->d_rec, &ctx->rec_cap, (size_t)n * ns * kRec)) return -1;
 
-    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[0], st));
+    hipEvent_t *ev = nullptr;
+    if (ctx->timing && timing_events(ctx, &ev)) return -1;
+    if (ev) HIPCHK(ctx, hipEventRecord(ev[0], st));
     {
         const int64_t total = n * (int64_t)ns;
         const unsigned blocks = (unsigned)((total + 255) / 256);
         hipLaunchKernelGGL(k_fourier_table, dim3(blocks), dim3(256), 0, st, P, n, in->phases, ctx->d_fs);
     }
-    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
+    if (ev) HIPCHK(ctx, hipEventRecord(ev[1], st));
     {
         KArgs a{};
         a.P = P; a.D = dev_fields(ctx); a.n = n;
@@ -374,7 +408,7 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
         const unsigned blocks = (unsigned)((n + kWave - 1) / kWave);
         hipLaunchKernelGGL(k_integrate, dim3(blocks), dim3(kWave), 0, st, a);
     }
-    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
+    if (ev) HIPCHK(ctx, hipEventRecord(ev[2], st));
     {
         PArgs a{};
         a.P = P; a.n = n; a.rec = ctx->d_rec; a.n_valid = out->n_valid; a.status = out->status;
@@ -382,7 +416,7 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
         a.envw = out->envw; a.flags = out->flags;
         hipLaunchKernelGGL(k_post_unpack, dim3((unsigned)n), dim3(kPostThreads), 0, st, a);
     }
-    if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[3], st)); ctx->ev_valid = true; }
+    if (ev) HIPCHK(ctx, hipEventRecord(ev[3], st));
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
@@ -518,6 +552,63 @@ int tcr_seed_host(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t 
     D2H(lon0, n, double); D2H(lat0, n, double); D2H(v0, n, double); D2H(m0, n, double); D2H(h_bl, n, double);
     D2H(slot, n, int32_t); D2H(phases, n * 4 * N, double); D2H(basin_idx, n, int32_t); D2H(seed_flags, n, int32_t);
 #undef D2H
+    return 0;
+}
+
+int tcr_compact_dev(tcr_ctx *ctx, int64_t n, const int32_t *flags, int32_t mask, int64_t max_out,
+                    int32_t *idx, int64_t *count, void *stream_)
+{
+    if (!ctx) return -1;
+    if (!flags || !idx || !count || n < 0 || max_out < 0) return fail(ctx, "tcr_compact_dev: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    const int64_t tiles = (n + kScanTile - 1) / kScanTile;
+    if ((size_t)tiles + 1 > ctx->tiles_cap) {
+        if (ctx->d_tiles) HIPCHK(ctx, hipFree(ctx->d_tiles));
+        ctx->d_tiles = nullptr; ctx->tiles_cap = 0;
+        if (dev_alloc(ctx, &ctx->d_tiles, (size_t)tiles + 1024)) return -1;
+        ctx->tiles_cap = (size_t)tiles + 1024;
+    }
+    if (tiles > 0)
+        hipLaunchKernelGGL(k_compact_count, dim3((unsigned)tiles), dim3(kScanThreads), 0, st, n, flags, mask, ctx->d_tiles);
+    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, (int)tiles, ctx->d_tiles, count);
+    if (tiles > 0)
+        hipLaunchKernelGGL(k_compact_write, dim3((unsigned)tiles), dim3(kScanThreads), 0, st, n, flags, mask,
+                           ctx->d_tiles, max_out, idx);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+int tcr_gather_seeds_dev(tcr_ctx *ctx, const tcr_seeds *src, const int32_t *idx, int64_t n_out,
+                         const tcr_seeds *dst, void *stream_)
+{
+    if (!ctx) return -1;
+    if (!ctx->have_prm) return fail(ctx, "tcr_params_set has not been called");
+    if (!src || !dst || !idx) return fail(ctx, "tcr_gather_seeds_dev: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n_out <= 0) return 0;
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    GatherSeedArgs a{};
+    a.src = *src; a.dst = *dst; a.idx = idx; a.n_out = n_out; a.phases_per_storm = 4 * ctx->prm.n_series;
+    const int64_t threads = n_out * 64;
+    hipLaunchKernelGGL(k_gather_seeds, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+int tcr_pack_tracks_dev(tcr_ctx *ctx, const tcr_tracks *src, const int32_t *idx, const int64_t *count,
+                        int64_t cap, double *packed, void *stream_)
+{
+    if (!ctx) return -1;
+    if (!ctx->have_prm) return fail(ctx, "tcr_params_set has not been called");
+    if (!src || !idx || !count || !packed) return fail(ctx, "tcr_pack_tracks_dev: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (cap <= 0) return 0;
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    PackArgs a{};
+    a.src = *src; a.idx = idx; a.count = count; a.cap = cap; a.ns = ctx->prm.n_steps; a.packed = packed;
+    hipLaunchKernelGGL(k_pack_tracks, dim3((unsigned)cap), dim3(256), 0, st, a);
+    HIPCHK(ctx, hipGetLastError());
     return 0;
 }
 

@@ -1,0 +1,144 @@
+// Order-preserving stream compaction and row gathers.
+//
+// The reference's accept loop is sequential: "keep drawing candidates until
+// n_tracks have survived" (util/compute.py:134-209).  Batched, that becomes
+// "seed a round of candidates, keep the ones that pass *in candidate order*,
+// integrate, keep the accepted ones in candidate order".  Order preservation is
+// what makes the result independent of batch size and GPU count, so compaction
+// is a scan, not an atomic append.
+#include "tcr_device.h"
+
+namespace tcr {
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;                       // items per thread
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+// pass 1: per-tile count of selected items
+__global__ __launch_bounds__(kScanThreads) void k_compact_count(int64_t n, const int32_t *__restrict__ flags,
+                                                                 int32_t mask, int32_t *__restrict__ tile_count)
+{
+    __shared__ int s[kScanThreads / 64];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const int64_t i = base + k;
+        if (i < n && (flags[i] & mask)) ++c;
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_count[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+// pass 2: exclusive scan of the tile counts by one workgroup (tiles <= a few thousand)
+__global__ __launch_bounds__(1024) void k_compact_scan(int n_tiles, int32_t *__restrict__ tile_count,
+                                                        int64_t *__restrict__ total)
+{
+    __shared__ int s[1024];
+    int carry = 0;
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n_tiles ? tile_count[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n_tiles) tile_count[i] = carry + s[threadIdx.x] - v;     // exclusive
+        const int tile_total = s[1023];
+        __syncthreads();
+        carry += tile_total;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+// pass 3: write the indices of selected items at their rank (first max_out only)
+__global__ __launch_bounds__(kScanThreads) void k_compact_write(int64_t n, const int32_t *__restrict__ flags,
+                                                                 int32_t mask, const int32_t *__restrict__ tile_off,
+                                                                 int64_t max_out, int32_t *__restrict__ idx)
+{
+    __shared__ int s[kScanThreads];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int c = 0;
+    bool sel[kScanItems];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const int64_t i = base + k;
+        sel[k] = i < n && (flags[i] & mask);
+        c += sel[k];
+    }
+    s[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 1; off < kScanThreads; off <<= 1) {
+        const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+        __syncthreads();
+        s[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int64_t rank = (int64_t)tile_off[blockIdx.x] + s[threadIdx.x] - c;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+        if (sel[k]) {
+            if (rank < max_out) idx[rank] = (int32_t)(base + k);
+            ++rank;
+        }
+}
+
+// Gather candidate rows idx[0..n_out) into a dense storm batch.
+struct GatherSeedArgs {
+    tcr_seeds src, dst;
+    const int32_t *idx;
+    int64_t n_out;
+    int phases_per_storm;
+};
+
+__global__ __launch_bounds__(256) void k_gather_seeds(GatherSeedArgs a)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = gid / 64;           // one wave per output row: lanes copy the phases
+    const int lane = (int)(gid & 63);
+    if (row >= a.n_out) return;
+    const int32_t j = a.idx[row];
+    if (lane == 0) {
+        a.dst.lon0[row] = a.src.lon0[j]; a.dst.lat0[row] = a.src.lat0[j];
+        a.dst.v0[row] = a.src.v0[j]; a.dst.m0[row] = a.src.m0[j]; a.dst.h_bl[row] = a.src.h_bl[j];
+        a.dst.slot[row] = a.src.slot[j];
+        if (a.dst.basin_idx) a.dst.basin_idx[row] = a.src.basin_idx[j];
+        if (a.dst.seed_flags) a.dst.seed_flags[row] = a.src.seed_flags[j];
+    }
+    const double *sp = a.src.phases + (size_t)j * a.phases_per_storm;
+    double *dp = a.dst.phases + (size_t)row * a.phases_per_storm;
+    for (int k = lane; k < a.phases_per_storm; k += 64) dp[k] = sp[k];
+}
+
+// Pack selected tracks into fixed-size survivor records for the all-gather:
+// packed[row] = { lon[ns], lat[ns], v[ns], m[ns], vmax[ns], envw[ns*4] }  (9*ns doubles)
+struct PackArgs {
+    tcr_tracks src;
+    const int32_t *idx;
+    const int64_t *count;       // device scalar written by k_compact_scan
+    int64_t cap;
+    int ns;
+    double *packed;
+};
+
+__global__ __launch_bounds__(256) void k_pack_tracks(PackArgs a)
+{
+    const int64_t row = blockIdx.x;
+    const int64_t cnt = *a.count < a.cap ? *a.count : a.cap;
+    if (row >= cnt) return;
+    const size_t j = (size_t)a.idx[row];
+    const int ns = a.ns;
+    double *dst = a.packed + (size_t)row * 9 * ns;
+    const double *planes[5] = {a.src.lon, a.src.lat, a.src.v, a.src.m, a.src.vmax};
+    for (int p = 0; p < 5; ++p)
+        for (int i = threadIdx.x; i < ns; i += blockDim.x) dst[(size_t)p * ns + i] = planes[p][j * ns + i];
+    for (int i = threadIdx.x; i < ns * 4; i += blockDim.x) dst[(size_t)5 * ns + i] = a.src.envw[j * ns * 4 + i];
+}
+
+}  // namespace tcr

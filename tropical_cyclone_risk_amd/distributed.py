@@ -1,0 +1,120 @@
+"""Multi-GPU sharding of the candidate index space + the all-gather of final tracks.
+
+The reference parallelises with ``dask.delayed(run_tracks)`` — one *process per
+simulated year*, results pickled back (`util/compute.py:223-230`).  Storms are
+independent, so here the **candidate index space of a year** is sharded instead:
+one process per GPU (``torch.distributed``; backend "nccl" is RCCL on ROCm, "gloo"
+on CPU for the tests), every rank holding a replica of the read-only fields.
+
+Determinism across world sizes comes from two rules:
+  * a candidate's random stream is keyed by its *global* index (tcr_seed.hip), and
+  * a round of ``world * C`` candidates is split into contiguous blocks in rank
+    order, so concatenating per-rank survivors in rank order *is* candidate order —
+    the order in which the reference's sequential loop would have met them.
+
+The only data-path collective is the all-gather of survivor records (fixed-size
+rows of 9*n_steps fp64 = 26 kB); counts and ``n_seeds`` travel as tiny
+all-gathers / all-reduces.  xGMI is point-to-point, so one large all-gather per
+round (not one per storm or per variable) is the shape that suits it.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's environment (no-op when
+    WORLD_SIZE is 1 or unset).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def round_block(round_idx, per_rank, rank_=None, world_=None):
+    """First global candidate index of this rank's block in round ``round_idx``."""
+    r = rank() if rank_ is None else rank_
+    w = world() if world_ is None else world_
+    return (int(round_idx) * w + r) * int(per_rank)
+
+
+def allgather_counts(count):
+    """count: int64 tensor [1] on the compute device -> list of python ints per rank."""
+    if world() == 1:
+        return [int(count.item())]
+    buf = torch.empty(world(), dtype=count.dtype, device=count.device)
+    dist.all_gather_into_tensor(buf, count.reshape(1))
+    return [int(x) for x in buf.tolist()]
+
+
+def allgather_rows(rows, count, counts=None, async_op=False):
+    """All-gather variable-length row blocks.
+
+    rows  : [cap, width] tensor whose first ``count`` rows are valid (cap may differ
+            per rank; only ``max(counts)`` rows are sent)
+    Returns (gathered [sum(counts), width] in rank order, counts) — or, with
+    ``async_op=True``, (work handle, finish()) where finish() returns that pair.
+    """
+    counts = allgather_counts(count) if counts is None else counts
+    w = world()
+    if w == 1:
+        out = rows[:counts[0]]
+        return ((None, lambda: (out, counts)) if async_op else (out, counts))
+    m = max(counts)
+    width = rows.shape[1]
+    if rows.shape[0] < m:       # pad so every rank contributes the same shape
+        pad = torch.empty(m, width, dtype=rows.dtype, device=rows.device)
+        pad[:rows.shape[0]] = rows
+        rows = pad
+    send = rows[:m].contiguous()
+    recv = torch.empty(w * m, width, dtype=rows.dtype, device=rows.device)
+    work = dist.all_gather_into_tensor(recv, send, async_op=async_op) if m > 0 else None
+
+    def finish():
+        if work is not None and async_op:
+            work.wait()
+        parts = [recv[r * m: r * m + counts[r]] for r in range(w)]
+        return torch.cat(parts, dim=0), counts
+    return (work, finish) if async_op else finish()
+
+
+def allreduce_sum_(t):
+    if world() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def barrier():
+    if world() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(x, device):
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    if world() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(x, device):
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    if world() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

@@ -243,5 +243,12 @@ class TCEngine:
         self._ck(self.L.tcr_timing_last(self.h, ms))
         return dict(fourier_ms=ms[0], integrate_ms=ms[1], post_ms=ms[2])
 
+    def timing_sum(self):
+        """Summed HIP-event durations of every timed integrate call since timing_enable()."""
+        ms = (C.c_double * 3)()
+        n = C.c_int64(0)
+        self._ck(self.L.tcr_timing_sum(self.h, ms, C.byref(n)))
+        return dict(fourier_ms=ms[0], integrate_ms=ms[1], post_ms=ms[2], calls=int(n.value))
+
     def sync(self, stream=None):
         self._ck(self.L.tcr_sync(self.h, C.c_void_p(stream or 0)))

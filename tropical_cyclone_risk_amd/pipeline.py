@@ -1,0 +1,127 @@
+"""Device-resident seed → select → integrate → pack pipeline.
+
+PyTorch is used for what it is good at here — owning HBM buffers, exposing the
+current HIP stream, and (in ``distributed.py``) driving RCCL — while every
+computation on those buffers is one of the library's HIP kernels, launched
+through the C ABI with raw device pointers.
+
+One :class:`DevicePipeline` is the batched equivalent of the body of the
+reference's ``while nt < n_tracks`` loop (`util/compute.py:134-209`) for a round
+of candidates.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+F64 = torch.float64
+I32 = torch.int32
+
+
+class DevicePipeline:
+    def __init__(self, engine, max_candidates, max_storms, device=None):
+        self.eng = engine
+        self.dev = torch.device('cuda', engine.device) if device is None else device
+        self.C, self.B = int(max_candidates), int(max_storms)
+        ns, N = engine.n_steps, engine.n_series
+        z = lambda *shape, dtype=F64: torch.empty(*shape, dtype=dtype, device=self.dev)
+        seeds = lambda n: dict(n=n, lon0=z(n), lat0=z(n), v0=z(n), m0=z(n), h_bl=z(n),
+                               slot=z(n, dtype=I32), phases=z(n, 4 * N),
+                               basin_idx=z(n, dtype=I32), seed_flags=z(n, dtype=I32))
+        self.cand = seeds(self.C)             # one seeding round
+        self.storms = seeds(self.B)           # the candidates that passed, dense
+        self.tracks = dict(lon=z(self.B, ns), lat=z(self.B, ns), v=z(self.B, ns), m=z(self.B, ns),
+                           vmax=z(self.B, ns), envw=z(self.B, ns, 4),
+                           n_valid=z(self.B, dtype=I32), status=z(self.B, dtype=I32),
+                           flags=z(self.B, dtype=I32), nfev=z(self.B, dtype=I32),
+                           n_accept=z(self.B, dtype=I32), n_reject=z(self.B, dtype=I32))
+        self.cand_idx = z(self.C, dtype=I32)  # candidate index of each dense storm
+        self.n_passed = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.acc_idx = z(self.B, dtype=I32)
+        self.n_accepted = torch.zeros(1, dtype=torch.int64, device=self.dev)
+
+    # raw pointers -----------------------------------------------------------
+    @staticmethod
+    def _ptrs(d, keys):
+        return {k: (d[k] if k == 'n' else d[k].data_ptr()) for k in keys}
+
+    def _seeds_struct(self, d, n=None):
+        s = _lib.Seeds(int(d['n'] if n is None else n),
+                       *[d[k].data_ptr() for k in ('lon0', 'lat0', 'v0', 'm0', 'h_bl', 'slot', 'phases',
+                                                    'basin_idx', 'seed_flags')])
+        return s
+
+    def _tracks_struct(self):
+        t = self.tracks
+        return _lib.Tracks(*[t[k].data_ptr() for k in ('lon', 'lat', 'v', 'm', 'vmax', 'envw', 'n_valid',
+                                                        'status', 'flags', 'nfev', 'n_accept', 'n_reject')])
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    # stages -----------------------------------------------------------------
+    def seed_round(self, year, cand0, n_cand=None, experiment_seed=None):
+        """Draw candidates [cand0, cand0 + n_cand) (compute.py:136-175)."""
+        n = self.C if n_cand is None else int(n_cand)
+        assert n <= self.C
+        seed = int(self.eng.nl.gpu_experiment_seed if experiment_seed is None else experiment_seed)
+        s = self._seeds_struct(self.cand, n)
+        self.eng._ck(self.eng.L.tcr_seed_dev(self.eng.h, C.c_uint64(seed), int(year), int(cand0),
+                                             C.byref(s), C.c_void_p(self._stream())))
+        self.n_cand = n
+
+    def select_passed(self, n_take=None):
+        """Dense batch of the first n_take candidates whose seed passed (flag bit 1),
+        in candidate order.  ``self.n_passed`` (device) holds how many passed in total."""
+        n_take = self.B if n_take is None else int(n_take)
+        assert n_take <= self.B
+        L, h, st = self.eng.L, self.eng.h, C.c_void_p(self._stream())
+        self.eng._ck(L.tcr_compact_dev(h, self.n_cand, self.cand['seed_flags'].data_ptr(), 2, n_take,
+                                       self.cand_idx.data_ptr(), self.n_passed.data_ptr(), st))
+        src, dst = self._seeds_struct(self.cand, self.n_cand), self._seeds_struct(self.storms, n_take)
+        self.eng._ck(L.tcr_gather_seeds_dev(h, C.byref(src), self.cand_idx.data_ptr(), n_take, C.byref(dst), st))
+        self.n_storms = n_take
+
+    def load_storms(self, storms):
+        """Upload a host batch (dict as produced by ``synthetic.draw_storm_inputs``)."""
+        import numpy as np
+        n = len(storms['lon'])
+        assert n <= self.B
+        put = lambda dst, a, dt: dst[:n].copy_(torch.from_numpy(np.ascontiguousarray(a, dtype=dt)))
+        s = self.storms
+        put(s['lon0'], storms['lon'], np.float64); put(s['lat0'], storms['lat'], np.float64)
+        put(s['v0'], storms['v0'], np.float64); put(s['m0'], storms['m0'], np.float64)
+        put(s['h_bl'], storms['h_bl'], np.float64)
+        put(s['slot'], np.asarray(storms['month']) - 1, np.int32)
+        s['phases'][:n].copy_(torch.from_numpy(np.ascontiguousarray(storms['phases'], dtype=np.float64).reshape(n, -1)))
+        self.n_storms = n
+
+    def integrate(self, n=None):
+        """gen_track + accept tests + env-wind recompute + vmax for the dense batch."""
+        n = self.n_storms if n is None else int(n)
+        s = self.storms
+        si = _lib.Storms(n, *[s[k].data_ptr() for k in ('lon0', 'lat0', 'v0', 'm0', 'h_bl', 'slot', 'phases')])
+        so = self._tracks_struct()
+        self.eng._ck(self.eng.L.tcr_integrate_dev(self.eng.h, C.byref(si), C.byref(so),
+                                                  C.c_void_p(self._stream())))
+        self.n_done = n
+
+    def select_accepted(self):
+        """Indices (dense-batch order == candidate order) of accepted tracks → self.acc_idx."""
+        self.eng._ck(self.eng.L.tcr_compact_dev(self.eng.h, self.n_done, self.tracks['flags'].data_ptr(),
+                                                _lib.FLAG_ACCEPTED, self.B, self.acc_idx.data_ptr(),
+                                                self.n_accepted.data_ptr(), C.c_void_p(self._stream())))
+
+    def pack_accepted(self, packed, cap):
+        """Survivor records of the first ``cap`` accepted tracks into ``packed`` [cap, 9*ns]."""
+        so = self._tracks_struct()
+        self.eng._ck(self.eng.L.tcr_pack_tracks_dev(self.eng.h, C.byref(so), self.acc_idx.data_ptr(),
+                                                    self.n_accepted.data_ptr(), int(cap), packed.data_ptr(),
+                                                    C.c_void_p(self._stream())))
+
+    def host_tracks(self, n=None):
+        """Copy the per-storm outputs of the last integrate() back as NumPy arrays."""
+        n = self.n_done if n is None else n
+        out = {k: v[:n].cpu().numpy() for k, v in self.tracks.items()}
+        return self.eng._finish(out)
