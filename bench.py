@@ -82,17 +82,17 @@ def main():
     pending = [None, None]
     gathered_rows = 0
 
-    def step(k, timed):
+    def step(k):
+        # warm-up steps run exactly the same code; the accumulators are zeroed after them
         nonlocal gathered_rows
         pipe.seed_round(year, D.round_block(k, C, rank, world))
         pipe.select_passed(B)
         pipe.integrate(B)
-        if timed:
-            nv = pipe.tracks['n_valid'][:B]
-            acc[0] += (nv - 1).clamp_min(0).sum()
-            acc[1] += pipe.tracks['nfev'][:B].sum()
-            acc[2] += nv.sum()
-            short.add_((pipe.n_passed < B).long())
+        nv = pipe.tracks['n_valid'][:B]
+        acc[0] += (nv - 1).clamp_min(0).sum()
+        acc[1] += pipe.tracks['nfev'][:B].sum()
+        acc[2] += nv.sum()
+        short.add_((pipe.n_passed < B).long())
         if world > 1:
             # all-gather of this batch's final (accepted) tracks, overlapped with the next
             # batch's compute: packing goes to a double buffer, RCCL runs on its own stream
@@ -106,7 +106,7 @@ def main():
             counts = D.allgather_counts(pipe.n_accepted)
             _, fin = D.allgather_rows(packed[slot], None, counts=[min(c, cap) for c in counts], async_op=True)
             pending[slot] = fin
-        elif timed:
+        else:
             pipe.select_accepted()
             n_acc_total.add_(pipe.n_accepted)
 
@@ -118,15 +118,17 @@ def main():
                 gathered_rows += rows.shape[0]
                 pending[s] = None
 
-    for k in range(args.warmup):
-        step(k, False)
-    drain()
-    D.barrier(); torch.cuda.synchronize()
     eng.timing_enable(True)
+    for k in range(args.warmup):
+        step(k)
+    drain()
+    acc.zero_(); short.zero_(); n_acc_total.zero_()
+    D.barrier(); torch.cuda.synchronize()
+    eng.timing_enable(True)          # resets the event record: only the K timed steps count
     gathered_rows = 0
     t0 = time.perf_counter()
     for k in range(args.warmup, args.warmup + args.steps):
-        step(k, True)
+        step(k)
     drain()
     torch.cuda.synchronize(); D.barrier()
     dt = time.perf_counter() - t0

@@ -43,6 +43,7 @@ extern "C" {
 #define TCR_STATUS_FINISHED 0      /* solve_ivp status 0: reached total_time */
 #define TCR_STATUS_EVENT 1         /* solve_ivp status 1: tc_dissipates fired (coupled_fast.py:246-256) */
 #define TCR_STATUS_STEP_FAIL (-2)  /* solve_ivp status -1: step size underflow */
+#define TCR_STATUS_STEP_OVERFLOW (-3) /* more accepted RK steps than tcr_params.max_rk_steps: raise it */
 
 /* flags bit field written by the post-step (util/compute.py:185-209) */
 #define TCR_FLAG_IS_TC 1           /* any(v >= 15) and v(2 d) >= 6.5        (compute.py:185-189) */
@@ -76,7 +77,7 @@ typedef struct {
     int32_t n_series;                       /* 15 (bam_track.py:112) */
     int32_t n_steps;                        /* int(total_time/dt_out)+1 (bam_track.py:54) */
     int32_t coupled_track;                  /* namelist.py:72 */
-    int32_t reserved;
+    int32_t max_rk_steps;                   /* capacity of the per-storm accepted-step record (0 = 64) */
     /* seeding (util/compute.py:134-175) */
     double seed_v_init;                     /* namelist.py:80 */
     double pi_gate;                         /* 35 m/s (compute.py:168) */

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(PKG_DIR, 'libtcrisk_hip.so')
 
 TCR_ABI_VERSION = 1
 TCR_NW, TCR_NCOV, TCR_MAX_SERIES, TCR_N_BASINS = 4, 10, 32, 7
-STATUS_GATED, STATUS_FINISHED, STATUS_EVENT, STATUS_STEP_FAIL = -1, 0, 1, -2
+STATUS_GATED, STATUS_FINISHED, STATUS_EVENT, STATUS_STEP_FAIL, STATUS_STEP_OVERFLOW = -1, 0, 1, -2, -3
 FLAG_IS_TC, FLAG_ACCEPTED = 1, 2
 
 DP = C.POINTER(C.c_double)
@@ -44,7 +44,7 @@ class Params(C.Structure):
                 ('v_dissipate', C.c_double), ('earth_R', C.c_double), ('box', C.c_double * 4),
                 ('fs_amp', C.c_double), ('fs_wgt', C.c_double * TCR_MAX_SERIES),
                 ('n_series', C.c_int32), ('n_steps', C.c_int32),
-                ('coupled_track', C.c_int32), ('reserved', C.c_int32),
+                ('coupled_track', C.c_int32), ('max_rk_steps', C.c_int32),
                 ('seed_v_init', C.c_double), ('pi_gate', C.c_double), ('lat_vort_fac', C.c_double),
                 ('lat_vort_power', C.c_double * TCR_N_BASINS),
                 ('atm_bl_depth', C.c_double * TCR_N_BASINS),

@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -23,8 +24,26 @@ thread_local std::string g_create_error;
 struct GridStore {
     std::vector<double> lon, lat;
     double *d_lon = nullptr, *d_lat = nullptr, *d_rlon = nullptr, *d_rlat = nullptr;
+    bool affine_lon = false, affine_lat = false;
     bool set = false;
 };
+
+// An axis is "affine" when x0 + i*dx reproduces every knot bit for bit and every cell's
+// reciprocal width 1.0/(x[i+1]-x[i]) is the same double; the kernels then never load knots.
+bool axis_is_affine(const std::vector<double> &x)
+{
+    const int n = (int)x.size();
+    const double x0 = x[0], dx = x[1] - x[0];
+    const double rdx = 1.0 / dx;
+    for (int i = 0; i < n; ++i) {
+        volatile double prod = (double)i * dx;      // no FMA contraction: mirror the device expression
+        volatile double xi = x0 + prod;
+        if (xi != x[i]) return false;
+    }
+    for (int i = 0; i + 1 < n; ++i)
+        if (1.0 / (x[i + 1] - x[i]) != rdx) return false;
+    return true;
+}
 
 struct SlotStore {
     double *wind = nullptr, *thermo = nullptr, *rh = nullptr;
@@ -46,10 +65,14 @@ struct tcr_ctx {
     double *d_stat = nullptr;
     uint8_t *d_run_mask = nullptr, *d_basin_masks = nullptr;
     // workspaces
-    double *d_fs = nullptr, *d_rec = nullptr;
-    size_t fs_cap = 0, rec_cap = 0;
+    double *d_fs = nullptr, *d_srec = nullptr;    // forcing tables, accepted-step records
+    size_t fs_cap = 0, srec_cap = 0;
     int32_t *d_tiles = nullptr;
     size_t tiles_cap = 0;
+    unsigned long long *d_queue = nullptr;      // storm queue head of k_integrate
+    double2 *d_sc_table = nullptr;              // one period of (sin, cos)(2π j / period)
+    int fs_period = 0;                          // 0: direct Fourier kernel
+    int cu_count = 256;
     // timing: four events per timed tcr_integrate_dev call since tcr_timing_enable(ctx, 1)
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -110,8 +133,23 @@ int stage_grid(tcr_ctx *ctx, GridStore &g, const tcr_grid *in, const char *what)
     HIPCHK(ctx, hipMemcpy(g.d_lat, g.lat.data(), sizeof(double) * in->nlat, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(g.d_rlon, rlon.data(), sizeof(double) * (in->nlon - 1), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(g.d_rlat, rlat.data(), sizeof(double) * (in->nlat - 1), hipMemcpyHostToDevice));
+    g.affine_lon = axis_is_affine(g.lon);
+    g.affine_lat = axis_is_affine(g.lat);
     g.set = true;
     return 0;
+}
+
+DevAxis dev_axis(const std::vector<double> &x, const double *d_x, const double *d_rx, bool affine)
+{
+    DevAxis a{};
+    a.n = (int)x.size();
+    a.affine = affine ? 1 : 0;
+    a.x = d_x; a.rx = d_rx;
+    a.x0 = x.front(); a.xn = x.back();
+    a.dx = x[1] - x[0];
+    a.rdx = 1.0 / a.dx;
+    a.inv_step = (a.n - 1) / (x.back() - x.front());
+    return a;
 }
 
 DevGrid dev_grid(const GridStore &g)
@@ -119,9 +157,8 @@ DevGrid dev_grid(const GridStore &g)
     DevGrid d{};
     if (!g.set) return d;
     d.nlon = (int)g.lon.size(); d.nlat = (int)g.lat.size();
-    d.lon = g.d_lon; d.lat = g.d_lat; d.rlon = g.d_rlon; d.rlat = g.d_rlat;
-    d.lon_inv_step = (d.nlon - 1) / (g.lon.back() - g.lon.front());
-    d.lat_inv_step = (d.nlat - 1) / (g.lat.back() - g.lat.front());
+    d.ax = dev_axis(g.lon, g.d_lon, g.d_rlon, g.affine_lon);
+    d.ay = dev_axis(g.lat, g.d_lat, g.d_rlat, g.affine_lat);
     return d;
 }
 
@@ -173,6 +210,37 @@ int grow(tcr_ctx *ctx, double **p, size_t *cap, size_t need)
 }  // namespace
 
 namespace {
+
+int launch_fourier(tcr_ctx *ctx, int64_t n, const double *phases, double *fs, hipStream_t st)
+{
+    const tcr_params &P = ctx->prm;
+    if (ctx->fs_period > 0) {
+        const size_t lds = sizeof(double2) * ((size_t)ctx->fs_period + 4 * (size_t)P.n_series);
+        hipLaunchKernelGGL(k_fourier_periodic, dim3((unsigned)n), dim3(kFsThreads), lds, st, P, n,
+                           ctx->fs_period, ctx->d_sc_table, phases, fs);
+    } else {
+        const int64_t total = n * (int64_t)P.n_steps;
+        hipLaunchKernelGGL(k_fourier_direct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, n, phases, fs);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+// Number of persistent waves of k_integrate.  Lanes pull storms from a queue, so fewer
+// lanes than storms is fine (and balances storm lifetimes); up to one wave per SIMD while
+// the batch is small, two per SIMD once every lane would still get several storms.
+unsigned integrate_waves(const tcr_ctx *ctx, int64_t n)
+{
+    const int64_t simds = (int64_t)ctx->cu_count * 4;
+    int64_t waves = (n + kWave - 1) / kWave;
+    if (const char *e = getenv("TCR_WAVES")) {
+        const long v = atol(e);
+        if (v > 0) return (unsigned)(v < waves ? v : waves);
+    }
+    if (waves > simds) waves = (n >= simds * kWave * 4) ? 2 * simds : simds;
+    return (unsigned)(waves < 1 ? 1 : waves);
+}
+
 struct DevBuf {
     std::vector<void *> ptrs;
     ~DevBuf() { for (void *p : ptrs) (void)hipFree(p); }
@@ -216,6 +284,14 @@ int tcr_ctx_create(int device, tcr_ctx **out)
         delete ctx;
         return fail(nullptr, "tcr_ctx_create: hipSetDevice/hipStreamCreate failed");
     }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        ctx->cu_count = prop.multiProcessorCount;
+    if (hipMalloc(reinterpret_cast<void **>(&ctx->d_queue), 256) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return fail(nullptr, "tcr_ctx_create: hipMalloc failed");
+    }
     *out = ctx;
     return 0;
 }
@@ -230,9 +306,9 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     }
     for (auto &s : ctx->slots) { (void)hipFree(s.wind); (void)hipFree(s.thermo); (void)hipFree(s.rh); }
     (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_run_mask); (void)hipFree(ctx->d_basin_masks);
-    (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_rec);
+    (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_srec);
     for (auto &ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
-    (void)hipFree(ctx->d_tiles);
+    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sc_table);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -242,10 +318,31 @@ int tcr_params_set(tcr_ctx *ctx, const tcr_params *p)
 {
     if (!ctx || !p) return -1;
     if (p->n_series < 1 || p->n_series > TCR_MAX_SERIES) return fail(ctx, "n_series out of range");
-    if (p->n_steps < 2) return fail(ctx, "n_steps must be >= 2");
+    if (p->n_steps < 2 || p->n_steps > 4096) return fail(ctx, "n_steps must be in [2, 4096]");
+    if (p->max_rk_steps < 0 || p->max_rk_steps > 4096) return fail(ctx, "max_rk_steps out of range");
     if (!(p->total_time > 0) || !(p->dt_out > 0)) return fail(ctx, "total_time and dt_out must be positive");
     ctx->prm = *p;
     ctx->have_prm = true;
+    // Periodic Fourier kernel when the series period is a whole number of output intervals
+    // and the output times are exactly k*dt_out (np.linspace with an exact step).
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->fs_period = 0;
+    const double per = p->T_Fs / p->dt_out;
+    const int iper = (int)per;
+    const bool regular = p->dt_out * (double)(p->n_steps - 1) == p->total_time;
+    if (regular && iper >= 2 && iper <= 4096 && (double)iper == per && (double)iper * p->dt_out == p->T_Fs) {
+        std::vector<double2> tab(iper);
+        const long double two_pi = 6.283185307179586476925286766559005768L;
+        for (int j = 0; j < iper; ++j) {
+            const long double ang = two_pi * (long double)j / (long double)iper;
+            tab[j] = make_double2((double)sinl(ang), (double)cosl(ang));
+        }
+        if (ctx->d_sc_table) HIPCHK(ctx, hipFree(ctx->d_sc_table));
+        ctx->d_sc_table = nullptr;
+        if (dev_alloc(ctx, &ctx->d_sc_table, (size_t)iper)) return -1;
+        HIPCHK(ctx, hipMemcpy(ctx->d_sc_table, tab.data(), sizeof(double2) * iper, hipMemcpyHostToDevice));
+        ctx->fs_period = iper;
+    }
     return 0;
 }
 
@@ -387,34 +484,34 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
     const tcr_params &P = ctx->prm;
     const size_t ns = (size_t)P.n_steps;
     if (grow(ctx, &ctx->d_fs, &ctx->fs_cap, (size_t)n * ns * 4)) return -1;
-    if (grow(ctx, &ctx->d_rec, &ctx->rec_cap, (size_t)n * ns * kRec)) return -1;
+    const int max_rk = P.max_rk_steps > 0 ? P.max_rk_steps : 64;
+    if (grow(ctx, &ctx->d_srec, &ctx->srec_cap, (size_t)n * max_rk * kStepRec)) return -1;
 
     hipEvent_t *ev = nullptr;
     if (ctx->timing && timing_events(ctx, &ev)) return -1;
     if (ev) HIPCHK(ctx, hipEventRecord(ev[0], st));
-    {
-        const int64_t total = n * (int64_t)ns;
-        const unsigned blocks = (unsigned)((total + 255) / 256);
-        hipLaunchKernelGGL(k_fourier_table, dim3(blocks), dim3(256), 0, st, P, n, in->phases, ctx->d_fs);
-    }
+    if (launch_fourier(ctx, n, in->phases, ctx->d_fs, st)) return -1;
     if (ev) HIPCHK(ctx, hipEventRecord(ev[1], st));
     {
         KArgs a{};
         a.P = P; a.D = dev_fields(ctx); a.n = n;
         a.lon0 = in->lon0; a.lat0 = in->lat0; a.v0 = in->v0; a.m0 = in->m0; a.h_bl = in->h_bl;
-        a.slot = in->slot; a.phases = in->phases; a.fs = ctx->d_fs; a.rec = ctx->d_rec;
+        a.slot = in->slot; a.phases = in->phases; a.fs = ctx->d_fs; a.srec = ctx->d_srec; a.max_rk_steps = max_rk;
         a.n_valid = out->n_valid; a.status = out->status; a.nfev = out->nfev;
         a.n_accept = out->n_accept; a.n_reject = out->n_reject;
-        const unsigned blocks = (unsigned)((n + kWave - 1) / kWave);
-        hipLaunchKernelGGL(k_integrate, dim3(blocks), dim3(kWave), 0, st, a);
+        a.queue = ctx->d_queue;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_integrate, dim3(integrate_waves(ctx, n)), dim3(kWave), 0, st, a);
     }
     if (ev) HIPCHK(ctx, hipEventRecord(ev[2], st));
     {
-        PArgs a{};
-        a.P = P; a.n = n; a.rec = ctx->d_rec; a.n_valid = out->n_valid; a.status = out->status;
+        EArgs a{};
+        a.P = P; a.D = dev_fields(ctx); a.n = n; a.max_rk_steps = max_rk; a.srec = ctx->d_srec; a.fs = ctx->d_fs;
+        a.slot = in->slot; a.n_valid = out->n_valid; a.status = out->status; a.n_accept = out->n_accept;
         a.lon = out->lon; a.lat = out->lat; a.v = out->v; a.m = out->m; a.vmax = out->vmax;
         a.envw = out->envw; a.flags = out->flags;
-        hipLaunchKernelGGL(k_post_unpack, dim3((unsigned)n), dim3(kPostThreads), 0, st, a);
+        const size_t lds = sizeof(double) * ((size_t)max_rk + 2 * ns);
+        hipLaunchKernelGGL(k_emit, dim3((unsigned)n), dim3(kEmitThreads), lds, st, a);
     }
     if (ev) HIPCHK(ctx, hipEventRecord(ev[3], st));
     HIPCHK(ctx, hipGetLastError());
@@ -470,10 +567,7 @@ int tcr_fourier_table_host(tcr_ctx *ctx, int64_t n, const double *phases, double
     const double *d_ph = B.put(phases, (size_t)n * 4 * N);
     double *d_fs = B.get<double>((size_t)n * ns * 4);
     if (!d_ph || !d_fs) return fail(ctx, "tcr_fourier_table_host: device allocation failed");
-    const int64_t total = n * (int64_t)ns;
-    hipLaunchKernelGGL(k_fourier_table, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                       ctx->prm, n, d_ph, d_fs);
-    HIPCHK(ctx, hipGetLastError());
+    if (launch_fourier(ctx, n, d_ph, d_fs, ctx->stream)) return -1;
     std::vector<double> h((size_t)n * ns * 4);
     HIPCHK(ctx, hipMemcpyAsync(h.data(), d_fs, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -19,14 +19,21 @@ constexpr double kPi = 3.141592653589793;
 constexpr int kWindStride = 16;     // 14 fields + 2 pad  -> one 128-B line per grid point
 constexpr int kThermoStride = 4;    // vpot, chi, mld, strat -> 32 B per grid point
 constexpr int kStaticStride = 2;    // land, bathy -> 16 B per grid point
-constexpr int kRec = 8;             // record: lon, lat, v, m, u250, v250, u850, v850
+constexpr int kStepRec = 24;         // accepted-step record: t_old, h, t_new, -, y_old[4], Q[4][4]
 
 // Rectilinear grid: knots + per-cell reciprocal widths (host-computed 1.0/(x[i+1]-x[i]),
 // the same IEEE division fpbspl.f performs) + a uniform-grid guess for the cell index.
+struct DevAxis {
+    int n;
+    int affine;              // knots are bitwise x0 + i*dx and every 1/(x[i+1]-x[i]) == rdx (host-verified)
+    const double *x, *rx;    // knots, per-cell reciprocal widths (general path)
+    double x0, xn, dx, rdx;  // first/last knot; affine step and its reciprocal
+    double inv_step;         // (n-1)/(xn-x0): cell-index guess
+};
+
 struct DevGrid {
     int nlon, nlat;
-    const double *lon, *lat, *rlon, *rlat;
-    double lon_inv_step, lat_inv_step;
+    DevAxis ax, ay;
 };
 
 // One month slot.  Field-interleaved ("AoS at the grid point") so that a
@@ -50,22 +57,34 @@ struct Cell {
     double w0, w1;
 };
 
-// fpbisp.f (clamp + interval search) and fpbspl.f (k = 1 weights)
-__device__ __forceinline__ Cell locate(const double *__restrict__ x, const double *__restrict__ rx,
-                                       int n, double inv_step, double arg)
+// fpbisp.f (clamp + interval search) and fpbspl.f (k = 1 weights).
+// Affine axes (ERA5's 1 deg / 0.25 deg grids, CMIP regular grids) need no memory
+// traffic at all: the host has verified that x0 + i*dx reproduces every knot
+// bit for bit and that 1/(x[i+1]-x[i]) is the same double in every cell.
+__device__ __forceinline__ Cell locate(const DevAxis &A, double arg)
 {
-    const double x0 = x[0], xn = x[n - 1];
-    if (arg < x0) arg = x0;
-    if (arg > xn) arg = xn;
-    int i = (int)((arg - x0) * inv_step);
+    if (arg < A.x0) arg = A.x0;
+    if (arg > A.xn) arg = A.xn;
+    const int n = A.n;
+    int i = (int)((arg - A.x0) * A.inv_step);
     i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
-    while (i < n - 2 && arg >= x[i + 1]) ++i;
-    while (i > 0 && arg < x[i]) --i;
-    const double f = rx[i];
     Cell c;
-    c.i = i;
-    c.w0 = 0.0 + f * (x[i + 1] - arg);
-    c.w1 = f * (arg - x[i]);
+    if (A.affine) {
+        double xl = A.x0 + (double)i * A.dx, xr = A.x0 + (double)(i + 1) * A.dx;
+        if (i < n - 2 && arg >= xr) { ++i; xl = xr; xr = A.x0 + (double)(i + 1) * A.dx; }
+        else if (i > 0 && arg < xl) { --i; xr = xl; xl = A.x0 + (double)i * A.dx; }
+        c.i = i;
+        c.w0 = 0.0 + A.rdx * (xr - arg);
+        c.w1 = A.rdx * (arg - xl);
+    } else {
+        const double *__restrict__ x = A.x;
+        while (i < n - 2 && arg >= x[i + 1]) ++i;
+        while (i > 0 && arg < x[i]) --i;
+        const double f = A.rx[i];
+        c.i = i;
+        c.w0 = 0.0 + f * (x[i + 1] - arg);
+        c.w1 = f * (arg - x[i]);
+    }
     return c;
 }
 
@@ -136,8 +155,8 @@ __device__ __forceinline__ void env_winds(const tcr_params &P, const DevFields &
                                           double t, double (&w)[4])
 {
     if (lon != lon || t != t) { w[0] = w[1] = w[2] = w[3] = 0.0; return; }
-    const Cell cx = locate(D.wg.lon, D.wg.rlon, D.wg.nlon, D.wg.lon_inv_step, lon);
-    const Cell cy = locate(D.wg.lat, D.wg.rlat, D.wg.nlat, D.wg.lat_inv_step, lat);
+    const Cell cx = locate(D.wg.ax, lon);
+    const Cell cy = locate(D.wg.ay, lat);
     double q[14];
     bilinear<14, kWindStride>(S.wind, D.wg.nlon, cx, cy, q);
     double F[4];
@@ -198,21 +217,27 @@ __device__ __forceinline__ void steering(const tcr_params &P, double v, double (
 struct Rhs {
     double d[4];     // d lon/dt, d lat/dt, dv/dt, dm/dt
     double alpha;    // ocean feedback (probe only)
+    double shear, vpot, chi;   // what the ventilation gate needs (coupled_fast.py:238-244)
 };
 
-// coupled_fast.py:196-207 (dydt) with _step_bam_track (bam_track.py:131-144), _dvdt
-// (:141-150), _calc_alpha/_calc_z (:65-94), _dmdt (:175-180).
-__device__ __forceinline__ Rhs rhs_eval(const tcr_params &P, const DevFields &D, const DevSlot &S,
-                                        const double *__restrict__ fs, double h_bl, double t,
-                                        double lon, double lat, double v, double m)
+// coupled_fast.py:196-207 (dydt) given the raw env winds at (lon, lat, t):
+// _step_bam_track (bam_track.py:131-144), _dvdt (:141-150), _calc_alpha/_calc_z (:65-94),
+// _dmdt (:175-180).  `shear` is the gate's S of the *raw* winds (coupled_fast.py:238).
+__device__ __forceinline__ Rhs rhs_from_winds(const tcr_params &P, const DevFields &D, const DevSlot &S,
+                                              double h_bl, double lon, double lat, double v, double m,
+                                              const double (&w_raw)[4])
 {
     Rhs r;
     double c[2], w[4], vb0, vb1;
     steering(P, v, c);
+    {
+        const double du = w_raw[0] - w_raw[2], dw = w_raw[1] - w_raw[3];
+        r.shear = sqrt(du * du + dw * dw);
+    }
     if (fabs(lat) >= 80) {
         vb0 = vb1 = 0.0; w[0] = w[1] = w[2] = w[3] = 0.0;
     } else {
-        env_winds(P, D, S, fs, lon, lat, t, w);
+        w[0] = w_raw[0]; w[1] = w_raw[1]; w[2] = w_raw[2]; w[3] = w_raw[3];
         const double cl = cos(lat * (kPi / 180.0));                        // np.deg2rad
         vb0 = (w[0] * c[0] + w[2] * c[1]) + P.u_beta * cl;
         vb1 = (w[1] * c[0] + w[3] * c[1]) + (sign_of(lat) * P.v_beta) * cl;
@@ -221,12 +246,12 @@ __device__ __forceinline__ Rhs rhs_eval(const tcr_params &P, const DevFields &D,
     r.d[1] = vb1 / P.earth_R * 180. / kPi;
 
     // thermo grid: vpot, chi, mld, strat; hi-res grid: land, bathy
-    const Cell tx = locate(D.tg.lon, D.tg.rlon, D.tg.nlon, D.tg.lon_inv_step, lon);
-    const Cell ty = locate(D.tg.lat, D.tg.rlat, D.tg.nlat, D.tg.lat_inv_step, lat);
+    const Cell tx = locate(D.tg.ax, lon);
+    const Cell ty = locate(D.tg.ay, lat);
     double th[4];
     bilinear<4, kThermoStride>(S.thermo, D.tg.nlon, tx, ty, th);
-    const Cell hx = locate(D.hg.lon, D.hg.rlon, D.hg.nlon, D.hg.lon_inv_step, lon);
-    const Cell hy = locate(D.hg.lat, D.hg.rlat, D.hg.nlat, D.hg.lat_inv_step, lat);
+    const Cell hx = locate(D.hg.ax, lon);
+    const Cell hy = locate(D.hg.ay, lat);
     double lb[2];
     bilinear<2, kStaticStride>(D.stat, D.hg.nlon, hx, hy, lb);
     const double vp = (lb[0] == 1.0) ? 0.0 : th[0];                        // coupled_fast.py:35-58
@@ -248,9 +273,19 @@ __device__ __forceinline__ Rhs rhs_eval(const tcr_params &P, const DevFields &D,
     if (dv != dv) dv = 0.0;
     const double du = w[0] - w[2], dw = w[1] - w[3];
     const double venti = sqrt(du * du + dw * dw) * th[1];
+    r.vpot = vp; r.chi = th[1];
     r.d[2] = dv;
     r.d[3] = 0.5 * P.Ck / h_bl * ((1 - m) * v - venti * m);
     return r;
+}
+
+__device__ __forceinline__ Rhs rhs_eval(const tcr_params &P, const DevFields &D, const DevSlot &S,
+                                        const double *__restrict__ fs, double h_bl, double t,
+                                        double lon, double lat, double v, double m)
+{
+    double w[4];
+    env_winds(P, D, S, fs, lon, lat, t, w);
+    return rhs_from_winds(P, D, S, h_bl, lon, lat, v, m, w);
 }
 
 // coupled_fast.py:246-256 with util/basins.py:32-37 (dx = 1); always >= 0

@@ -1,8 +1,24 @@
-// HIP kernels of the storm hot path (gfx950).  One wave64 per workgroup, one
-// lane per storm: the state of a storm (y, f, step size, event value, output
-// cursor) lives in VGPRs, the seven Runge–Kutta stage derivatives live in LDS
-// (lane-contiguous, conflict-free ds_read_b64), fields are read through L1/L2
-// from the interleaved HBM layout described in tcr_device.h.
+// HIP kernels of the storm hot path (gfx950, fp64).
+//
+// The hot path is split where its parallelism changes:
+//   k_integrate  the inherently sequential part of a storm (adaptive RK45 steps up to the
+//                terminal event): ~60 RHS evaluations per storm on average, one lane per
+//                storm at a time, leaving one dense-output record per accepted step;
+//   k_emit       everything that is independent per hourly output sample (2/3 of all field
+//                evaluations): dense-output evaluation, env-wind recompute, vmax, accept
+//                flags, NaN-padded planes — one thread per sample, full occupancy.
+//
+// k_integrate — persistent, one lane per storm *at a time*:
+//   * every lane runs a small state machine whose only expensive state is "evaluate
+//     fun(t, y)"; RK stages and the two evaluations of SciPy's initial-step heuristic
+//     funnel through that one evaluation, so lanes of a wave stay converged on the
+//     costly code whatever step / stage each storm is at;
+//   * a lane whose storm ends (dissipation, basin exit, 15 days) pulls the next storm
+//     from a device-wide queue (wave-aggregated atomic), which removes the 3x
+//     lifetime imbalance between storms from the critical path;
+//   * storm state lives in VGPRs, the 7 RK stage derivatives live in LDS,
+//     lane-contiguous (conflict-free ds_read_b64); fields are gathered through L1/L2 from the interleaved HBM
+//     layout of tcr_device.h with 16-B loads.
 //
 // The integrator is SciPy's RK45 restated per lane:
 //   scipy/integrate/_ivp/rk.py:14-79 (rk_step), :111-176 (_step_impl), :293-420
@@ -21,16 +37,19 @@ struct KArgs {
     const int32_t *slot;
     const double *phases;    // [n][4][n_series]
     double *fs;              // [n][n_steps][4]
-    double *rec;             // [n][n_steps][kRec]
+    double *srec;            // [n][max_rk_steps][kStepRec] accepted-step records
     int32_t *n_valid, *status, *nfev, *n_accept, *n_reject;
+    unsigned long long *queue;   // next storm index to hand out (zeroed before the launch)
+    int max_rk_steps;
 };
 
 // ---------------------------------------------------------------------------
-// gen_f (track/bam_track.py:23-31): one thread per (storm, sample), 4 series.
-// arg keeps NumPy's evaluation order 2π·((n·t)/T + x).
-__global__ __launch_bounds__(256) void k_fourier_table(tcr_params P, int64_t n,
-                                                        const double *__restrict__ phases,
-                                                        double *__restrict__ fs)
+// gen_f (track/bam_track.py:23-31), direct form: one thread per (storm, sample),
+// 4 series x n_series sines, NumPy's evaluation order 2π·((n·t)/T + x).
+// Used when the Fourier period is not a whole number of output intervals.
+__global__ __launch_bounds__(256) void k_fourier_direct(tcr_params P, int64_t n,
+                                                         const double *__restrict__ phases,
+                                                         double *__restrict__ fs)
 {
     const int ns = P.n_steps, N = P.n_series;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -56,18 +75,69 @@ __global__ __launch_bounds__(256) void k_fourier_table(tcr_params P, int64_t n,
     o[1] = make_double2(out[2], out[3]);
 }
 
+// gen_f, periodic form.  With T_Fs = period * dt_out (the reference's defaults: 20 d
+// and 1 h -> 480) the phase of harmonic n at output sample k is
+//     2π·(n·k mod period)/period  +  2π·x_{s,n},
+// so  sin(.) = S[j]·cos(2πx) + C[j]·sin(2πx)  with j = n·k mod period and (S, C) a
+// host-computed (long-double accurate) table of one period.  Per storm that is 60
+// sincospi instead of 21 660 sines.  It evaluates the same series the reference
+// does; the values differ from NumPy's only by the rounding of NumPy's own argument
+// 2π·(n t/T + x) (|Δ| ~ 1e-14, tests/test_gpu_parity.py states the bound).
+// One workgroup per storm; thread = (sample, series) pairs, coalesced stores.
+constexpr int kFsThreads = 128;
+
+__global__ __launch_bounds__(kFsThreads) void k_fourier_periodic(tcr_params P, int64_t n, int period,
+                                                                  const double2 *__restrict__ sc_table,
+                                                                  const double *__restrict__ phases,
+                                                                  double *__restrict__ fs)
+{
+    extern __shared__ double2 lds[];            // [period] table, then [4*N] (sin, cos)(2π x)
+    const int N = P.n_series, ns = P.n_steps;
+    double2 *tab = lds, *ph = lds + period;
+    const int64_t storm = blockIdx.x;
+    for (int j = threadIdx.x; j < period; j += kFsThreads) tab[j] = sc_table[j];
+    if (threadIdx.x < 4 * N) {
+        const double x = phases[storm * 4 * N + threadIdx.x];
+        ph[threadIdx.x] = make_double2(sinpi(2.0 * x), cospi(2.0 * x));
+    }
+    __syncthreads();
+    double *out = fs + storm * ns * 4;
+    for (int p = threadIdx.x; p < ns * 4; p += kFsThreads) {
+        const int k = p >> 2, s = p & 3;
+        double acc = 0.0;
+        int j = 0;                               // (n * k) mod period, built incrementally
+        const int kk = k % period;
+        for (int h = 0; h < N; ++h) {
+            j += kk; if (j >= period) j -= period;
+            const double2 a = tab[j], b = ph[s * N + h];
+            const double term = P.fs_wgt[h] * (a.x * b.y + a.y * b.x);
+            acc = (h == 0) ? term : acc + term;
+        }
+        out[p] = P.fs_amp * acc;
+    }
+}
+
 // ---------------------------------------------------------------------------
-__constant__ double RK_C[6] = {0, 1. / 5, 3. / 10, 4. / 5, 8. / 9, 1};
-__constant__ double RK_A[6][5] = {
-    {0, 0, 0, 0, 0},
-    {1. / 5, 0, 0, 0, 0},
-    {3. / 40, 9. / 40, 0, 0, 0},
-    {44. / 45, -56. / 15, 32. / 9, 0, 0},
-    {19372. / 6561, -25360. / 2187, 64448. / 6561, -212. / 729, 0},
-    {9017. / 3168, -355. / 33, 46732. / 5247, 49. / 176, -5103. / 18656}};
-__constant__ double RK_B[6] = {35. / 384, 0, 500. / 1113, 125. / 192, -2187. / 6784, 11. / 84};
-__constant__ double RK_E[7] = {-71. / 57600, 0, 71. / 16695, -71. / 1920, 17253. / 339200, -22. / 525, 1. / 40};
-__constant__ double RK_P[7][4] = {
+// Dormand–Prince tableau exactly as SciPy spells it (rk.py:384-408)
+#define A10 (1. / 5)
+#define A20 (3. / 40)
+#define A21 (9. / 40)
+#define A30 (44. / 45)
+#define A31 (-56. / 15)
+#define A32 (32. / 9)
+#define A40 (19372. / 6561)
+#define A41 (-25360. / 2187)
+#define A42 (64448. / 6561)
+#define A43 (-212. / 729)
+#define A50 (9017. / 3168)
+#define A51 (-355. / 33)
+#define A52 (46732. / 5247)
+#define A53 (49. / 176)
+#define A54 (-5103. / 18656)
+__device__ constexpr double RK_C[7] = {0, 1. / 5, 3. / 10, 4. / 5, 8. / 9, 1, 1};
+__device__ constexpr double RK_B[6] = {35. / 384, 0, 500. / 1113, 125. / 192, -2187. / 6784, 11. / 84};
+__device__ constexpr double RK_E[7] = {-71. / 57600, 0, 71. / 16695, -71. / 1920, 17253. / 339200, -22. / 525, 1. / 40};
+__device__ constexpr double RK_P[7][4] = {
     {1, -8048581381. / 2820520608, 8663915743. / 2820520608, -12715105075. / 11282082432},
     {0, 0, 0, 0},
     {0, 131558114200. / 32700410799, -68118460800. / 10900136933, 87487479700. / 32700410799},
@@ -82,115 +152,143 @@ __device__ __forceinline__ double rms4(double a, double b, double c, double d)
     return sqrt(a * a + b * b + c * c + d * d) / 2.0;
 }
 
-constexpr int kWave = 64;
+// Number of t_eval samples <= t_emit: np.searchsorted(t_eval, t, side='right') (ivp.py:708)
+__device__ __forceinline__ int samples_upto(const tcr_params &P, double t_emit)
+{
+    const int ns = P.n_steps;
+    int k = (int)(t_emit / (P.total_time / (double)(ns - 1)));
+    k = k < 0 ? 0 : (k > ns - 1 ? ns - 1 : k);
+    while (k + 1 < ns && ts_at(P, k + 1) <= t_emit) ++k;
+    while (k >= 0 && ts_at(P, k) > t_emit) --k;
+    return k + 1;
+}
 
+constexpr int kWave = 64;
+enum : int { PH_IDLE = 0, PH_F0, PH_F1, PH_STAGE };
+constexpr int kRunning = 99;
+
+// k_integrate: the sequential part of a storm — RK45 steps until the terminal event.
+// Every accepted step leaves one kStepRec-double record (t_old, h, t_new, y_old, Q) from
+// which k_emit later evaluates the hourly samples in parallel.
 __global__ __launch_bounds__(kWave) void k_integrate(KArgs a)
 {
-    // K[stage][component][lane]
-    __shared__ double K[7][4][kWave];
+    // Kl[(stage*4 + component)*64 + lane]
+    __shared__ double Kl[7 * 4 * kWave];
     const tcr_params &P = a.P;
     const DevFields &D = a.D;
     const int lane = threadIdx.x;
-    const int64_t sid = (int64_t)blockIdx.x * kWave + lane;
-    if (sid >= a.n) return;
-
     const int ns = P.n_steps;
-    const DevSlot S = D.slots[a.slot[sid]];
-    const double *fs = a.fs + sid * ns * 4;
-    const double h_bl = a.h_bl[sid];
-    double y[4] = {a.lon0[sid], a.lat0[sid], a.v0[sid], a.m0[sid]};
-    double *rec = a.rec + sid * ns * kRec;
+    const double tb = P.total_time;
+#define KS(j, i) Kl[((j) * 4 + (i)) * kWave + lane]
 
-    int status = 99, nfev = 0, nacc = 0, nrej = 0, next_out = 0;
+    // ---- per-lane storm state
+    long long sid = -1;
+    int phase = PH_IDLE, st = 0, status = kRunning, nfev = 0, nacc = 0, nrej = 0, next_out = 0;
+    bool exhausted = false, rejected = false;
+    DevSlot S{};
+    const double *fs = nullptr;
+    double *srec = nullptr;
+    double h_bl = 0.0;
+    double y[4] = {0, 0, 0, 0}, f[4] = {0, 0, 0, 0}, yn[4] = {0, 0, 0, 0};
+    double e[5] = {0, 0, 0, 0, 0};          // evaluation point: t, lon, lat, v, m
+    double t = 0, h = 0, ha = 0, h_abs = 0, t_new = 0, g = 0;
 
-    // ventilation gate (coupled_fast.py:238-244)
-    {
-        double w[4];
-        env_winds(P, D, S, fs, y[0], y[1], 0.0, w);
-        const double du = w[0] - w[2], dw = w[1] - w[3];
-        const double Sh = sqrt(du * du + dw * dw);
-        const Cell tx = locate(D.tg.lon, D.tg.rlon, D.tg.nlon, D.tg.lon_inv_step, y[0]);
-        const Cell ty = locate(D.tg.lat, D.tg.rlat, D.tg.nlat, D.tg.lat_inv_step, y[1]);
-        double th[4];
-        bilinear<4, kThermoStride>(S.thermo, D.tg.nlon, tx, ty, th);
-        const Cell hx = locate(D.hg.lon, D.hg.rlon, D.hg.nlon, D.hg.lon_inv_step, y[0]);
-        const Cell hy = locate(D.hg.lat, D.hg.rlat, D.hg.nlat, D.hg.lat_inv_step, y[1]);
-        double lb[2];
-        bilinear<2, kStaticStride>(D.stat, D.hg.nlon, hx, hy, lb);
-        const double vp = (lb[0] == 1.0) ? 0.0 : th[0];
-        if (vp > 0 && Sh * th[1] / vp >= 1) status = TCR_STATUS_GATED;
-    }
+    auto finalize = [&]() {
+        a.n_valid[sid] = next_out;
+        a.status[sid] = status;
+        a.nfev[sid] = (status == TCR_STATUS_GATED) ? 0 : nfev;
+        a.n_accept[sid] = nacc;
+        a.n_reject[sid] = nrej;
+        phase = PH_IDLE;
+    };
+    // one attempt of _step_impl's while-loop: clip to t_bound, stage 1 input (rk.py:137-146)
+    auto attempt_setup = [&]() {
+        const double min_step = 10 * fabs(nextafter(t, INFINITY) - t);
+        if (ha < min_step) { status = TCR_STATUS_STEP_FAIL; finalize(); return; }
+        h = ha;
+        t_new = t + h;
+        if (t_new - tb > 0) t_new = tb;
+        h = t_new - t;
+        ha = fabs(h);
+        for (int i = 0; i < 4; ++i) {
+            KS(0, i) = f[i];
+            const double dy = 0.0 + f[i] * A10;
+            e[1 + i] = y[i] + dy * h;
+        }
+        e[0] = t + RK_C[1] * h;
+        st = 1;
+        phase = PH_STAGE;
+    };
+    auto begin_step = [&]() {
+        const double min_step = 10 * fabs(nextafter(t, INFINITY) - t);
+        ha = h_abs;
+        if (ha > P.max_step) ha = P.max_step;
+        else if (ha < min_step) ha = min_step;
+        rejected = false;
+        attempt_setup();
+    };
 
-    if (status == 99) {
-        const double tb = P.total_time;
-        double t = 0.0, f[4], h_abs;
-        // RungeKutta.__init__: f0 = fun(t0, y0); select_initial_step (common.py:68-134)
-        {
-            double sc[4], y1[4], h0 = 0.0, d1 = 0.0;
-            double yy[4] = {y[0], y[1], y[2], y[3]};
-            double tt = t;
-            for (int q = 0; q < 2; ++q) {
-                const Rhs r = rhs_eval(P, D, S, fs, h_bl, tt, yy[0], yy[1], yy[2], yy[3]);
-                ++nfev;
-                if (q == 0) {
-                    for (int i = 0; i < 4; ++i) { f[i] = r.d[i]; sc[i] = P.atol + fabs(y[i]) * P.rtol; }
-                    const double d0 = rms4(y[0] / sc[0], y[1] / sc[1], y[2] / sc[2], y[3] / sc[3]);
-                    d1 = rms4(f[0] / sc[0], f[1] / sc[1], f[2] / sc[2], f[3] / sc[3]);
-                    h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-                    h0 = h0 < tb ? h0 : tb;
-                    for (int i = 0; i < 4; ++i) { y1[i] = y[i] + h0 * 1.0 * f[i]; yy[i] = y1[i]; }
-                    tt = t + h0 * 1.0;
+    for (;;) {
+        // ---- refill idle lanes from the storm queue (wave-aggregated atomic)
+        const unsigned long long want = __ballot(phase == PH_IDLE && !exhausted);
+        if (want) {
+            const int leader = __ffsll((long long)want) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(a.queue, (unsigned long long)__popcll(want));
+            base = __shfl(base, leader);
+            if (phase == PH_IDLE && !exhausted) {
+                sid = (long long)(base + (unsigned long long)__popcll(want & ((1ull << lane) - 1ull)));
+                if (sid >= a.n) {
+                    exhausted = true;
                 } else {
-                    const double d2 = rms4((r.d[0] - f[0]) / sc[0], (r.d[1] - f[1]) / sc[1],
-                                           (r.d[2] - f[2]) / sc[2], (r.d[3] - f[3]) / sc[3]) / h0;
-                    double h1;
-                    if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
-                    else h1 = pow(0.01 / fmax(d1, d2), 0.2);
-                    h_abs = fmin(fmin(100 * h0, h1), fmin(tb, P.max_step));
+                    S = D.slots[a.slot[sid]];
+                    fs = a.fs + sid * ns * 4;
+                    srec = a.srec + sid * (long long)a.max_rk_steps * kStepRec;
+                    h_bl = a.h_bl[sid];
+                    y[0] = a.lon0[sid]; y[1] = a.lat0[sid]; y[2] = a.v0[sid]; y[3] = a.m0[sid];
+                    status = kRunning; nfev = 0; nacc = 0; nrej = 0; next_out = 0;
+                    t = 0.0;
+                    e[0] = 0.0; e[1] = y[0]; e[2] = y[1]; e[3] = y[2]; e[4] = y[3];
+                    phase = PH_F0;
                 }
             }
         }
-        double g = event_fn(P, y[0], y[1], y[2]);
+        if (!__ballot(phase != PH_IDLE)) break;
 
-        while (status == 99) {
-            const double min_step = 10 * fabs(nextafter(t, INFINITY) - t);
-            double ha = h_abs;
-            if (ha > P.max_step) ha = P.max_step;
-            else if (ha < min_step) ha = min_step;
-            bool accepted = false, rejected = false, failed = false;
-            double h = 0.0, t_new = 0.0, y_new[4], f_new[4];
-            while (!accepted) {
-                if (ha < min_step) { failed = true; break; }
-                h = ha;
-                t_new = t + h;
-                if (t_new - tb > 0) t_new = tb;
-                h = t_new - t;
-                ha = fabs(h);
-                // rk_step: K[s] = fun(t + c_s h, y + h * sum_j a_sj K[j])
-                for (int i = 0; i < 4; ++i) K[0][i][lane] = f[i];
-                for (int st = 1; st <= 6; ++st) {
-                    double ys[4];
-                    for (int i = 0; i < 4; ++i) {
-                        double dy = 0.0;
-                        if (st < 6) {
-                            for (int j = 0; j < st; ++j) dy += K[j][i][lane] * RK_A[st][j];
-                            ys[i] = y[i] + dy * h;
-                        } else {
-                            for (int j = 0; j < 6; ++j) dy += K[j][i][lane] * RK_B[j];
-                            ys[i] = y[i] + h * dy;
-                        }
+        // ---- the one expensive state: fun(t, y) at the evaluation point
+        Rhs r{};
+        if (phase != PH_IDLE) r = rhs_eval(P, D, S, fs, h_bl, e[0], e[1], e[2], e[3], e[4]);
+
+        // ---- bookkeeping of whatever this lane was waiting for
+        if (phase == PH_STAGE) {
+            ++nfev;
+            for (int i = 0; i < 4; ++i) KS(st, i) = r.d[i];
+            if (st < 6) {
+                ++st;
+                // rk_step: dy = dot(K[:s].T, a[:s]) * h (rk.py:64-66); y_new = y + h * dot(K[:-1].T, B) (:68)
+                for (int i = 0; i < 4; ++i) {
+                    double dy = 0.0;
+                    switch (st) {
+                    case 2: dy += KS(0, i) * A20; dy += KS(1, i) * A21; break;
+                    case 3: dy += KS(0, i) * A30; dy += KS(1, i) * A31; dy += KS(2, i) * A32; break;
+                    case 4: dy += KS(0, i) * A40; dy += KS(1, i) * A41; dy += KS(2, i) * A42; dy += KS(3, i) * A43; break;
+                    case 5: dy += KS(0, i) * A50; dy += KS(1, i) * A51; dy += KS(2, i) * A52; dy += KS(3, i) * A53;
+                            dy += KS(4, i) * A54; break;
+                    default:
+                        for (int j = 0; j < 6; ++j) dy += KS(j, i) * RK_B[j];
+                        break;
                     }
-                    const double ts = (st < 6) ? t + RK_C[st] * h : t + h;
-                    const Rhs r = rhs_eval(P, D, S, fs, h_bl, ts, ys[0], ys[1], ys[2], ys[3]);
-                    ++nfev;
-                    for (int i = 0; i < 4; ++i) K[st][i][lane] = r.d[i];
-                    if (st == 6) for (int i = 0; i < 4; ++i) { y_new[i] = ys[i]; f_new[i] = r.d[i]; }
+                    if (st < 6) e[1 + i] = y[i] + dy * h;
+                    else { e[1 + i] = y[i] + h * dy; yn[i] = e[1 + i]; }
                 }
+                e[0] = (st < 6) ? t + RK_C[st] * h : t + h;
+            } else {
+                // error estimate and step-size control (rk.py:147-165)
                 double er[4];
                 for (int i = 0; i < 4; ++i) {
-                    const double sc = P.atol + fmax(fabs(y[i]), fabs(y_new[i])) * P.rtol;
+                    const double sc = P.atol + fmax(fabs(y[i]), fabs(yn[i])) * P.rtol;
                     double acc = 0.0;
-                    for (int j = 0; j < 7; ++j) acc += K[j][i][lane] * RK_E[j];
+                    for (int j = 0; j < 7; ++j) acc += KS(j, i) * RK_E[j];
                     er[i] = (acc * h) / sc;
                 }
                 const double err = rms4(er[0], er[1], er[2], er[3]);
@@ -198,77 +296,105 @@ __global__ __launch_bounds__(kWave) void k_integrate(KArgs a)
                     double fac = (err == 0) ? 10.0 : fmin(10.0, 0.9 * pow(err, -0.2));
                     if (rejected && fac > 1) fac = 1;
                     ha *= fac;
-                    accepted = true;
+                    // step record for k_emit: t_old, h, t_new, -, y_old[4], Q = K^T P (rk.py:179-181)
+                    if (nacc < a.max_rk_steps) {
+                        double2 *o = reinterpret_cast<double2 *>(srec + (size_t)nacc * kStepRec);
+                        o[0] = make_double2(t, h);
+                        o[1] = make_double2(t_new, 0.0);
+                        o[2] = make_double2(y[0], y[1]);
+                        o[3] = make_double2(y[2], y[3]);
+                        for (int i = 0; i < 4; ++i) {
+                            double q[4];
+                            for (int k = 0; k < 4; ++k) {
+                                double acc = 0.0;
+                                for (int j = 0; j < 7; ++j) acc += KS(j, i) * RK_P[j][k];
+                                q[k] = acc;
+                            }
+                            o[4 + 2 * i] = make_double2(q[0], q[1]);
+                            o[5 + 2 * i] = make_double2(q[2], q[3]);
+                        }
+                    }
+                    ++nacc;
+                    const double t_old = t;
+                    t = t_new;
+                    for (int i = 0; i < 4; ++i) { y[i] = yn[i]; f[i] = r.d[i]; }
+                    h_abs = ha;
+                    if (t - tb >= 0) status = TCR_STATUS_FINISHED;
+                    // terminal event at the step end (ivp.py:673-693); g >= 0 always, so a trigger
+                    // is g_new == 0 (root = step end) or g0 == 0 on the first step (root = t0)
+                    const double g_new = event_fn(P, y[0], y[1], y[2]);
+                    double t_emit = t;
+                    if (g == 0.0) { status = TCR_STATUS_EVENT; t_emit = t_old; }
+                    else if (g_new == 0.0) status = TCR_STATUS_EVENT;
+                    g = g_new;
+                    next_out = samples_upto(P, t_emit);         // t_eval emission count (ivp.py:706-723)
+                    if (status == kRunning && nacc >= a.max_rk_steps) status = TCR_STATUS_STEP_OVERFLOW;
+                    if (status != kRunning) finalize();
+                    else begin_step();
                 } else {
                     ha *= fmax(0.2, 0.9 * pow(err, -0.2));
                     rejected = true;
                     ++nrej;
+                    attempt_setup();
                 }
             }
-            if (failed) { status = TCR_STATUS_STEP_FAIL; break; }
-            ++nacc;
-            const double t_old = t;
-            const double y_old[4] = {y[0], y[1], y[2], y[3]};
-            t = t_new;
-            for (int i = 0; i < 4; ++i) { y[i] = y_new[i]; f[i] = f_new[i]; }
-            h_abs = ha;
-            if (t - tb >= 0) status = TCR_STATUS_FINISHED;
-            // dense output Q = K^T P (rk.py:179-181)
-            double Q[4][4];
-            for (int i = 0; i < 4; ++i)
-                for (int k = 0; k < 4; ++k) {
-                    double acc = 0.0;
-                    for (int j = 0; j < 7; ++j) acc += K[j][i][lane] * RK_P[j][k];
-                    Q[i][k] = acc;
-                }
-            // terminal event at the step end (ivp.py:673-693); g >= 0 always, so a
-            // trigger is g_new == 0 (root = step end) or g0 == 0 on the first step (root = t0)
-            const double g_new = event_fn(P, y[0], y[1], y[2]);
-            double t_emit = t;
-            if (g == 0.0) { status = TCR_STATUS_EVENT; t_emit = t_old; }
-            else if (g_new == 0.0) status = TCR_STATUS_EVENT;
-            g = g_new;
-            // t_eval emission (ivp.py:706-723) fused with the env-wind recompute of
-            // util/compute.py:201-202 at the emitted sample
-            while (next_out < ns) {
-                const double te = ts_at(P, next_out);
-                if (te > t_emit) break;
-                const double x = (te - t_old) / h;
-                const double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
-                double ye[4];
-                for (int i = 0; i < 4; ++i) {
-                    double acc = 0.0;
-                    acc += Q[i][0] * p1; acc += Q[i][1] * p2; acc += Q[i][2] * p3; acc += Q[i][3] * p4;
-                    ye[i] = h * acc + y_old[i];
-                }
-                double w[4];
-                env_winds(P, D, S, fs, ye[0], ye[1], te, w);
-                double2 *o = reinterpret_cast<double2 *>(rec + (size_t)next_out * kRec);
-                o[0] = make_double2(ye[0], ye[1]);
-                o[1] = make_double2(ye[2], ye[3]);
-                o[2] = make_double2(w[0], w[1]);
-                o[3] = make_double2(w[2], w[3]);
-                ++next_out;
+        } else if (phase == PH_F0) {
+            // ventilation gate (coupled_fast.py:238-244): same lookups as fun(t0, y0)
+            if (r.vpot > 0 && r.shear * r.chi / r.vpot >= 1) {
+                status = TCR_STATUS_GATED;
+                finalize();
+            } else {
+                // RungeKutta.__init__: f0; select_initial_step part 1 (common.py:112-126)
+                nfev = 1;
+                double sc[4];
+                for (int i = 0; i < 4; ++i) { f[i] = r.d[i]; sc[i] = P.atol + fabs(y[i]) * P.rtol; }
+                const double d0 = rms4(y[0] / sc[0], y[1] / sc[1], y[2] / sc[2], y[3] / sc[3]);
+                const double d1 = rms4(f[0] / sc[0], f[1] / sc[1], f[2] / sc[2], f[3] / sc[3]);
+                double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+                h0 = h0 < tb ? h0 : tb;
+                for (int i = 0; i < 4; ++i) e[1 + i] = y[i] + h0 * 1.0 * f[i];
+                e[0] = t + h0 * 1.0;
+                h = h0;
+                phase = PH_F1;
             }
+        } else if (phase == PH_F1) {   // select_initial_step part 2 (common.py:127-134)
+            ++nfev;
+            const double h0 = h;
+            double sc[4];
+            for (int i = 0; i < 4; ++i) sc[i] = P.atol + fabs(y[i]) * P.rtol;
+            const double d1 = rms4(f[0] / sc[0], f[1] / sc[1], f[2] / sc[2], f[3] / sc[3]);
+            const double d2 = rms4((r.d[0] - f[0]) / sc[0], (r.d[1] - f[1]) / sc[1],
+                                   (r.d[2] - f[2]) / sc[2], (r.d[3] - f[3]) / sc[3]) / h0;
+            double h1;
+            if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
+            else h1 = pow(0.01 / fmax(d1, d2), 0.2);
+            h_abs = fmin(fmin(100 * h0, h1), fmin(tb, P.max_step));
+            g = event_fn(P, y[0], y[1], y[2]);
+            begin_step();
         }
     }
-    a.n_valid[sid] = next_out;
-    a.status[sid] = status;
-    a.nfev[sid] = (status == TCR_STATUS_GATED) ? 0 : nfev;
-    a.n_accept[sid] = nacc;
-    a.n_reject[sid] = nrej;
+#undef KS
 }
 
 // ---------------------------------------------------------------------------
-// Post-step: accept test 1 (compute.py:185-189), axi_to_max_wind (wind/tc_wind.py:6-21
-// with util/sphere.py:15-30,58-83), accept test 2 (compute.py:205), and the unpack of
-// the [storm][sample][8] records into the reference's per-variable planes with NaN
-// padding (compute.py:124-133).  One workgroup per storm, threads stride over samples.
-struct PArgs {
+// k_emit: everything of run_tracks that is independent per output sample, fused:
+//   * t_eval emission from the dense output of the step that contains the sample
+//     (ivp.py:706-723, rk.py:552-574),
+//   * the env-wind recompute at every emitted sample (util/compute.py:201-202),
+//   * axi_to_max_wind (wind/tc_wind.py:6-21 with util/sphere.py:15-30,58-83),
+//   * accept tests 1 and 2 (compute.py:185-189, 205),
+//   * the reference's per-variable [n_tracks][n_steps] planes with NaN padding
+//     (compute.py:124-133), written coalesced.
+// One workgroup per storm; a thread owns samples tid, tid+T, ...
+struct EArgs {
     tcr_params P;
+    DevFields D;
     int64_t n;
-    const double *rec;
-    const int32_t *n_valid, *status;
+    int max_rk_steps;
+    const double *srec;          // [n][max_rk_steps][kStepRec]
+    const double *fs;            // [n][n_steps][4]
+    const int32_t *slot;
+    const int32_t *n_valid, *status, *n_accept;
     double *lon, *lat, *v, *m, *vmax, *envw;
     int32_t *flags;
 };
@@ -283,60 +409,107 @@ __device__ __forceinline__ double haversine_km(const tcr_params &P, double lon1,
     return (P.earth_R / 1000.) * (2 * asin(sqrt(aa)));
 }
 
-constexpr int kPostThreads = 128;
+constexpr int kEmitThreads = 128;
+constexpr int kEmitMaxSamples = 1024;      // LDS staging of one storm's lon/lat/v (n_steps <= this)
 
-__global__ __launch_bounds__(kPostThreads) void k_post_unpack(PArgs a)
+__global__ __launch_bounds__(kEmitThreads) void k_emit(EArgs a)
 {
-    __shared__ double s_best[kPostThreads];
-    __shared__ int s_any[kPostThreads];
+    extern __shared__ double esh[];        // t_new[max_rk_steps], lon[ns], lat[ns]
+    __shared__ double s_best[kEmitThreads];
+    __shared__ int s_any[kEmitThreads];
+    __shared__ double s_v2d[2];
     const tcr_params &P = a.P;
     const int64_t sid = blockIdx.x;
     const int ns = P.n_steps;
     const int n = a.n_valid[sid];
     const int status = a.status[sid];
-    const double *rec = a.rec + sid * ns * kRec;
+    int nst = a.n_accept[sid];
+    nst = nst < a.max_rk_steps ? nst : a.max_rk_steps;
+    double *s_tnew = esh, *s_lon = esh + a.max_rk_steps, *s_lat = s_lon + ns;
+    const double *srec = a.srec + sid * (int64_t)a.max_rk_steps * kStepRec;
+    const double *fs = a.fs + sid * ns * 4;
+    const DevSlot S = a.D.slots[a.slot[sid]];
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
-    double best = -INFINITY;
+    for (int j = threadIdx.x; j < nst; j += kEmitThreads) s_tnew[j] = srec[(size_t)j * kStepRec + 2];
+    __syncthreads();
+
+    // ---- pass 1: dense output + env winds per sample
+    const double step_out = P.total_time / (double)(ns - 1);
+    const double t2d = 2 * 86400.0;
     int any15 = 0;
-    for (int i = threadIdx.x; i < ns; i += kPostThreads) {
-        double lon = nan, lat = nan, v = nan, m = nan, vm = nan, w0 = nan, w1 = nan, w2 = nan, w3 = nan;
+    for (int i = threadIdx.x; i < ns; i += kEmitThreads) {
+        double lon = nan, lat = nan, v = nan, m = nan, w[4] = {nan, nan, nan, nan};
         if (i < n) {
-            const double2 *q = reinterpret_cast<const double2 *>(rec + (size_t)i * kRec);
-            const double2 r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3];
-            lon = r0.x; lat = r0.y; v = r1.x; m = r1.y; w0 = r2.x; w1 = r2.y; w2 = r3.x; w3 = r3.y;
-            if (v >= P.v_thresh) any15 = 1;
-            if (n > 1) {
-                // linear extrapolation at both ends, centred differences (sphere.py:66-77)
-                double lom, lam, lop, lap;
-                if (i == 0) { lom = 2 * lon - rec[kRec]; lam = 2 * lat - rec[kRec + 1]; }
-                else { lom = rec[(size_t)(i - 1) * kRec]; lam = rec[(size_t)(i - 1) * kRec + 1]; }
-                if (i == n - 1) { lop = 2 * lon - rec[(size_t)(n - 2) * kRec]; lap = 2 * lat - rec[(size_t)(n - 2) * kRec + 1]; }
-                else { lop = rec[(size_t)(i + 1) * kRec]; lap = rec[(size_t)(i + 1) * kRec + 1]; }
-                const double dlon = 0.5 * (sign_of(lop - lom) * haversine_km(P, lop, lat, lom, lat));
-                const double dlat = 0.5 * (sign_of(lap - lam) * haversine_km(P, lon, lap, lon, lam));
-                const double ut = dlon * 1000. / P.dt_out, vt = dlat * 1000. / P.dt_out;
-                const double G = fmin(1., 0.8 + 0.35 * (1. + tanh((lat - 35.) / 10.)));
-                const double Ui = G * ut + 0.1 * (w0 - w2) * v / 15.;
-                const double Vi = G * vt + 0.1 * (w1 - w3) * v / 15.;
-                const double mag = sqrt(Ui * Ui + Vi * Vi);
-                const double fac = np_min((v * 0.50) / mag, 1.0);
-                const double th = atan2(-Ui, Vi);
-                const double ug = v * -sin(th) + Ui * fac;
-                const double vg = v * cos(th) + Vi * fac;
-                vm = sqrt(ug * ug + vg * vg);
-                if (vm > best) best = vm;
+            const double te = ts_at(P, i);
+            // the sample belongs to the first accepted step whose end is >= te
+            int lo = 0, hi = nst - 1;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_tnew[mid] >= te) hi = mid; else lo = mid + 1; }
+            const double2 *q = reinterpret_cast<const double2 *>(srec + (size_t)lo * kStepRec);
+            const double2 th = q[0];                 // t_old, h
+            const double x = (te - th.x) / th.y;
+            const double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
+            const double2 y01 = q[2], y23 = q[3];
+            const double yo[4] = {y01.x, y01.y, y23.x, y23.y};
+            double ye[4];
+            for (int c = 0; c < 4; ++c) {
+                const double2 qa = q[4 + 2 * c], qb = q[5 + 2 * c];
+                double acc = 0.0;
+                acc += qa.x * p1; acc += qa.y * p2; acc += qb.x * p3; acc += qb.y * p4;
+                ye[c] = th.y * acc + yo[c];
             }
+            lon = ye[0]; lat = ye[1]; v = ye[2]; m = ye[3];
+            env_winds(P, a.D, S, fs, lon, lat, te, w);
+            if (v >= P.v_thresh) any15 = 1;
         }
+        s_lon[i] = lon; s_lat[i] = lat;
         const size_t o = (size_t)sid * ns + i;
-        a.lon[o] = lon; a.lat[o] = lat; a.v[o] = v; a.m[o] = m; a.vmax[o] = vm;
-        double2 *e = reinterpret_cast<double2 *>(a.envw + o * 4);
-        e[0] = make_double2(w0, w1);
-        e[1] = make_double2(w2, w3);
+        a.lon[o] = lon; a.lat[o] = lat; a.v[o] = v; a.m[o] = m;
+        double2 *eo = reinterpret_cast<double2 *>(a.envw + o * 4);
+        eo[0] = make_double2(w[0], w[1]);
+        eo[1] = make_double2(w[2], w[3]);
+        // np.interp(2 d, res.t, v) needs v at the two samples bracketing 2 d (or the last one)
+        if (i < n) {
+            const int j2 = (int)floor(t2d / step_out);
+            if (t2d >= ts_at(P, n - 1)) { if (i == n - 1) s_v2d[0] = s_v2d[1] = v; }
+            else { if (i == j2) s_v2d[0] = v; if (i == j2 + 1) s_v2d[1] = v; }
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 2: translation speed by centred differences -> vmax (needs the neighbours)
+    double best = -INFINITY;
+    for (int i = threadIdx.x; i < ns; i += kEmitThreads) {
+        double vm = nan;
+        if (i < n && n > 1) {
+            const size_t o = (size_t)sid * ns + i;
+            const double lon = s_lon[i], lat = s_lat[i], v = a.v[o];
+            const double2 *eo = reinterpret_cast<const double2 *>(a.envw + o * 4);
+            const double2 w01 = eo[0], w23 = eo[1];
+            // linear extrapolation at both ends (sphere.py:66-69)
+            const double lom = (i == 0) ? 2 * lon - s_lon[1] : s_lon[i - 1];
+            const double lam = (i == 0) ? 2 * lat - s_lat[1] : s_lat[i - 1];
+            const double lop = (i == n - 1) ? 2 * lon - s_lon[n - 2] : s_lon[i + 1];
+            const double lap = (i == n - 1) ? 2 * lat - s_lat[n - 2] : s_lat[i + 1];
+            const double dlon = 0.5 * (sign_of(lop - lom) * haversine_km(P, lop, lat, lom, lat));
+            const double dlat = 0.5 * (sign_of(lap - lam) * haversine_km(P, lon, lap, lon, lam));
+            const double ut = dlon * 1000. / P.dt_out, vt = dlat * 1000. / P.dt_out;
+            const double G = fmin(1., 0.8 + 0.35 * (1. + tanh((lat - 35.) / 10.)));
+            const double Ui = G * ut + 0.1 * (w01.x - w23.x) * v / 15.;
+            const double Vi = G * vt + 0.1 * (w01.y - w23.y) * v / 15.;
+            const double mag = sqrt(Ui * Ui + Vi * Vi);
+            const double fac = np_min((v * 0.50) / mag, 1.0);
+            const double th = atan2(-Ui, Vi);
+            const double ug = v * -sin(th) + Ui * fac;
+            const double vg = v * cos(th) + Vi * fac;
+            vm = sqrt(ug * ug + vg * vg);
+            if (vm > best) best = vm;
+        }
+        a.vmax[(size_t)sid * ns + i] = vm;
     }
     s_best[threadIdx.x] = best;
     s_any[threadIdx.x] = any15;
     __syncthreads();
-    for (int s = kPostThreads / 2; s > 0; s >>= 1) {
+    for (int s = kEmitThreads / 2; s > 0; s >>= 1) {
         if (threadIdx.x < s) {
             s_best[threadIdx.x] = fmax(s_best[threadIdx.x], s_best[threadIdx.x + s]);
             s_any[threadIdx.x] |= s_any[threadIdx.x + s];
@@ -346,16 +519,11 @@ __global__ __launch_bounds__(kPostThreads) void k_post_unpack(PArgs a)
     if (threadIdx.x == 0) {
         int fl = 0;
         if (n > 0 && status != TCR_STATUS_GATED) {
-            // np.interp(2 d, res.t, v): clamps to the last sample of a short track
-            const double t2d = 2 * 86400.0;
             double v2d;
-            if (t2d >= ts_at(P, n - 1)) v2d = rec[(size_t)(n - 1) * kRec + 2];
+            if (t2d >= ts_at(P, n - 1)) v2d = s_v2d[0];
             else {
-                int j = (int)floor(t2d / (P.total_time / (double)(ns - 1)));
-                while (j > 0 && ts_at(P, j) > t2d) --j;
-                while (j < n - 2 && ts_at(P, j + 1) <= t2d) ++j;
-                const double va = rec[(size_t)j * kRec + 2], vb = rec[(size_t)(j + 1) * kRec + 2];
-                v2d = (vb - va) / (ts_at(P, j + 1) - ts_at(P, j)) * (t2d - ts_at(P, j)) + va;
+                const int j = (int)floor(t2d / step_out);
+                v2d = (s_v2d[1] - s_v2d[0]) / (ts_at(P, j + 1) - ts_at(P, j)) * (t2d - ts_at(P, j)) + s_v2d[0];
             }
             if (s_any[0] && v2d >= P.v_2d_thresh) {
                 fl |= TCR_FLAG_IS_TC;

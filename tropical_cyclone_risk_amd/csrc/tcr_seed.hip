@@ -86,16 +86,16 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a)
     uniform2(a, cand, 0u, 0u, u0, u1);
     double lon = P.box[0] + (P.box[2] - P.box[0]) * u0;
     double lat = asin(y_min + (y_max - y_min) * u1) * 180 / kPi;
-    Cell cx = locate(D.mg.lon, D.mg.rlon, D.mg.nlon, D.mg.lon_inv_step, lon);
-    Cell cy = locate(D.mg.lat, D.mg.rlat, D.mg.nlat, D.mg.lat_inv_step, lat);
+    Cell cx = locate(D.mg.ax, lon);
+    Cell cy = locate(D.mg.ay, lat);
     int redraw = 0;
     while (mask_at(D.mg, D.run_mask, cx, cy) < 1e-2 && redraw < kMaxRedraw) {
         ++redraw;                                           // compute.py:146-148: uniform in lat
         uniform2(a, cand, 0u, (uint32_t)redraw, u0, u1);
         lon = P.box[0] + (P.box[2] - P.box[0]) * u0;
         lat = P.box[1] + (P.box[3] - P.box[1]) * u1;
-        cx = locate(D.mg.lon, D.mg.rlon, D.mg.nlon, D.mg.lon_inv_step, lon);
-        cy = locate(D.mg.lat, D.mg.rlat, D.mg.nlat, D.mg.lat_inv_step, lat);
+        cx = locate(D.mg.ax, lon);
+        cy = locate(D.mg.ay, lat);
     }
     double um, ul;
     uniform2(a, cand, 1u, 0u, um, ul);
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a)
     }
     // PI at genesis from the month's field set (compute.py:162)
     const DevSlot S = D.slots[month - 1];
-    const Cell tx = locate(D.tg.lon, D.tg.rlon, D.tg.nlon, D.tg.lon_inv_step, lon);
-    const Cell ty = locate(D.tg.lat, D.tg.rlat, D.tg.nlat, D.tg.lat_inv_step, lat);
+    const Cell tx = locate(D.tg.ax, lon);
+    const Cell ty = locate(D.tg.ay, lat);
     double th[4];
     bilinear<4, kThermoStride>(S.thermo, D.tg.nlon, tx, ty, th);
     const double pi_gen = th[0];
