@@ -184,6 +184,8 @@ DevFields dev_fields(const tcr_ctx *ctx)
     D.wg = dev_grid(ctx->wg); D.tg = dev_grid(ctx->tg); D.hg = dev_grid(ctx->hg); D.mg = dev_grid(ctx->mg);
     D.slots = ctx->d_slots; D.stat = ctx->d_stat;
     D.run_mask = ctx->d_run_mask; D.basin_masks = ctx->d_basin_masks;
+    D.all_affine = (ctx->wg.affine_lon && ctx->wg.affine_lat && ctx->tg.affine_lon && ctx->tg.affine_lat &&
+                    ctx->hg.affine_lon && ctx->hg.affine_lat) ? 1 : 0;
     return D;
 }
 
@@ -501,7 +503,8 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
         a.n_accept = out->n_accept; a.n_reject = out->n_reject;
         a.queue = ctx->d_queue;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_integrate, dim3(integrate_waves(ctx, n)), dim3(kWave), 0, st, a);
+        if (a.D.all_affine) hipLaunchKernelGGL(k_integrate<true>, dim3(integrate_waves(ctx, n)), dim3(kWave), 0, st, a);
+        else hipLaunchKernelGGL(k_integrate<false>, dim3(integrate_waves(ctx, n)), dim3(kWave), 0, st, a);
     }
     if (ev) HIPCHK(ctx, hipEventRecord(ev[2], st));
     {
@@ -510,8 +513,9 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
         a.slot = in->slot; a.n_valid = out->n_valid; a.status = out->status; a.n_accept = out->n_accept;
         a.lon = out->lon; a.lat = out->lat; a.v = out->v; a.m = out->m; a.vmax = out->vmax;
         a.envw = out->envw; a.flags = out->flags;
-        const size_t lds = sizeof(double) * ((size_t)max_rk + 2 * ns);
-        hipLaunchKernelGGL(k_emit, dim3((unsigned)n), dim3(kEmitThreads), lds, st, a);
+        const size_t lds = sizeof(double) * ((size_t)max_rk * 17 + 2 * ns);
+        if (a.D.all_affine) hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)n), dim3(kEmitThreads), lds, st, a);
+        else hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)n), dim3(kEmitThreads), lds, st, a);
     }
     if (ev) HIPCHK(ctx, hipEventRecord(ev[3], st));
     HIPCHK(ctx, hipGetLastError());
@@ -597,8 +601,13 @@ int tcr_probe_rhs_host(tcr_ctx *ctx, int slot, double h_bl, const double *Fs, in
     double *d_dy = B.get<double>(n * 4), *d_w = B.get<double>(n * 4), *d_al = B.get<double>(n);
     if (!d_fs || !d_t || !d_lon || !d_lat || !d_v || !d_m || !d_dy || !d_w || !d_al)
         return fail(ctx, "tcr_probe_rhs_host: device allocation failed");
-    hipLaunchKernelGGL(k_probe_rhs, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, ctx->prm,
-                       dev_fields(ctx), slot, h_bl, d_fs, n, d_t, d_lon, d_lat, d_v, d_m, d_dy, d_w, d_al);
+    const DevFields DF = dev_fields(ctx);
+    if (DF.all_affine)
+        hipLaunchKernelGGL(k_probe_rhs<true>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, ctx->prm,
+                           DF, slot, h_bl, d_fs, n, d_t, d_lon, d_lat, d_v, d_m, d_dy, d_w, d_al);
+    else
+        hipLaunchKernelGGL(k_probe_rhs<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, ctx->prm,
+                           DF, slot, h_bl, d_fs, n, d_t, d_lon, d_lat, d_v, d_m, d_dy, d_w, d_al);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipMemcpy(dydt, d_dy, sizeof(double) * n * 4, hipMemcpyDeviceToHost));

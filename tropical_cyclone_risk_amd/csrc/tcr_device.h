@@ -7,6 +7,13 @@
 // RectBivariateSpline(kx=1,ky=1).ev executes at intensity/coupled_fast.py:37-57,126
 // and track/bam_track.py:100-103 — and the translation unit is compiled with
 // -ffp-contract=off so no FMA is fused into it.
+//
+// Performance shape of one evaluation of fun(t, y) (the unit everything is made of):
+// all six cell searches are pure ALU on affine grids, then the 44 16-byte gathers
+// (28 wind, 4 forcing table, 8 thermo, 4 land/bathymetry) are independent of each
+// other and are issued back to back — ONE memory round trip per evaluation — and
+// the rest is straight-line fp64 math with selects instead of branches, so the
+// lanes of a wave never diverge inside an evaluation.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,10 +26,10 @@ constexpr double kPi = 3.141592653589793;
 constexpr int kWindStride = 16;     // 14 fields + 2 pad  -> one 128-B line per grid point
 constexpr int kThermoStride = 4;    // vpot, chi, mld, strat -> 32 B per grid point
 constexpr int kStaticStride = 2;    // land, bathy -> 16 B per grid point
-constexpr int kStepRec = 24;         // accepted-step record: t_old, h, t_new, -, y_old[4], Q[4][4]
+constexpr int kStepRec = 36;        // accepted-step record: t_old, h, t_new, -, y_old[4], K[7][4]
 
-// Rectilinear grid: knots + per-cell reciprocal widths (host-computed 1.0/(x[i+1]-x[i]),
-// the same IEEE division fpbspl.f performs) + a uniform-grid guess for the cell index.
+// One axis of a rectilinear grid: knots + per-cell reciprocal widths (host-computed
+// 1.0/(x[i+1]-x[i]), the IEEE division fpbspl.f performs) + a uniform guess for the cell.
 struct DevAxis {
     int n;
     int affine;              // knots are bitwise x0 + i*dx and every 1/(x[i+1]-x[i]) == rdx (host-verified)
@@ -50,7 +57,36 @@ struct DevFields {
     const double *stat;      // [nlat_h][nlon_h][2]: land, bathy
     const uint8_t *run_mask; // [nlat_m][nlon_m]
     const uint8_t *basin_masks;   // [7][nlat_m][nlon_m]
+    int all_affine;          // wind, thermo and static axes are all affine
 };
+
+// Constants one evaluation reads.  Kernels copy them into LDS once per workgroup so
+// they neither occupy ~150 SGPRs for the whole kernel (spilling) nor get reloaded
+// from the kernarg segment in the hot loop.
+struct EvalK {
+    DevAxis wx, wy, tx, ty, hx, hy;
+    const double *stat;
+    double earth_R, Ck, epsilon, kappa, u_beta, v_beta;
+    double y_alpha[2], m_alpha[2], alpha_max[2], alpha_min[2], steering_coefs[2];
+    double total_time, tstep, inv_tstep;
+    int n_steps, coupled_track;
+};
+
+__device__ inline void make_eval_k(const tcr_params &P, const DevFields &D, EvalK &K)
+{
+    K.wx = D.wg.ax; K.wy = D.wg.ay; K.tx = D.tg.ax; K.ty = D.tg.ay; K.hx = D.hg.ax; K.hy = D.hg.ay;
+    K.stat = D.stat;
+    K.earth_R = P.earth_R; K.Ck = P.Ck; K.epsilon = P.epsilon; K.kappa = P.kappa;
+    K.u_beta = P.u_beta; K.v_beta = P.v_beta;
+    for (int i = 0; i < 2; ++i) {
+        K.y_alpha[i] = P.y_alpha[i]; K.m_alpha[i] = P.m_alpha[i]; K.alpha_max[i] = P.alpha_max[i];
+        K.alpha_min[i] = P.alpha_min[i]; K.steering_coefs[i] = P.steering_coefs[i];
+    }
+    K.total_time = P.total_time;
+    K.tstep = P.total_time / (double)(P.n_steps - 1);
+    K.inv_tstep = (double)(P.n_steps - 1) / P.total_time;
+    K.n_steps = P.n_steps; K.coupled_track = P.coupled_track;
+}
 
 struct Cell {
     int i;
@@ -61,21 +97,26 @@ struct Cell {
 // Affine axes (ERA5's 1 deg / 0.25 deg grids, CMIP regular grids) need no memory
 // traffic at all: the host has verified that x0 + i*dx reproduces every knot
 // bit for bit and that 1/(x[i+1]-x[i]) is the same double in every cell.
-__device__ __forceinline__ Cell locate(const DevAxis &A, double arg)
+template <bool AFFINE>
+__device__ __forceinline__ Cell locate_t(const DevAxis &A, double arg)
 {
-    if (arg < A.x0) arg = A.x0;
-    if (arg > A.xn) arg = A.xn;
+    arg = (arg < A.x0) ? A.x0 : arg;
+    arg = (arg > A.xn) ? A.xn : arg;
     const int n = A.n;
     int i = (int)((arg - A.x0) * A.inv_step);
     i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
     Cell c;
-    if (A.affine) {
-        double xl = A.x0 + (double)i * A.dx, xr = A.x0 + (double)(i + 1) * A.dx;
-        if (i < n - 2 && arg >= xr) { ++i; xl = xr; xr = A.x0 + (double)(i + 1) * A.dx; }
-        else if (i > 0 && arg < xl) { --i; xr = xl; xl = A.x0 + (double)i * A.dx; }
+    if (AFFINE) {
+        const double dx = A.dx, x0 = A.x0, rdx = A.rdx;
+        const double xl = x0 + (double)i * dx, xr = x0 + (double)(i + 1) * dx;
+        const bool up = (i < n - 2) && (arg >= xr);
+        const bool dn = !up && (i > 0) && (arg < xl);
+        i += up ? 1 : (dn ? -1 : 0);
+        const double xl2 = up ? xr : (dn ? x0 + (double)i * dx : xl);
+        const double xr2 = up ? x0 + (double)(i + 1) * dx : (dn ? xl : xr);
         c.i = i;
-        c.w0 = 0.0 + A.rdx * (xr - arg);
-        c.w1 = A.rdx * (arg - xl);
+        c.w0 = 0.0 + rdx * (xr2 - arg);
+        c.w1 = rdx * (arg - xl2);
     } else {
         const double *__restrict__ x = A.x;
         while (i < n - 2 && arg >= x[i + 1]) ++i;
@@ -88,11 +129,21 @@ __device__ __forceinline__ Cell locate(const DevAxis &A, double arg)
     return c;
 }
 
-// Bilinear sum of NF interleaved fields in fpbisp.f's order:
-// (x0,y0), (x0,y1), (x1,y0), (x1,y1), each term (c*hx)*hy.
+__device__ __forceinline__ Cell locate(const DevAxis &A, double arg)
+{
+    return A.affine ? locate_t<true>(A, arg) : locate_t<false>(A, arg);
+}
+
+// The four corners of NF interleaved fields as 16-byte gathers ...
+template <int NF>
+struct Corners {
+    static constexpr int NV = (NF + 1) / 2;
+    double2 c00[NV], c01[NV], c10[NV], c11[NV];
+};
+
 template <int NF, int STRIDE>
-__device__ __forceinline__ void bilinear(const double *__restrict__ base, int nlon, const Cell &cx,
-                                         const Cell &cy, double (&out)[NF])
+__device__ __forceinline__ void gather(const double *__restrict__ base, int nlon, const Cell &cx,
+                                       const Cell &cy, Corners<NF> &C)
 {
     const double *p00 = base + ((size_t)cy.i * nlon + cx.i) * STRIDE;
     const double *p01 = p00 + (size_t)nlon * STRIDE;
@@ -100,16 +151,21 @@ __device__ __forceinline__ void bilinear(const double *__restrict__ base, int nl
     const double2 *q01 = reinterpret_cast<const double2 *>(p01);
     const double2 *q10 = reinterpret_cast<const double2 *>(p00 + STRIDE);
     const double2 *q11 = reinterpret_cast<const double2 *>(p01 + STRIDE);
-    constexpr int NV = (NF + 1) / 2;
-    double2 c00[NV], c01[NV], c10[NV], c11[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) { c00[k] = q00[k]; c01[k] = q01[k]; c10[k] = q10[k]; c11[k] = q11[k]; }
+    for (int k = 0; k < Corners<NF>::NV; ++k) { C.c00[k] = q00[k]; C.c01[k] = q01[k]; C.c10[k] = q10[k]; C.c11[k] = q11[k]; }
+}
+
+// ... and their bilinear sums in fpbisp.f's order: (x0,y0), (x0,y1), (x1,y0), (x1,y1),
+// each term (c*hx)*hy.
+template <int NF>
+__device__ __forceinline__ void blend(const Corners<NF> &C, const Cell &cx, const Cell &cy, double (&out)[NF])
+{
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        const double a = (f & 1) ? c00[f >> 1].y : c00[f >> 1].x;
-        const double b = (f & 1) ? c01[f >> 1].y : c01[f >> 1].x;
-        const double c = (f & 1) ? c10[f >> 1].y : c10[f >> 1].x;
-        const double d = (f & 1) ? c11[f >> 1].y : c11[f >> 1].x;
+        const double a = (f & 1) ? C.c00[f >> 1].y : C.c00[f >> 1].x;
+        const double b = (f & 1) ? C.c01[f >> 1].y : C.c01[f >> 1].x;
+        const double c = (f & 1) ? C.c10[f >> 1].y : C.c10[f >> 1].x;
+        const double d = (f & 1) ? C.c11[f >> 1].y : C.c11[f >> 1].x;
         double sp = 0.0;
         sp = sp + a * cx.w0 * cy.w0;
         sp = sp + b * cx.w0 * cy.w1;
@@ -119,60 +175,87 @@ __device__ __forceinline__ void bilinear(const double *__restrict__ base, int nl
     }
 }
 
+template <int NF, int STRIDE>
+__device__ __forceinline__ void bilinear(const double *__restrict__ base, int nlon, const Cell &cx,
+                                         const Cell &cy, double (&out)[NF])
+{
+    Corners<NF> C;
+    gather<NF, STRIDE>(base, nlon, cx, cy, C);
+    blend<NF>(C, cx, cy, out);
+}
+
 __device__ __forceinline__ double ts_at(const tcr_params &P, int i)
 {
     // np.linspace(0, total_time, n_steps)[i]
     return (i == P.n_steps - 1) ? P.total_time : (double)i * (P.total_time / (double)(P.n_steps - 1));
 }
 
-// interp1d(t_s, Fs, axis=1)(t): scipy/interpolate/_interpolate.py:457-486.
-// fs is this storm's table laid out [n_steps][4].
-__device__ __forceinline__ void fs_at(const tcr_params &P, const double *__restrict__ fs, double t,
-                                      double (&F)[4])
+__device__ __forceinline__ double ts_k(const EvalK &K, int i)
 {
-    const int ns = P.n_steps;
-    const double step = P.total_time / (double)(ns - 1);
-    int idx = (int)ceil(t / step);
-    idx = idx < 0 ? 0 : (idx > ns - 1 ? ns - 1 : idx);
-    while (idx > 0 && ts_at(P, idx - 1) >= t) --idx;          // searchsorted(..., side='left')
-    while (idx < ns - 1 && ts_at(P, idx) < t) ++idx;
-    idx = idx < 1 ? 1 : idx;
-    const int lo = idx - 1;
-    const double x_lo = ts_at(P, lo), x_hi = ts_at(P, idx);
-    const double2 *q = reinterpret_cast<const double2 *>(fs + (size_t)lo * 4);
-    const double2 a0 = q[0], a1 = q[1], b0 = q[2], b1 = q[3];
-    const double dx = x_hi - x_lo, dt = t - x_lo;
-    F[0] = (b0.x - a0.x) / dx * dt + a0.x;
-    F[1] = (b0.y - a0.y) / dx * dt + a0.y;
-    F[2] = (b1.x - a1.x) / dx * dt + a1.x;
-    F[3] = (b1.y - a1.y) / dx * dt + a1.y;
+    return (i == K.n_steps - 1) ? K.total_time : (double)i * K.tstep;
 }
 
-// track/bam_track.py:116-128: mean + chol(cov) · F(t).  Cholesky as LAPACK dpotrf('L')
-// unblocked: ajj = a_jj - dot; fail if ajj <= 0; sub-column scaled by 1/ajj.
-__device__ __forceinline__ void env_winds(const tcr_params &P, const DevFields &D, const DevSlot &S,
-                                          const double *__restrict__ fs, double lon, double lat,
-                                          double t, double (&w)[4])
+// interp1d(t_s, Fs, axis=1)(t) (scipy/interpolate/_interpolate.py:457-486), split into the
+// bracket search (searchsorted side='left', clipped to [1, n-1]; branch-free: the guess from
+// t * (1/step) is at most one off) and the blend, so the 64-byte gather sits with the others.
+struct FsBracket {
+    int lo;
+    double x_lo, dx;
+};
+
+__device__ __forceinline__ FsBracket fs_bracket(const EvalK &K, double t)
 {
-    if (lon != lon || t != t) { w[0] = w[1] = w[2] = w[3] = 0.0; return; }
-    const Cell cx = locate(D.wg.ax, lon);
-    const Cell cy = locate(D.wg.ay, lat);
-    double q[14];
-    bilinear<14, kWindStride>(S.wind, D.wg.nlon, cx, cy, q);
-    double F[4];
-    fs_at(P, fs, t, F);
+    const int ns = K.n_steps;
+    int idx = (int)ceil(t * K.inv_tstep);
+    idx = idx < 0 ? 0 : (idx > ns - 1 ? ns - 1 : idx);
+    const bool dn = (idx > 0) && (ts_k(K, idx - 1) >= t);
+    const bool up = !dn && (idx < ns - 1) && (ts_k(K, idx) < t);
+    idx += up ? 1 : (dn ? -1 : 0);
+    idx = idx < 1 ? 1 : idx;
+    FsBracket b;
+    b.lo = idx - 1;
+    b.x_lo = ts_k(K, idx - 1);
+    b.dx = ts_k(K, idx) - b.x_lo;
+    return b;
+}
+
+struct FsPair {
+    double2 a0, a1, b0, b1;
+};
+
+__device__ __forceinline__ void fs_gather(const double *__restrict__ fs, const FsBracket &b, FsPair &p)
+{
+    const double2 *q = reinterpret_cast<const double2 *>(fs + (size_t)b.lo * 4);
+    p.a0 = q[0]; p.a1 = q[1]; p.b0 = q[2]; p.b1 = q[3];
+}
+
+__device__ __forceinline__ void fs_blend(const FsPair &p, const FsBracket &b, double t, double (&F)[4])
+{
+    const double dt = t - b.x_lo;
+    F[0] = (p.b0.x - p.a0.x) / b.dx * dt + p.a0.x;
+    F[1] = (p.b0.y - p.a0.y) / b.dx * dt + p.a0.y;
+    F[2] = (p.b1.x - p.a1.x) / b.dx * dt + p.a1.x;
+    F[3] = (p.b1.y - p.a1.y) / b.dx * dt + p.a1.y;
+}
+
+// track/bam_track.py:116-128 after the 14 lookups: mean + chol(cov) · F(t).  Cholesky as
+// LAPACK dpotrf('L') unblocked: ajj = a_jj - dot; fail if ajj <= 0 (-> zero winds, the
+// LinAlgError branch :124-126); sub-column scaled by 1/ajj.  NaN lon/t -> zeros (:117-118).
+__device__ __forceinline__ void winds_from_lookups(const double (&q)[14], const double (&F)[4], double lon,
+                                                   double t, double (&w)[4])
+{
     // packed lower triangle: q[4]=a00 q[5]=a10 q[6]=a11 q[7]=a20 q[8]=a21 q[9]=a22 q[10]=a30 q[11]=a31 q[12]=a32 q[13]=a33
-    bool ok = true;
+    bool ok = !(lon != lon) && !(t != t);
     double l00, l10, l20, l30, l11, l21, l31, l22, l32, l33;
     {
-        double ajj = q[4] - 0.0;
+        const double ajj = q[4] - 0.0;
         ok = ok && (ajj > 0.0);
         l00 = sqrt(ajj);
         const double r = 1.0 / l00;
         l10 = (q[5] - 0.0) * r; l20 = (q[7] - 0.0) * r; l30 = (q[10] - 0.0) * r;
     }
     {
-        double ajj = q[6] - (0.0 + l10 * l10);
+        const double ajj = q[6] - (0.0 + l10 * l10);
         ok = ok && (ajj > 0.0);
         l11 = sqrt(ajj);
         const double r = 1.0 / l11;
@@ -180,112 +263,129 @@ __device__ __forceinline__ void env_winds(const tcr_params &P, const DevFields &
         l31 = (q[11] - (0.0 + l30 * l10)) * r;
     }
     {
-        double ajj = q[9] - ((0.0 + l20 * l20) + l21 * l21);
+        const double ajj = q[9] - ((0.0 + l20 * l20) + l21 * l21);
         ok = ok && (ajj > 0.0);
         l22 = sqrt(ajj);
         const double r = 1.0 / l22;
         l32 = (q[12] - ((0.0 + l30 * l20) + l31 * l21)) * r;
     }
     {
-        double ajj = q[13] - (((0.0 + l30 * l30) + l31 * l31) + l32 * l32);
+        const double ajj = q[13] - (((0.0 + l30 * l30) + l31 * l31) + l32 * l32);
         ok = ok && (ajj > 0.0);
         l33 = sqrt(ajj);
     }
-    if (!ok) { w[0] = w[1] = w[2] = w[3] = 0.0; return; }     // LinAlgError branch (bam_track.py:124-126)
-    w[0] = q[0] + ((((0.0 + l00 * F[0]) + 0.0 * F[1]) + 0.0 * F[2]) + 0.0 * F[3]);
-    w[1] = q[1] + ((((0.0 + l10 * F[0]) + l11 * F[1]) + 0.0 * F[2]) + 0.0 * F[3]);
-    w[2] = q[2] + ((((0.0 + l20 * F[0]) + l21 * F[1]) + l22 * F[2]) + 0.0 * F[3]);
-    w[3] = q[3] + ((((0.0 + l30 * F[0]) + l31 * F[1]) + l32 * F[2]) + l33 * F[3]);
+    const double w0 = q[0] + ((((0.0 + l00 * F[0]) + 0.0 * F[1]) + 0.0 * F[2]) + 0.0 * F[3]);
+    const double w1 = q[1] + ((((0.0 + l10 * F[0]) + l11 * F[1]) + 0.0 * F[2]) + 0.0 * F[3]);
+    const double w2 = q[2] + ((((0.0 + l20 * F[0]) + l21 * F[1]) + l22 * F[2]) + 0.0 * F[3]);
+    const double w3 = q[3] + ((((0.0 + l30 * F[0]) + l31 * F[1]) + l32 * F[2]) + l33 * F[3]);
+    w[0] = ok ? w0 : 0.0; w[1] = ok ? w1 : 0.0; w[2] = ok ? w2 : 0.0; w[3] = ok ? w3 : 0.0;
+}
+
+// _env_winds(lon, lat, t) on its own (output samples, probes)
+template <bool AFFINE>
+__device__ __forceinline__ void env_winds(const EvalK &K, const DevSlot &S, const double *__restrict__ fs,
+                                          double lon, double lat, double t, double (&w)[4])
+{
+    const Cell cx = locate_t<AFFINE>(K.wx, lon);
+    const Cell cy = locate_t<AFFINE>(K.wy, lat);
+    const FsBracket fb = fs_bracket(K, t);
+    Corners<14> CW;
+    FsPair fp;
+    gather<14, kWindStride>(S.wind, K.wx.n, cx, cy, CW);
+    fs_gather(fs, fb, fp);
+    double q[14], F[4];
+    blend<14>(CW, cx, cy, q);
+    fs_blend(fp, fb, t, F);
+    winds_from_lookups(q, F, lon, t, w);
 }
 
 __device__ __forceinline__ double sign_of(double x) { return (double)((x > 0) - (x < 0)); }
 __device__ __forceinline__ double np_min(double a, double b) { return (a != a) ? a : (a < b ? a : b); }
 __device__ __forceinline__ double np_max(double a, double b) { return (a != a) ? a : (a > b ? a : b); }
 
-// coupled_fast.py:183-192
-__device__ __forceinline__ void steering(const tcr_params &P, double v, double (&c)[2])
-{
-    if (!P.coupled_track) { c[0] = P.steering_coefs[0]; c[1] = P.steering_coefs[1]; return; }
-    double a0 = (v * 1.94384) * P.m_alpha[0] + P.y_alpha[0];
-    double a1 = (v * 1.94384) * P.m_alpha[1] + P.y_alpha[1];
-    a0 = np_max(np_min(a0, P.alpha_max[0]), P.alpha_min[0]);
-    a1 = np_max(np_min(a1, P.alpha_max[1]), P.alpha_min[1]);
-    if (a0 != a0 || a1 != a1) { a0 = P.y_alpha[0]; a1 = P.y_alpha[1]; }
-    c[0] = a0; c[1] = a1;
-}
-
 struct Rhs {
     double d[4];     // d lon/dt, d lat/dt, dv/dt, dm/dt
+    double w[4];     // raw env winds at the point (what _env_winds returns)
     double alpha;    // ocean feedback (probe only)
     double shear, vpot, chi;   // what the ventilation gate needs (coupled_fast.py:238-244)
 };
 
-// coupled_fast.py:196-207 (dydt) given the raw env winds at (lon, lat, t):
-// _step_bam_track (bam_track.py:131-144), _dvdt (:141-150), _calc_alpha/_calc_z (:65-94),
-// _dmdt (:175-180).  `shear` is the gate's S of the *raw* winds (coupled_fast.py:238).
-__device__ __forceinline__ Rhs rhs_from_winds(const tcr_params &P, const DevFields &D, const DevSlot &S,
-                                              double h_bl, double lon, double lat, double v, double m,
-                                              const double (&w_raw)[4])
+// fun(t, y) = Coupled_FAST.dydt (coupled_fast.py:196-207): _calc_steering_coefs (:183-192),
+// _step_bam_track (bam_track.py:131-144) on _env_winds (:116-128), _dvdt (:141-150) with
+// _get_current_vpot (:54-58), _calc_alpha/_calc_z (:65-94), _dmdt (:175-180).
+template <bool AFFINE>
+__device__ __forceinline__ Rhs rhs_eval(const EvalK &K, const DevSlot &S, const double *__restrict__ fs,
+                                        double h_bl, double t, double lon, double lat, double v, double m)
 {
+    // ---- address generation: pure ALU on affine grids
+    const Cell wx = locate_t<AFFINE>(K.wx, lon), wy = locate_t<AFFINE>(K.wy, lat);
+    const Cell tx = locate_t<AFFINE>(K.tx, lon), ty = locate_t<AFFINE>(K.ty, lat);
+    const Cell hx = locate_t<AFFINE>(K.hx, lon), hy = locate_t<AFFINE>(K.hy, lat);
+    const FsBracket fb = fs_bracket(K, t);
+    // ---- one round of independent 16-byte gathers
+    Corners<14> CW;
+    Corners<4> CT;
+    Corners<2> CH;
+    FsPair fp;
+    gather<14, kWindStride>(S.wind, K.wx.n, wx, wy, CW);
+    fs_gather(fs, fb, fp);
+    gather<4, kThermoStride>(S.thermo, K.tx.n, tx, ty, CT);
+    gather<2, kStaticStride>(K.stat, K.hx.n, hx, hy, CH);
+    // ---- straight-line math
     Rhs r;
-    double c[2], w[4], vb0, vb1;
-    steering(P, v, c);
+    double q[14], F[4], th[4], lb[2];
+    blend<14>(CW, wx, wy, q);
+    fs_blend(fp, fb, t, F);
+    winds_from_lookups(q, F, lon, t, r.w);
+    blend<4>(CT, tx, ty, th);
+    blend<2>(CH, hx, hy, lb);
     {
-        const double du = w_raw[0] - w_raw[2], dw = w_raw[1] - w_raw[3];
+        const double du = r.w[0] - r.w[2], dw = r.w[1] - r.w[3];
         r.shear = sqrt(du * du + dw * dw);
     }
-    if (fabs(lat) >= 80) {
-        vb0 = vb1 = 0.0; w[0] = w[1] = w[2] = w[3] = 0.0;
-    } else {
-        w[0] = w_raw[0]; w[1] = w_raw[1]; w[2] = w_raw[2]; w[3] = w_raw[3];
-        const double cl = cos(lat * (kPi / 180.0));                        // np.deg2rad
-        vb0 = (w[0] * c[0] + w[2] * c[1]) + P.u_beta * cl;
-        vb1 = (w[1] * c[0] + w[3] * c[1]) + (sign_of(lat) * P.v_beta) * cl;
+    // steering coefficients
+    double c0, c1;
+    {
+        double a0 = (v * 1.94384) * K.m_alpha[0] + K.y_alpha[0];
+        double a1 = (v * 1.94384) * K.m_alpha[1] + K.y_alpha[1];
+        a0 = np_max(np_min(a0, K.alpha_max[0]), K.alpha_min[0]);
+        a1 = np_max(np_min(a1, K.alpha_max[1]), K.alpha_min[1]);
+        const bool bad = (a0 != a0) || (a1 != a1);
+        a0 = bad ? K.y_alpha[0] : a0;
+        a1 = bad ? K.y_alpha[1] : a1;
+        c0 = K.coupled_track ? a0 : K.steering_coefs[0];
+        c1 = K.coupled_track ? a1 : K.steering_coefs[1];
     }
-    r.d[0] = vb0 / P.earth_R * 180. / kPi / cos(lat * kPi / 180.);
-    r.d[1] = vb1 / P.earth_R * 180. / kPi;
-
-    // thermo grid: vpot, chi, mld, strat; hi-res grid: land, bathy
-    const Cell tx = locate(D.tg.ax, lon);
-    const Cell ty = locate(D.tg.ay, lat);
-    double th[4];
-    bilinear<4, kThermoStride>(S.thermo, D.tg.nlon, tx, ty, th);
-    const Cell hx = locate(D.hg.ax, lon);
-    const Cell hy = locate(D.hg.ay, lat);
-    double lb[2];
-    bilinear<2, kStaticStride>(D.stat, D.hg.nlon, hx, hy, lb);
+    // beta-advection; |lat| >= 80 -> zero motion and zero winds (bam_track.py:134-135)
+    const bool polar = fabs(lat) >= 80;
+    const double w0 = polar ? 0.0 : r.w[0], w1 = polar ? 0.0 : r.w[1];
+    const double w2 = polar ? 0.0 : r.w[2], w3 = polar ? 0.0 : r.w[3];
+    const double cl = cos(lat * (kPi / 180.0));                            // np.deg2rad
+    double vb0 = (w0 * c0 + w2 * c1) + K.u_beta * cl;
+    double vb1 = (w1 * c0 + w3 * c1) + (sign_of(lat) * K.v_beta) * cl;
+    vb0 = polar ? 0.0 : vb0;
+    vb1 = polar ? 0.0 : vb1;
+    r.d[0] = vb0 / K.earth_R * 180. / kPi / cos(lat * kPi / 180.);
+    r.d[1] = vb1 / K.earth_R * 180. / kPi;
+    // intensity
     const double vp = (lb[0] == 1.0) ? 0.0 : th[0];                        // coupled_fast.py:35-58
     const double h_m = th[2], gam = th[3], bathy = lb[1];
-    double al;
-    if (bathy >= 0 || -h_m <= bathy || gam == 0) {
-        al = 1.0;
-    } else {
-        const double uT = sqrt(vb0 * vb0 + vb1 * vb1);
-        const double z = 0.01 * pow(gam, -0.4) * h_m * uT * vp / v;
-        const double zc = np_min(np_max(z, 0.0), 100.0);
-        al = 1 - 0.87 * exp(-zc);
-    }
+    const bool no_mix = (bathy >= 0) || (-h_m <= bathy) || (gam == 0);
+    const double uT = sqrt(vb0 * vb0 + vb1 * vb1);
+    const double z = 0.01 * pow(gam, -0.4) * h_m * uT * vp / v;
+    const double zc = np_min(np_max(z, 0.0), 100.0);
+    const double al = no_mix ? 1.0 : 1 - 0.87 * exp(-zc);
     r.alpha = al;
-    const double beta = 1 - P.epsilon - P.kappa;
-    const double gamma = P.epsilon + al * P.kappa;
+    const double beta = 1 - K.epsilon - K.kappa;
+    const double gamma = K.epsilon + al * K.kappa;
     const double m3 = m * m * m;
-    double dv = 0.5 * P.Ck / h_bl * (al * beta * (vp * vp) * m3 - (1 - gamma * m3) * (v * v));
-    if (dv != dv) dv = 0.0;
-    const double du = w[0] - w[2], dw = w[1] - w[3];
+    const double dv = 0.5 * K.Ck / h_bl * (al * beta * (vp * vp) * m3 - (1 - gamma * m3) * (v * v));
+    const double du = w0 - w2, dw = w1 - w3;
     const double venti = sqrt(du * du + dw * dw) * th[1];
     r.vpot = vp; r.chi = th[1];
-    r.d[2] = dv;
-    r.d[3] = 0.5 * P.Ck / h_bl * ((1 - m) * v - venti * m);
+    r.d[2] = (dv != dv) ? 0.0 : dv;
+    r.d[3] = 0.5 * K.Ck / h_bl * ((1 - m) * v - venti * m);
     return r;
-}
-
-__device__ __forceinline__ Rhs rhs_eval(const tcr_params &P, const DevFields &D, const DevSlot &S,
-                                        const double *__restrict__ fs, double h_bl, double t,
-                                        double lon, double lat, double v, double m)
-{
-    double w[4];
-    env_winds(P, D, S, fs, lon, lat, t, w);
-    return rhs_from_winds(P, D, S, h_bl, lon, lat, v, m, w);
 }
 
 // coupled_fast.py:246-256 with util/basins.py:32-37 (dx = 1); always >= 0

@@ -164,27 +164,40 @@ __device__ __forceinline__ int samples_upto(const tcr_params &P, double t_emit)
 }
 
 constexpr int kWave = 64;
-enum : int { PH_IDLE = 0, PH_F0, PH_F1, PH_STAGE };
+#ifndef TCR_INT_WPS
+#define TCR_INT_WPS 1      // waves per SIMD the integrator is register-budgeted for
+#endif
 constexpr int kRunning = 99;
 
 // k_integrate: the sequential part of a storm — RK45 steps until the terminal event.
-// Every accepted step leaves one kStepRec-double record (t_old, h, t_new, y_old, Q) from
-// which k_emit later evaluates the hourly samples in parallel.
-__global__ __launch_bounds__(kWave) void k_integrate(KArgs a)
+//
+// Wave-synchronous cycles: one cycle = one attempt of _step_impl for every lane = six
+// evaluations of fun (stages 2..6 and f_new; stage 1 is FSAL).  All lanes evaluate the
+// same stage in the same slot, so the per-stage bookkeeping is wave-uniform code instead
+// of a divergent state machine.  A lane whose storm ends pulls the next one from the
+// queue at the cycle boundary; a fresh storm spends slots 0 and 1 of its first cycle on
+// the two evaluations of RungeKutta.__init__ (f0 and select_initial_step's f1) and idles
+// for the other four.  Every accepted step leaves one kStepRec-double record
+// (t_old, h, t_new, y_old, K[7][4]) from which k_emit evaluates the hourly samples.
+template <bool AFFINE>
+__global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
 {
     // Kl[(stage*4 + component)*64 + lane]
     __shared__ double Kl[7 * 4 * kWave];
+    __shared__ EvalK K;
     const tcr_params &P = a.P;
     const DevFields &D = a.D;
     const int lane = threadIdx.x;
+    if (lane == 0) make_eval_k(P, D, K);
+    __syncthreads();
     const int ns = P.n_steps;
     const double tb = P.total_time;
 #define KS(j, i) Kl[((j) * 4 + (i)) * kWave + lane]
 
     // ---- per-lane storm state
     long long sid = -1;
-    int phase = PH_IDLE, st = 0, status = kRunning, nfev = 0, nacc = 0, nrej = 0, next_out = 0;
-    bool exhausted = false, rejected = false;
+    int status = kRunning, nfev = 0, nacc = 0, nrej = 0, next_out = 0;
+    bool active = false, fresh = false, exhausted = false, rejected = false;
     DevSlot S{};
     const double *fs = nullptr;
     double *srec = nullptr;
@@ -199,9 +212,9 @@ __global__ __launch_bounds__(kWave) void k_integrate(KArgs a)
         a.nfev[sid] = (status == TCR_STATUS_GATED) ? 0 : nfev;
         a.n_accept[sid] = nacc;
         a.n_reject[sid] = nrej;
-        phase = PH_IDLE;
+        active = false;
     };
-    // one attempt of _step_impl's while-loop: clip to t_bound, stage 1 input (rk.py:137-146)
+    // one attempt of _step_impl's while-loop: clip to t_bound, stage-2 input (rk.py:137-146, 62-66)
     auto attempt_setup = [&]() {
         const double min_step = 10 * fabs(nextafter(t, INFINITY) - t);
         if (ha < min_step) { status = TCR_STATUS_STEP_FAIL; finalize(); return; }
@@ -216,8 +229,6 @@ __global__ __launch_bounds__(kWave) void k_integrate(KArgs a)
             e[1 + i] = y[i] + dy * h;
         }
         e[0] = t + RK_C[1] * h;
-        st = 1;
-        phase = PH_STAGE;
     };
     auto begin_step = [&]() {
         const double min_step = 10 * fabs(nextafter(t, INFINITY) - t);
@@ -229,14 +240,14 @@ __global__ __launch_bounds__(kWave) void k_integrate(KArgs a)
     };
 
     for (;;) {
-        // ---- refill idle lanes from the storm queue (wave-aggregated atomic)
-        const unsigned long long want = __ballot(phase == PH_IDLE && !exhausted);
+        // ---- cycle boundary: refill idle lanes from the storm queue (wave-aggregated atomic)
+        const unsigned long long want = __ballot(!active && !exhausted);
         if (want) {
             const int leader = __ffsll((long long)want) - 1;
             unsigned long long base = 0;
             if (lane == leader) base = atomicAdd(a.queue, (unsigned long long)__popcll(want));
             base = __shfl(base, leader);
-            if (phase == PH_IDLE && !exhausted) {
+            if (!active && !exhausted) {
                 sid = (long long)(base + (unsigned long long)__popcll(want & ((1ull << lane) - 1ull)));
                 if (sid >= a.n) {
                     exhausted = true;
@@ -249,129 +260,128 @@ __global__ __launch_bounds__(kWave) void k_integrate(KArgs a)
                     status = kRunning; nfev = 0; nacc = 0; nrej = 0; next_out = 0;
                     t = 0.0;
                     e[0] = 0.0; e[1] = y[0]; e[2] = y[1]; e[3] = y[2]; e[4] = y[3];
-                    phase = PH_F0;
+                    active = true; fresh = true;
                 }
             }
         }
-        if (!__ballot(phase != PH_IDLE)) break;
+        if (!__ballot(active)) break;
 
-        // ---- the one expensive state: fun(t, y) at the evaluation point
-        Rhs r{};
-        if (phase != PH_IDLE) r = rhs_eval(P, D, S, fs, h_bl, e[0], e[1], e[2], e[3], e[4]);
-
-        // ---- bookkeeping of whatever this lane was waiting for
-        if (phase == PH_STAGE) {
-            ++nfev;
-            for (int i = 0; i < 4; ++i) KS(st, i) = r.d[i];
-            if (st < 6) {
-                ++st;
-                // rk_step: dy = dot(K[:s].T, a[:s]) * h (rk.py:64-66); y_new = y + h * dot(K[:-1].T, B) (:68)
-                for (int i = 0; i < 4; ++i) {
-                    double dy = 0.0;
-                    switch (st) {
-                    case 2: dy += KS(0, i) * A20; dy += KS(1, i) * A21; break;
-                    case 3: dy += KS(0, i) * A30; dy += KS(1, i) * A31; dy += KS(2, i) * A32; break;
-                    case 4: dy += KS(0, i) * A40; dy += KS(1, i) * A41; dy += KS(2, i) * A42; dy += KS(3, i) * A43; break;
-                    case 5: dy += KS(0, i) * A50; dy += KS(1, i) * A51; dy += KS(2, i) * A52; dy += KS(3, i) * A53;
-                            dy += KS(4, i) * A54; break;
-                    default:
-                        for (int j = 0; j < 6; ++j) dy += KS(j, i) * RK_B[j];
-                        break;
-                    }
-                    if (st < 6) e[1 + i] = y[i] + dy * h;
-                    else { e[1 + i] = y[i] + h * dy; yn[i] = e[1 + i]; }
-                }
-                e[0] = (st < 6) ? t + RK_C[st] * h : t + h;
-            } else {
-                // error estimate and step-size control (rk.py:147-165)
-                double er[4];
-                for (int i = 0; i < 4; ++i) {
-                    const double sc = P.atol + fmax(fabs(y[i]), fabs(yn[i])) * P.rtol;
-                    double acc = 0.0;
-                    for (int j = 0; j < 7; ++j) acc += KS(j, i) * RK_E[j];
-                    er[i] = (acc * h) / sc;
-                }
-                const double err = rms4(er[0], er[1], er[2], er[3]);
-                if (err < 1) {
-                    double fac = (err == 0) ? 10.0 : fmin(10.0, 0.9 * pow(err, -0.2));
-                    if (rejected && fac > 1) fac = 1;
-                    ha *= fac;
-                    // step record for k_emit: t_old, h, t_new, -, y_old[4], Q = K^T P (rk.py:179-181)
-                    if (nacc < a.max_rk_steps) {
-                        double2 *o = reinterpret_cast<double2 *>(srec + (size_t)nacc * kStepRec);
-                        o[0] = make_double2(t, h);
-                        o[1] = make_double2(t_new, 0.0);
-                        o[2] = make_double2(y[0], y[1]);
-                        o[3] = make_double2(y[2], y[3]);
-                        for (int i = 0; i < 4; ++i) {
-                            double q[4];
-                            for (int k = 0; k < 4; ++k) {
-                                double acc = 0.0;
-                                for (int j = 0; j < 7; ++j) acc += KS(j, i) * RK_P[j][k];
-                                q[k] = acc;
-                            }
-                            o[4 + 2 * i] = make_double2(q[0], q[1]);
-                            o[5 + 2 * i] = make_double2(q[2], q[3]);
+        // ---- six evaluation slots
+#pragma unroll 1
+        for (int slot = 0; slot < 6; ++slot) {
+            const bool live = active && !(fresh && slot >= 2);
+            Rhs r{};
+            if (live) r = rhs_eval<AFFINE>(K, S, fs, h_bl, e[0], e[1], e[2], e[3], e[4]);
+            if (live && !fresh) {
+                // rk_step (rk.py:62-70): K[s] = fun(...); next stage input dy = dot(K[:s].T, a[:s]) * h
+                ++nfev;
+                const int st = slot + 1;
+                for (int i = 0; i < 4; ++i) KS(st, i) = r.d[i];
+                if (slot < 5) {
+                    for (int i = 0; i < 4; ++i) {
+                        double dy = 0.0;
+                        switch (slot) {
+                        case 0: dy += KS(0, i) * A20; dy += KS(1, i) * A21; break;
+                        case 1: dy += KS(0, i) * A30; dy += KS(1, i) * A31; dy += KS(2, i) * A32; break;
+                        case 2: dy += KS(0, i) * A40; dy += KS(1, i) * A41; dy += KS(2, i) * A42; dy += KS(3, i) * A43; break;
+                        case 3: dy += KS(0, i) * A50; dy += KS(1, i) * A51; dy += KS(2, i) * A52; dy += KS(3, i) * A53;
+                                dy += KS(4, i) * A54; break;
+                        default:
+                            for (int j = 0; j < 6; ++j) dy += KS(j, i) * RK_B[j];
+                            break;
                         }
+                        if (slot < 4) e[1 + i] = y[i] + dy * h;
+                        else { e[1 + i] = y[i] + h * dy; yn[i] = e[1 + i]; }     // y_new (rk.py:68)
                     }
-                    ++nacc;
-                    const double t_old = t;
-                    t = t_new;
-                    for (int i = 0; i < 4; ++i) { y[i] = yn[i]; f[i] = r.d[i]; }
-                    h_abs = ha;
-                    if (t - tb >= 0) status = TCR_STATUS_FINISHED;
-                    // terminal event at the step end (ivp.py:673-693); g >= 0 always, so a trigger
-                    // is g_new == 0 (root = step end) or g0 == 0 on the first step (root = t0)
-                    const double g_new = event_fn(P, y[0], y[1], y[2]);
-                    double t_emit = t;
-                    if (g == 0.0) { status = TCR_STATUS_EVENT; t_emit = t_old; }
-                    else if (g_new == 0.0) status = TCR_STATUS_EVENT;
-                    g = g_new;
-                    next_out = samples_upto(P, t_emit);         // t_eval emission count (ivp.py:706-723)
-                    if (status == kRunning && nacc >= a.max_rk_steps) status = TCR_STATUS_STEP_OVERFLOW;
-                    if (status != kRunning) finalize();
-                    else begin_step();
+                    e[0] = (slot < 4) ? t + RK_C[slot + 2] * h : t + h;
                 } else {
-                    ha *= fmax(0.2, 0.9 * pow(err, -0.2));
-                    rejected = true;
-                    ++nrej;
-                    attempt_setup();
+                    // f_new is in K[6]: error estimate and step-size control (rk.py:147-165)
+                    double er[4];
+                    for (int i = 0; i < 4; ++i) {
+                        const double sc = P.atol + fmax(fabs(y[i]), fabs(yn[i])) * P.rtol;
+                        double acc = 0.0;
+                        for (int j = 0; j < 7; ++j) acc += KS(j, i) * RK_E[j];
+                        er[i] = (acc * h) / sc;
+                    }
+                    const double err = rms4(er[0], er[1], er[2], er[3]);
+                    const double pw = 0.9 * pow(err, -0.2);
+                    if (err < 1) {
+                        double fac = (err == 0) ? 10.0 : fmin(10.0, pw);
+                        if (rejected && fac > 1) fac = 1;
+                        ha *= fac;
+                        // step record for k_emit: t_old, h, t_new, -, y_old[4], K[7][4]
+                        if (nacc < a.max_rk_steps) {
+                            double2 *o = reinterpret_cast<double2 *>(srec + (size_t)nacc * kStepRec);
+                            o[0] = make_double2(t, h);
+                            o[1] = make_double2(t_new, 0.0);
+                            o[2] = make_double2(y[0], y[1]);
+                            o[3] = make_double2(y[2], y[3]);
+                            for (int j = 0; j < 7; ++j) {
+                                o[4 + 2 * j] = make_double2(KS(j, 0), KS(j, 1));
+                                o[5 + 2 * j] = make_double2(KS(j, 2), KS(j, 3));
+                            }
+                        }
+                        ++nacc;
+                        const double t_old = t;
+                        t = t_new;
+                        for (int i = 0; i < 4; ++i) { y[i] = yn[i]; f[i] = r.d[i]; }
+                        h_abs = ha;
+                        if (t - tb >= 0) status = TCR_STATUS_FINISHED;
+                        // terminal event at the step end (ivp.py:673-693); g >= 0 always, so a trigger
+                        // is g_new == 0 (root = step end) or g0 == 0 on the first step (root = t0)
+                        const double g_new = event_fn(P, y[0], y[1], y[2]);
+                        double t_emit = t;
+                        if (g == 0.0) { status = TCR_STATUS_EVENT; t_emit = t_old; }
+                        else if (g_new == 0.0) status = TCR_STATUS_EVENT;
+                        g = g_new;
+                        next_out = samples_upto(P, t_emit);         // t_eval emission count (ivp.py:706-723)
+                        if (status == kRunning && nacc >= a.max_rk_steps) status = TCR_STATUS_STEP_OVERFLOW;
+                        if (status != kRunning) finalize();
+                        else begin_step();
+                    } else {
+                        ha *= fmax(0.2, pw);
+                        rejected = true;
+                        ++nrej;
+                        attempt_setup();
+                    }
                 }
-            }
-        } else if (phase == PH_F0) {
-            // ventilation gate (coupled_fast.py:238-244): same lookups as fun(t0, y0)
-            if (r.vpot > 0 && r.shear * r.chi / r.vpot >= 1) {
-                status = TCR_STATUS_GATED;
-                finalize();
-            } else {
-                // RungeKutta.__init__: f0; select_initial_step part 1 (common.py:112-126)
-                nfev = 1;
+            } else if (live && slot == 0) {
+                // fresh storm, fun(t0, y0): ventilation gate (coupled_fast.py:238-244) on the same
+                // lookups, then RungeKutta.__init__'s f0 and select_initial_step part 1 (common.py:112-126)
+                if (r.vpot > 0 && r.shear * r.chi / r.vpot >= 1) {
+                    status = TCR_STATUS_GATED;
+                    finalize();
+                    fresh = false;
+                } else {
+                    nfev = 1;
+                    double sc[4];
+                    for (int i = 0; i < 4; ++i) { f[i] = r.d[i]; sc[i] = P.atol + fabs(y[i]) * P.rtol; }
+                    const double d0 = rms4(y[0] / sc[0], y[1] / sc[1], y[2] / sc[2], y[3] / sc[3]);
+                    const double d1 = rms4(f[0] / sc[0], f[1] / sc[1], f[2] / sc[2], f[3] / sc[3]);
+                    double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+                    h0 = h0 < tb ? h0 : tb;
+                    for (int i = 0; i < 4; ++i) e[1 + i] = y[i] + h0 * 1.0 * f[i];
+                    e[0] = t + h0 * 1.0;
+                    h = h0;
+                }
+            } else if (live && slot == 1) {
+                // fresh storm, f1: select_initial_step part 2 (common.py:127-134); first attempt set up
+                ++nfev;
+                const double h0 = h;
                 double sc[4];
-                for (int i = 0; i < 4; ++i) { f[i] = r.d[i]; sc[i] = P.atol + fabs(y[i]) * P.rtol; }
-                const double d0 = rms4(y[0] / sc[0], y[1] / sc[1], y[2] / sc[2], y[3] / sc[3]);
+                for (int i = 0; i < 4; ++i) sc[i] = P.atol + fabs(y[i]) * P.rtol;
                 const double d1 = rms4(f[0] / sc[0], f[1] / sc[1], f[2] / sc[2], f[3] / sc[3]);
-                double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-                h0 = h0 < tb ? h0 : tb;
-                for (int i = 0; i < 4; ++i) e[1 + i] = y[i] + h0 * 1.0 * f[i];
-                e[0] = t + h0 * 1.0;
-                h = h0;
-                phase = PH_F1;
+                const double d2 = rms4((r.d[0] - f[0]) / sc[0], (r.d[1] - f[1]) / sc[1],
+                                       (r.d[2] - f[2]) / sc[2], (r.d[3] - f[3]) / sc[3]) / h0;
+                double h1;
+                if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
+                else h1 = pow(0.01 / fmax(d1, d2), 0.2);
+                h_abs = fmin(fmin(100 * h0, h1), fmin(tb, P.max_step));
+                g = event_fn(P, y[0], y[1], y[2]);
+                begin_step();
             }
-        } else if (phase == PH_F1) {   // select_initial_step part 2 (common.py:127-134)
-            ++nfev;
-            const double h0 = h;
-            double sc[4];
-            for (int i = 0; i < 4; ++i) sc[i] = P.atol + fabs(y[i]) * P.rtol;
-            const double d1 = rms4(f[0] / sc[0], f[1] / sc[1], f[2] / sc[2], f[3] / sc[3]);
-            const double d2 = rms4((r.d[0] - f[0]) / sc[0], (r.d[1] - f[1]) / sc[1],
-                                   (r.d[2] - f[2]) / sc[2], (r.d[3] - f[3]) / sc[3]) / h0;
-            double h1;
-            if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
-            else h1 = pow(0.01 / fmax(d1, d2), 0.2);
-            h_abs = fmin(fmin(100 * h0, h1), fmin(tb, P.max_step));
-            g = event_fn(P, y[0], y[1], y[2]);
-            begin_step();
         }
+        fresh = false;
     }
 #undef KS
 }
@@ -412,9 +422,11 @@ __device__ __forceinline__ double haversine_km(const tcr_params &P, double lon1,
 constexpr int kEmitThreads = 128;
 constexpr int kEmitMaxSamples = 1024;      // LDS staging of one storm's lon/lat/v (n_steps <= this)
 
+template <bool AFFINE>
 __global__ __launch_bounds__(kEmitThreads) void k_emit(EArgs a)
 {
-    extern __shared__ double esh[];        // t_new[max_rk_steps], lon[ns], lat[ns]
+    extern __shared__ double esh[];        // t_new[max_rk_steps], lon[ns], lat[ns], Q[max_rk_steps][16]
+    __shared__ EvalK K;
     __shared__ double s_best[kEmitThreads];
     __shared__ int s_any[kEmitThreads];
     __shared__ double s_v2d[2];
@@ -425,12 +437,21 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(EArgs a)
     const int status = a.status[sid];
     int nst = a.n_accept[sid];
     nst = nst < a.max_rk_steps ? nst : a.max_rk_steps;
-    double *s_tnew = esh, *s_lon = esh + a.max_rk_steps, *s_lat = s_lon + ns;
+    double *s_tnew = esh, *s_lon = esh + a.max_rk_steps, *s_lat = s_lon + ns, *s_Q = s_lat + ns;
     const double *srec = a.srec + sid * (int64_t)a.max_rk_steps * kStepRec;
     const double *fs = a.fs + sid * ns * 4;
     const DevSlot S = a.D.slots[a.slot[sid]];
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     for (int j = threadIdx.x; j < nst; j += kEmitThreads) s_tnew[j] = srec[(size_t)j * kStepRec + 2];
+    // dense output Q = K^T P per accepted step (rk.py:179-181): one (step, component, power) per thread
+    for (int p = threadIdx.x; p < nst * 16; p += kEmitThreads) {
+        const int j = p >> 4, i = (p >> 2) & 3, k = p & 3;
+        const double *kr = srec + (size_t)j * kStepRec + 8;
+        double acc = 0.0;
+        for (int q = 0; q < 7; ++q) acc += kr[q * 4 + i] * RK_P[q][k];
+        s_Q[p] = acc;
+    }
+    if (threadIdx.x == 0) make_eval_k(P, a.D, K);
     __syncthreads();
 
     // ---- pass 1: dense output + env winds per sample
@@ -452,13 +473,13 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(EArgs a)
             const double yo[4] = {y01.x, y01.y, y23.x, y23.y};
             double ye[4];
             for (int c = 0; c < 4; ++c) {
-                const double2 qa = q[4 + 2 * c], qb = q[5 + 2 * c];
+                const double *Q = s_Q + lo * 16 + c * 4;
                 double acc = 0.0;
-                acc += qa.x * p1; acc += qa.y * p2; acc += qb.x * p3; acc += qb.y * p4;
+                acc += Q[0] * p1; acc += Q[1] * p2; acc += Q[2] * p3; acc += Q[3] * p4;
                 ye[c] = th.y * acc + yo[c];
             }
             lon = ye[0]; lat = ye[1]; v = ye[2]; m = ye[3];
-            env_winds(P, a.D, S, fs, lon, lat, te, w);
+            env_winds<AFFINE>(K, S, fs, lon, lat, te, w);
             if (v >= P.v_thresh) any15 = 1;
         }
         s_lon[i] = lon; s_lat[i] = lat;
@@ -537,18 +558,22 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(EArgs a)
 // ---------------------------------------------------------------------------
 // Probe: dydt / _env_winds / _calc_alpha at arbitrary points of one slot with one
 // forcing table (parity tests of the seam's leaf methods).
+template <bool AFFINE>
 __global__ __launch_bounds__(64) void k_probe_rhs(tcr_params P, DevFields D, int slot, double h_bl, const double *fs,
                             int64_t n, const double *t, const double *lon, const double *lat,
                             const double *v, const double *m, double *dydt, double *envw, double *alpha)
 {
+    __shared__ EvalK K;
+    if (threadIdx.x == 0) make_eval_k(P, D, K);
+    __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const DevSlot S = D.slots[slot];
-    const Rhs r = rhs_eval(P, D, S, fs, h_bl, t[i], lon[i], lat[i], v[i], m[i]);
+    const Rhs r = rhs_eval<AFFINE>(K, S, fs, h_bl, t[i], lon[i], lat[i], v[i], m[i]);
     for (int k = 0; k < 4; ++k) dydt[i * 4 + k] = r.d[k];
     alpha[i] = r.alpha;
     double w[4];
-    env_winds(P, D, S, fs, lon[i], lat[i], t[i], w);
+    env_winds<AFFINE>(K, S, fs, lon[i], lat[i], t[i], w);
     for (int k = 0; k < 4; ++k) envw[i * 4 + k] = w[k];
 }
 
