@@ -124,11 +124,15 @@ int tcr_params_set(tcr_ctx *ctx, const tcr_params *p);
 int tcr_static_upload(tcr_ctx *ctx, const tcr_grid *hg, const double *land, const double *bathy);
 /* replaces: BetaAdvectionTrack._load_wnd_stat (bam_track.py:76-91) +
  *           Coupled_FAST.init_fields (coupled_fast.py:217-225) for one month slot.
- * rh_mid feeds the initial m (compute.py:111,173); may be NULL if seeding is host-side. */
+ */
 int tcr_fields_upload(tcr_ctx *ctx, int slot,
                       const tcr_grid *wg, const double *const mean[TCR_NW], const double *const cov[TCR_NCOV],
                       const tcr_grid *tg, const double *vpot, const double *chi,
-                      const double *mld, const double *strat, const double *rh_mid);
+                      const double *mld, const double *strat);
+/* replaces: m_init_fx[month] = mat.interp2_fx(lon, lat, rh_mid_month) (compute.py:111): mid-level
+ * RH of one month slot on the *uncropped* thermo grid, as the reference builds it; only the
+ * device-side seeding reads it (initial m, compute.py:173-174). */
+int tcr_rh_upload(tcr_ctx *ctx, int slot, const tcr_grid *rg, const double *rh_mid);
 /* replaces: the land/<B>.nc interpolators f_b and f_basins (compute.py:87-97).
  * masks are uint8 0/1 planes on one global grid; run_mask is the run basin's. */
 int tcr_masks_upload(tcr_ctx *ctx, const tcr_grid *mg, const uint8_t *run_mask,

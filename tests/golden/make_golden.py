@@ -183,6 +183,66 @@ def unit_level(ref):
     return out
 
 
+def seeding_level(ref, env, basin, seed, year, cand0, n):
+    """Transcription of the seed loop of util/compute.py:134-175 over the reference's own
+    interpolators (mat.interp2_fx on the basin masks and rh_mid, Coupled_FAST.f_vpot), with
+    np.random replaced by the per-candidate Philox stream of oracle/seeding.py:
+        np.random.uniform(a, b, 1)[0] -> a + (b - a) * u      (NumPy's own formula)
+        np.random.randint(1, 13)      -> int(u * 12) + 1
+        np.random.randn(1)[0]         -> Box-Muller of two uniforms
+    One candidate = one pass of the `while not seed_passed` body."""
+    from oracle import seeding as OS
+    nl = ref.namelist
+    b = ref.basins.TC_Basin(basin)
+    basin_ids = np.array(sorted([k for k in nl.basin_bounds if k != 'GL']))
+    f_basins = {bid: ref.mat.interp2_fx(env.hlon, env.hlat, env.basin_masks[bid]) for bid in basin_ids}
+    f_b = ref.mat.interp2_fx(env.hlon, env.hlat, env.basin_masks[basin])
+    b_bounds = b.get_bounds()
+    cpl_fast = [H.build_coupled_fast(ref, env, basin, mo) for mo in range(12)]
+    m_init_fx = [ref.mat.interp2_fx(env.lon, env.lat, env.rh_mid[mo]) for mo in range(12)]
+    out = {k: [] for k in ('lon', 'lat', 'month', 'basin_idx', 'flags', 'v0', 'm0', 'h_bl', 'redraw')}
+    for cand in range(cand0, cand0 + n):
+        lat_min = 3 if np.sign(b_bounds[1]) >= 0 else -45
+        lat_max = 45 if np.sign(b_bounds[3]) >= 0 else -3
+        y_min = np.sin(np.pi / 180 * lat_min)
+        y_max = np.sin(np.pi / 180 * lat_max)
+        u0, u1 = OS.uniform2(seed, year, cand, 0, 0)
+        gen_lon = b_bounds[0] + (b_bounds[2] - b_bounds[0]) * float(u0)
+        gen_lat = np.arcsin(y_min + (y_max - y_min) * float(u1)) * 180 / np.pi
+        redraw = 0
+        while f_b.ev(gen_lon, gen_lat) < 1e-2:
+            redraw += 1
+            u0, u1 = OS.uniform2(seed, year, cand, 0, redraw)
+            gen_lon = b_bounds[0] + (b_bounds[2] - b_bounds[0]) * float(u0)
+            gen_lat = b_bounds[1] + (b_bounds[3] - b_bounds[1]) * float(u1)
+        um, ul = OS.uniform2(seed, year, cand, 1, 0)
+        month_seed = min(int(float(um) * 12.0) + 1, 12)
+        fast = cpl_fast[month_seed - 1]
+        basin_val = np.zeros(len(basin_ids))
+        for (b_idx, basin_id) in enumerate(basin_ids):
+            basin_val[b_idx] = f_basins[basin_id].ev(gen_lon, gen_lat).item()
+        basin_idx = np.argmax(basin_val)
+        pi_gen = float(fast.f_vpot.ev(gen_lon, gen_lat).item())
+        lat_vort_power = nl.lat_vort_power[basin_ids[basin_idx]]
+        prob_lowlat = np.power(np.minimum(np.maximum((np.abs(gen_lat) - nl.lat_vort_fac) / 12.0, 0), 1), lat_vort_power)
+        rand_lowlat = float(ul)
+        flags = 0
+        if (np.nanmax(basin_val) > 1e-3) and (rand_lowlat < prob_lowlat):
+            flags |= 1                         # n_seeds[basin_idx, month_seed-1] += 1
+            if (pi_gen > 35):
+                flags |= 2                     # seed_passed = True
+        n0, n1 = OS.uniform2(seed, year, cand, 1, 1)
+        v_init = nl.seed_v_init_ms + np.sqrt(-2.0 * np.log(1.0 - float(n0))) * np.cos(2. * np.pi * float(n1))
+        rh_init = float(m_init_fx[month_seed - 1].ev(gen_lon, gen_lat).item())
+        m_init = np.maximum(0, nl.f_mInit(rh_init))
+        for k, v in zip(out, (gen_lon, gen_lat, month_seed, basin_idx, flags, v_init, m_init,
+                              nl.atm_bl_depth[basin_ids[basin_idx]], redraw)):
+            out[k].append(v)
+    res = {k: np.array(v) for k, v in out.items()}
+    res.update(seed=np.uint64(seed), year=np.int32(year), cand0=np.int64(cand0), basin=np.array(basin))
+    return res
+
+
 def main():
     ref = H.import_reference()
     env = synthetic.make_env(**ENV_KW)
@@ -208,6 +268,11 @@ def main():
     d = rhs_level(ref, env, 'SI', 2, 600, 12)
     np.savez_compressed(os.path.join(HERE, 'rhs_SI.npz'), **d, **{'meta_' + k: v for k, v in META.items()})
     np.savez_compressed(os.path.join(HERE, 'units.npz'), **unit_level(ref))
+    for bsn, c0 in (('NA', 0), ('GL', 1 << 33), ('SI', 12345)):
+        d = seeding_level(ref, env, bsn, 20250614, 2001, c0, 1500)
+        print('seeds %s: counted %.3f passed %.3f mean redraws %.2f' % (bsn, (d['flags'] & 1).mean() if False else np.mean((d['flags'] & 1) != 0),
+                                                                     np.mean((d['flags'] & 2) != 0), d['redraw'].mean()))
+        np.savez_compressed(os.path.join(HERE, 'seeds_%s.npz' % bsn), **d, **{'meta_' + k: v for k, v in META.items()})
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith('.npz'):
             print('%-20s %8d bytes' % (fn, os.path.getsize(os.path.join(HERE, fn))))

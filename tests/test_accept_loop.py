@@ -1,0 +1,134 @@
+"""The batched accept loop and its all-gather (compute.accept_loop, distributed.py) on CPU:
+single process vs 2 gloo ranks vs a literal sequential loop over candidates."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NS = 9
+
+
+def fake_candidate(c):
+    """Deterministic pseudo-candidate: (counted, passed, accepted, basin, month, row)."""
+    rng = np.random.default_rng(1000003 * 7 + int(c))
+    counted = rng.random() < 0.7
+    passed = counted and rng.random() < 0.4
+    accepted = passed and rng.random() < 0.3
+    return counted, passed, accepted, int(rng.integers(0, 7)), int(rng.integers(1, 13)), rng.random(9 * NS)
+
+
+def fake_round(cand0, count):
+    rows = [fake_candidate(cand0 + i) for i in range(count)]
+    acc = [i for i, r in enumerate(rows) if r[2]]
+    return dict(counted=np.array([r[0] for r in rows]), basin_idx=np.array([r[3] for r in rows]),
+                month=np.array([r[4] for r in rows]), acc_cand=np.array([cand0 + i for i in acc], dtype=np.int64),
+                acc_rows=np.array([rows[i][5] for i in acc]).reshape(len(acc), 9 * NS),
+                acc_month=np.array([rows[i][4] for i in acc]), acc_basin=np.array([rows[i][3] for i in acc]))
+
+
+def sequential(n_tracks):
+    """The reference's loop shape: walk candidates in order until n_tracks are accepted."""
+    n_seeds = np.zeros((7, 12)); rows = []; cands = []
+    c = 0
+    while len(rows) < n_tracks:
+        counted, passed, accepted, b, m, row = fake_candidate(c)
+        if counted:
+            n_seeds[b, m - 1] += 1
+        if accepted:
+            rows.append(row); cands.append(c)
+        c += 1
+    return np.array(rows), np.array(cands), n_seeds
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, per_rank, n_tracks, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from tropical_cyclone_risk_amd import compute, distributed as D
+    D.init_from_env(backend='gloo')
+    res = compute.accept_loop(fake_round, n_tracks, per_rank, NS)
+    q.put((rank, res['rows'], res['cand'], res['n_seeds'], res['rounds']))
+    D.barrier()
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('per_rank', [64, 257])
+def test_single_process_matches_sequential(per_rank):
+    sys.path.insert(0, ROOT)
+    from tropical_cyclone_risk_amd import compute
+    res = compute.accept_loop(fake_round, 25, per_rank, NS)
+    rows, cands, n_seeds = sequential(25)
+    assert np.array_equal(res['cand'], cands)
+    assert np.array_equal(res['rows'], rows)
+    assert np.array_equal(res['n_seeds'], n_seeds)
+
+
+@pytest.mark.parametrize('world,per_rank', [(2, 64), (2, 150)])
+def test_gloo_ranks_match_sequential(world, per_rank):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, per_rank, 25, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rows, cands, n_seeds = sequential(25)
+    for rank, r_rows, r_cand, r_seeds, rounds in got:
+        assert np.array_equal(r_cand, cands), rank
+        assert np.array_equal(r_rows, rows), rank
+        assert np.array_equal(r_seeds, n_seeds), rank
+
+
+def test_allgather_rows_ragged_gloo():
+    """Ragged all-gather incl. an empty contribution and the rank-order guarantee."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, shapes, ok in got:
+        assert ok, (rank, shapes)
+
+
+def _ragged_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch
+    from tropical_cyclone_risk_amd import distributed as D
+    D.init_from_env(backend='gloo')
+    ok, shapes = True, []
+    for counts in ([3, 5], [0, 4], [2, 0], [0, 0]):
+        n = counts[rank]
+        rows = torch.full((max(n, 1), 6), float(rank)) + torch.arange(max(n, 1)).reshape(-1, 1) * 0.01
+        out, cs = D.allgather_rows(rows[:n] if n else rows[:0], torch.tensor([n]))
+        shapes.append(tuple(out.shape))
+        ok &= cs == counts and out.shape[0] == sum(counts)
+        if sum(counts):
+            exp = torch.cat([torch.full((counts[r], 6), float(r)) + torch.arange(counts[r]).reshape(-1, 1) * 0.01
+                             for r in range(world)])
+            ok &= bool(torch.equal(out, exp))
+        work, fin = D.allgather_rows(rows[:n] if n else rows[:0], None, counts=counts, async_op=True)
+        out2, _ = fin()
+        ok &= bool(torch.equal(out2, out))
+    q.put((rank, shapes, bool(ok)))
+    D.barrier()
+    import torch.distributed as dist
+    dist.destroy_process_group()

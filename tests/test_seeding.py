@@ -1,0 +1,83 @@
+"""Genesis seeding (util/compute.py:134-175): oracle vs the golden decisions produced by a
+transcription of the reference loop over the reference's own interpolators (CPU), and the
+device kernel vs the oracle (GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10."""
+    from oracle import seeding as S
+    z = np.zeros(1, dtype=np.uint64)
+    o = S.philox4x32_10(z, z, z, z, 0, 0)
+    assert [int(x[0]) for x in o] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    f = np.full(1, 0xffffffff, dtype=np.uint64)
+    o = S.philox4x32_10(f, f, f, f, 0xffffffff, 0xffffffff)
+    assert [int(x[0]) for x in o] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    o = S.philox4x32_10(*[np.array([v], dtype=np.uint64) for v in (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344)],
+                        0xa4093822, 0x299f31d0)
+    assert [int(x[0]) for x in o] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+@pytest.mark.parametrize('basin', ['NA', 'GL', 'SI'])
+def test_oracle_seeding_matches_reference_transcription(golden_env, basin):
+    from oracle import seeding as S
+    g = np.load(os.path.join(GOLDEN, 'seeds_%s.npz' % basin))
+    se = S.SeedEnv(golden_env, basin)
+    n = 400
+    o = S.seed_candidates(se, int(g['seed']), int(g['year']), int(g['cand0']), n)
+    for k in ('lon', 'lat', 'v0', 'm0', 'h_bl'):
+        assert np.array_equal(o[k], g[k][:n]), k
+    for k in ('month', 'basin_idx', 'flags', 'redraw'):
+        assert np.array_equal(o[k], g[k][:n]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('basin', ['NA', 'GL', 'SI'])
+def test_device_seeding_vs_golden(golden_env, built_lib, basin):
+    """tcr_seed_host vs the golden decisions: integers identical, positions to 1e-12
+    (device asin/sin/log/cos differ from libm by an ulp), phases bit-exact."""
+    from oracle import seeding as S
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    g = np.load(os.path.join(GOLDEN, 'seeds_%s.npz' % basin))
+    eng = TCEngine(basin, device=0).stage_env(golden_env)
+    n = len(g['lon'])
+    out = eng.seed(int(g['year']), int(g['cand0']), n, experiment_seed=int(g['seed']))
+    eng.close()
+    assert np.abs(out['lon'] - g['lon']).max() < 1e-12
+    assert np.abs(out['lat'] - g['lat']).max() < 1e-12
+    for k, gk in (('month', 'month'), ('basin_idx', 'basin_idx'), ('seed_flags', 'flags')):
+        assert np.array_equal(out[k], g[gk]), k
+    assert np.abs(out['v0'] - g['v0']).max() < 1e-12
+    assert np.abs(out['m0'] - g['m0']).max() < 1e-13
+    assert np.array_equal(out['h_bl'], g['h_bl'])
+    pairs = np.arange(30, dtype=np.uint64)
+    for i in (0, 7, n - 1):
+        a, b = S.uniform2(int(g['seed']), int(g['year']), int(g['cand0']) + i, 2, pairs)
+        assert np.array_equal(out['phases'][i].reshape(-1), np.stack([a, b], 1).reshape(-1))
+
+
+@pytest.mark.gpu
+def test_run_tracks_end_to_end(golden_env, built_lib):
+    """run_tracks through the device pipeline: quota, ordering, n_seeds bookkeeping, and
+    invariance to the round size (the batched loop must not depend on how it is batched)."""
+    from tropical_cyclone_risk_amd import compute
+    from tropical_cyclone_risk_amd.basins import TC_Basin
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    eng = TCEngine('NA', device=0).stage_env(golden_env)
+    a = compute.run_tracks(2003, 40, TC_Basin('NA'), engine=eng, per_rank=4096)
+    b = compute.run_tracks(2003, 40, TC_Basin('NA'), engine=eng, per_rank=1500)
+    eng.close()
+    lon, lat, v, m, vmax, envw, month, basin, n_seeds = a
+    assert lon.shape == (40, 361) and envw.shape == (40, 361, 4) and n_seeds.shape == (7, 12)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True) if x.dtype.kind == 'f' else np.array_equal(x, y)
+    assert (np.nanmax(vmax, axis=1) >= 18).all() and (np.nanmax(v, axis=1) >= 15).all()
+    assert set(basin) <= {'NA', 'EP'} and n_seeds.sum() > 40
+    n_valid = (~np.isnan(lon)).sum(axis=1)
+    for i in range(40):
+        assert np.isnan(lon[i, n_valid[i]:]).all() and np.isnan(vmax[i, n_valid[i]:]).all()

@@ -21,7 +21,7 @@ U8P = C.POINTER(C.c_uint8)
 
 # every symbol include/tcrisk_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = ('tcr_abi_version', 'tcr_ctx_create', 'tcr_ctx_destroy', 'tcr_last_error',
-           'tcr_params_set', 'tcr_static_upload', 'tcr_fields_upload', 'tcr_masks_upload',
+           'tcr_params_set', 'tcr_static_upload', 'tcr_fields_upload', 'tcr_rh_upload', 'tcr_masks_upload',
            'tcr_integrate_host', 'tcr_integrate_dev', 'tcr_seed_dev', 'tcr_seed_host',
            'tcr_probe_rhs_host', 'tcr_fourier_table_host', 'tcr_timing_enable',
            'tcr_timing_last', 'tcr_timing_sum', 'tcr_sync', 'tcr_compact_dev',
@@ -96,7 +96,8 @@ def lib():
     L.tcr_params_set.argtypes = [C.c_void_p, C.POINTER(Params)]
     L.tcr_static_upload.argtypes = [C.c_void_p, C.POINTER(Grid), DP, DP]
     L.tcr_fields_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Grid), C.POINTER(DP), C.POINTER(DP),
-                                    C.POINTER(Grid), DP, DP, DP, DP, DP]
+                                    C.POINTER(Grid), DP, DP, DP, DP]
+    L.tcr_rh_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Grid), DP]
     L.tcr_masks_upload.argtypes = [C.c_void_p, C.POINTER(Grid), U8P, C.POINTER(U8P)]
     L.tcr_integrate_host.argtypes = [C.c_void_p, C.POINTER(Storms), C.POINTER(Tracks)]
     L.tcr_integrate_dev.argtypes = [C.c_void_p, C.POINTER(Storms), C.POINTER(Tracks), C.c_void_p]

@@ -57,7 +57,7 @@ struct tcr_ctx {
     std::string err;
     tcr_params prm;
     bool have_prm = false;
-    GridStore wg, tg, hg, mg;
+    GridStore wg, tg, hg, mg, rg;
     std::vector<SlotStore> slots;
     DevSlot *d_slots = nullptr;
     size_t d_slots_cap = 0;
@@ -182,6 +182,7 @@ DevFields dev_fields(const tcr_ctx *ctx)
 {
     DevFields D{};
     D.wg = dev_grid(ctx->wg); D.tg = dev_grid(ctx->tg); D.hg = dev_grid(ctx->hg); D.mg = dev_grid(ctx->mg);
+    D.rg = dev_grid(ctx->rg);
     D.slots = ctx->d_slots; D.stat = ctx->d_stat;
     D.run_mask = ctx->d_run_mask; D.basin_masks = ctx->d_basin_masks;
     D.all_affine = (ctx->wg.affine_lon && ctx->wg.affine_lat && ctx->tg.affine_lon && ctx->tg.affine_lat &&
@@ -303,7 +304,7 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (GridStore *g : {&ctx->wg, &ctx->tg, &ctx->hg, &ctx->mg}) {
+    for (GridStore *g : {&ctx->wg, &ctx->tg, &ctx->hg, &ctx->mg, &ctx->rg}) {
         (void)hipFree(g->d_lon); (void)hipFree(g->d_lat); (void)hipFree(g->d_rlon); (void)hipFree(g->d_rlat);
     }
     for (auto &s : ctx->slots) { (void)hipFree(s.wind); (void)hipFree(s.thermo); (void)hipFree(s.rh); }
@@ -364,7 +365,7 @@ int tcr_static_upload(tcr_ctx *ctx, const tcr_grid *hg, const double *land, cons
 
 int tcr_fields_upload(tcr_ctx *ctx, int slot, const tcr_grid *wg, const double *const mean[TCR_NW],
                       const double *const cov[TCR_NCOV], const tcr_grid *tg, const double *vpot,
-                      const double *chi, const double *mld, const double *strat, const double *rh_mid)
+                      const double *chi, const double *mld, const double *strat)
 {
     if (!ctx) return -1;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -390,10 +391,22 @@ int tcr_fields_upload(tcr_ctx *ctx, int slot, const tcr_grid *wg, const double *
         if (!s.thermo && dev_alloc(ctx, &s.thermo, h.size())) return -1;
         HIPCHK(ctx, hipMemcpy(s.thermo, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
     }
-    if (rh_mid) {
-        if (!s.rh && dev_alloc(ctx, &s.rh, nt)) return -1;
-        HIPCHK(ctx, hipMemcpy(s.rh, rh_mid, sizeof(double) * nt, hipMemcpyHostToDevice));
-    }
+    ctx->slots_dirty = true;
+    return 0;
+}
+
+int tcr_rh_upload(tcr_ctx *ctx, int slot, const tcr_grid *rg, const double *rh_mid)
+{
+    if (!ctx) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (slot < 0 || slot >= 4096) return fail(ctx, "tcr_rh_upload: slot out of range");
+    if (!rh_mid) return fail(ctx, "tcr_rh_upload: NULL plane");
+    if (stage_grid(ctx, ctx->rg, rg, "rh")) return -1;
+    if ((size_t)slot >= ctx->slots.size()) ctx->slots.resize(slot + 1);
+    SlotStore &s = ctx->slots[slot];
+    const size_t nr = (size_t)rg->nlon * rg->nlat;
+    if (!s.rh && dev_alloc(ctx, &s.rh, nr)) return -1;
+    HIPCHK(ctx, hipMemcpy(s.rh, rh_mid, sizeof(double) * nr, hipMemcpyHostToDevice));
     ctx->slots_dirty = true;
     return 0;
 }
@@ -623,7 +636,8 @@ int tcr_seed_dev(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t c
     if (!out) return fail(ctx, "tcr_seed_dev: NULL argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (out->n <= 0) return 0;
-    for (auto &s : ctx->slots) if (!s.rh) return fail(ctx, "tcr_seed_dev: a slot was staged without rh_mid");
+    for (auto &s : ctx->slots) if (!s.rh) return fail(ctx, "tcr_seed_dev: a slot has no rh_mid (tcr_rh_upload)");
+    if (!ctx->rg.set) return fail(ctx, "tcr_seed_dev: rh_mid not staged (tcr_rh_upload)");
     if (ctx->slots.size() < 12) return fail(ctx, "tcr_seed_dev: needs the 12 month slots staged");
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
     SeedArgs a{};

@@ -48,11 +48,11 @@ struct DevGrid {
 struct DevSlot {
     const double *wind;      // [nlat_w][nlon_w][16]: mean0..3, cov(0,0),(1,0),(1,1),(2,0)...(3,3), pad, pad
     const double *thermo;    // [nlat_t][nlon_t][4] : vpot, chi, mld, strat
-    const double *rh;        // [nlat_t][nlon_t]
+    const double *rh;        // [nlat_r][nlon_r] on the uncropped thermo grid (seeding only)
 };
 
 struct DevFields {
-    DevGrid wg, tg, hg, mg;
+    DevGrid wg, tg, hg, mg, rg;   // wind, thermo, static hi-res, basin masks, (uncropped) rh grid
     const DevSlot *slots;    // device array
     const double *stat;      // [nlat_h][nlon_h][2]: land, bathy
     const uint8_t *run_mask; // [nlat_m][nlon_m]

@@ -128,12 +128,15 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a)
     double n0, n1;
     uniform2(a, cand, 1u, 1u, n0, n1);
     const double z = sqrt(-2.0 * log(1.0 - n0)) * cos(2. * kPi * n1);   // Box–Muller N(0,1)
-    const double *r0 = S.rh + (size_t)ty.i * D.tg.nlon + tx.i, *r1 = r0 + D.tg.nlon;
+    // m_init_fx[month].ev(lon, lat) on the uncropped thermo grid (compute.py:111,173)
+    const Cell rx = locate(D.rg.ax, lon);
+    const Cell ry = locate(D.rg.ay, lat);
+    const double *r0 = S.rh + (size_t)ry.i * D.rg.nlon + rx.i, *r1 = r0 + D.rg.nlon;
     double rh = 0.0;
-    rh = rh + r0[0] * tx.w0 * ty.w0;
-    rh = rh + r1[0] * tx.w0 * ty.w1;
-    rh = rh + r0[1] * tx.w1 * ty.w0;
-    rh = rh + r1[1] * tx.w1 * ty.w1;
+    rh = rh + r0[0] * rx.w0 * ry.w0;
+    rh = rh + r1[0] * rx.w0 * ry.w1;
+    rh = rh + r0[1] * rx.w1 * ry.w0;
+    rh = rh + r1[1] * rx.w1 * ry.w1;
     const double m_init = P.minit_a / (1 + exp(-(rh - P.minit_b) * P.minit_c)) + P.minit_d;
 
     a.out.lon0[i] = lon;

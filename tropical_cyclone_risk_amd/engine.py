@@ -134,11 +134,13 @@ class TCEngine:
         cov_p = (_lib.DP * 10)(*[_dp(x) for x in planes[4:]])
         tlo, tla, vp = tf(lon, lat, vpot)
         th = [_f64(vp)] + [_f64(tf(lon, lat, x)[2]) for x in (chi, mld, strat)]
-        rh = _f64(tf(lon, lat, rh_mid)[2]) if rh_mid is not None else None
         wg, tg = self._grid(wlo, wla), self._grid(tlo, tla)
         self._ck(self.L.tcr_fields_upload(self.h, int(slot), C.byref(wg), mean_p, cov_p, C.byref(tg),
-                                          _dp(th[0]), _dp(th[1]), _dp(th[2]), _dp(th[3]),
-                                          _dp(rh) if rh is not None else None))
+                                          _dp(th[0]), _dp(th[1]), _dp(th[2]), _dp(th[3])))
+        if rh_mid is not None:
+            # m_init_fx is built on the uncropped grid in the reference (compute.py:111)
+            rh, rg = _f64(rh_mid), self._grid(lon, lat)
+            self._ck(self.L.tcr_rh_upload(self.h, int(slot), C.byref(rg), _dp(rh)))
 
     def stage_masks(self, mlon, mlat, run_mask, basin_masks):
         """land/<B>.nc indicator grids (compute.py:87-97); basin_masks: dict id -> plane."""

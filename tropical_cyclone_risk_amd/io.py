@@ -1,0 +1,83 @@
+"""Track-file writer and environment loader (host plumbing around the hot path).
+
+Output schema = the reference's (`util/compute.py:250-264`, README "Model Output"):
+``lon_trks, lat_trks, u250_trks, v250_trks, u850_trks, v850_trks, v_trks, m_trks,
+vmax_trks [n_trk, time]``, ``tc_month, tc_basins, tc_years [n_trk]``,
+``seeds_per_month [year, basin, month]`` with coords ``n_trk, time, year, basin, month``.
+NetCDF through xarray when it is installed; otherwise a ``.npz`` with the same
+variable names (neither build nor bench container has xarray / netCDF4).
+"""
+import os
+
+import numpy as np
+
+from .basins import BASIN_IDS
+
+
+def _try_xarray():
+    try:
+        import xarray as xr
+        return xr
+    except Exception:
+        return None
+
+
+def get_fn_tracks(b, nl, out_dir=None, ext='nc'):
+    """`compute.py:40-46`."""
+    base = out_dir or '%s/%s' % (nl.output_directory, nl.exp_name)
+    return '%s/tracks_%s_%s_%d%02d_%d%02d.%s' % (base, b.basin_id, nl.exp_prefix, nl.start_year,
+                                                 nl.start_month, nl.end_year, nl.end_month, ext)
+
+
+def fn_tracks_duplicates(fn_trk):
+    """`compute.py:52-58`: never overwrite — append _e<k>."""
+    stem, ext = os.path.splitext(fn_trk)
+    out, k = fn_trk, 0
+    while os.path.exists(out):
+        out = '%s_e%d%s' % (stem, k, ext)
+        k += 1
+    return out
+
+
+def assemble(out, years, nl):
+    """Concatenate the per-year 9-tuples into the output variables (`compute.py:233-248`)."""
+    cat = lambda i: np.concatenate([x[i] for x in out], axis=0)
+    env = cat(5)
+    total_time_s = nl.total_track_time_days * 24 * 60 * 60
+    n_steps_output = int(total_time_s / nl.output_interval_s) + 1
+    data = dict(lon_trks=cat(0), lat_trks=cat(1), u250_trks=env[:, :, 0], v250_trks=env[:, :, 1],
+                u850_trks=env[:, :, 2], v850_trks=env[:, :, 3], v_trks=cat(2), m_trks=cat(3),
+                vmax_trks=cat(4), tc_month=cat(6), tc_basins=cat(7),
+                tc_years=np.concatenate([[yr] * out[i][0].shape[0] for i, yr in enumerate(years)]),
+                seeds_per_month=np.array([x[8] for x in out]))
+    coords = dict(n_trk=np.arange(data['lon_trks'].shape[0]), time=np.linspace(0, total_time_s, n_steps_output),
+                  year=np.array(years), basin=np.array(BASIN_IDS), month=np.arange(1, 13))
+    return data, coords
+
+
+def write_tracks(out, years, b, nl, out_dir=None):
+    data, coords = assemble(out, years, nl)
+    xr = _try_xarray()
+    fn = fn_tracks_duplicates(get_fn_tracks(b, nl, out_dir, 'nc' if xr is not None else 'npz'))
+    os.makedirs(os.path.dirname(fn), exist_ok=True)
+    if xr is not None:
+        two = ['lon_trks', 'lat_trks', 'u250_trks', 'v250_trks', 'u850_trks', 'v850_trks', 'v_trks', 'm_trks', 'vmax_trks']
+        dv = {k: (['n_trk', 'time'], data[k]) for k in two}
+        dv.update({k: (['n_trk'], data[k]) for k in ('tc_month', 'tc_basins', 'tc_years')})
+        dv['seeds_per_month'] = (['year', 'basin', 'month'], data['seeds_per_month'])
+        xr.Dataset(data_vars=dv, coords={k: list(v) if k in ('basin',) else v for k, v in coords.items()}).to_netcdf(fn, mode='w')
+    else:
+        np.savez_compressed(fn, **data, **{'coord_' + k: v for k, v in coords.items()})
+    return fn
+
+
+def load_env(nl):
+    """Environment for run_downscaling.  ``dataset_type = 'SYNTHETIC'`` (or no xarray) selects the
+    regenerated ERA5-shaped fields; real ERA5/CMIP6 input needs xarray + the reference's
+    preprocessed ``env_wnd_*.nc`` / ``thermo_*.nc`` files and is the next row of SURVEY §8f."""
+    from . import synthetic
+    if getattr(nl, 'dataset_type', '').upper() == 'SYNTHETIC' or _try_xarray() is None:
+        return synthetic.make_env('era5', seed=getattr(nl, 'gpu_experiment_seed', 20250614))
+    raise NotImplementedError(
+        'reading %s fields needs the NetCDF field loader (SURVEY.md §8 f-1), not built yet; '
+        'set namelist.dataset_type = "SYNTHETIC" to run on regenerated ERA5-shaped fields' % nl.dataset_type)
