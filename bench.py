@@ -142,15 +142,24 @@ def main():
     value = steps_total / dt
 
     # ---- roofline of the dominant kernel (k_integrate): algorithmic bytes per launch
-    # over its HIP-event duration (events recorded on the launch stream by the library)
+    # (704 B x RHS evaluations of that launch) over its HIP-event duration
+    # (events recorded on the launch stream by the library).  The per-sample share of the
+    # algorithmic bytes (520 B x output samples) is k_emit's and is reported next to it.
     launches = ms['calls']
-    per_launch_bytes = (BYTES_PER_RHS * nfev_total + BYTES_PER_SAMPLE * samples_total) / (launches * world)
     k_ms = ms['integrate_ms'] / launches
-    achieved = per_launch_bytes / (k_ms * 1e-3) / 1e9
+    e_ms = ms['post_ms'] / launches
+    int_bytes = BYTES_PER_RHS * nfev_total / (launches * world)
+    emit_bytes = BYTES_PER_SAMPLE * samples_total / (launches * world)
+    achieved = int_bytes / (k_ms * 1e-3) / 1e9
+    traffic = args.traffic if args.traffic is not None else measured_traffic('tcr::k_integrate<true>', B)
     roof = dict(bound='hbm', kernel='k_integrate', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
-                frac=achieved / HBM_PEAK_GBS, traffic=args.traffic,
-                kernel_ms=dict(fourier=ms['fourier_ms'] / launches, integrate=k_ms, post=ms['post_ms'] / launches),
-                algorithmic_bytes_per_launch=per_launch_bytes)
+                frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                algorithmic_bytes_per_launch=int_bytes, launch_ms=k_ms,
+                kernel_ms=dict(fourier=ms['fourier_ms'] / launches, integrate=k_ms, emit=e_ms),
+                emit=dict(kernel='k_emit', achieved=emit_bytes / (e_ms * 1e-3) / 1e9,
+                          frac=emit_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          algorithmic_bytes_per_launch=emit_bytes, launch_ms=e_ms,
+                          traffic=measured_traffic('tcr::k_emit<true>', B)))
 
     out = None
     if rank == 0:
@@ -178,6 +187,18 @@ def main():
     if world > 1:
         D.barrier()
         torch.distributed.destroy_process_group()
+
+
+def measured_traffic(kernel, storms):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/, collected
+    separately from timing as MI355X_MICROARCH.md prescribes); only valid for the profiled size."""
+    fn = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm.json')
+    if storms != 100_000 or not os.path.exists(fn):
+        return None
+    try:
+        return json.load(open(fn))['kernels'][kernel]['hbm_bytes_per_launch_raw']
+    except Exception:
+        return None
 
 
 def cpu_baseline(pipe, args, B):
