@@ -39,6 +39,7 @@ def main():
     ap.add_argument('--storms', type=int, default=100_000, help='storms integrated per GPU per step')
     ap.add_argument('--basin', default='GL')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-sort', action='store_true', help='keep the dense batch in candidate order')
     ap.add_argument('--cpu-budget', type=float, default=12.0)
     ap.add_argument('--traffic', type=float, default=None,
                     help='HBM bytes per integrate launch from a separate rocprofv3 --pmc pass (see profiles/)')
@@ -71,7 +72,7 @@ def main():
     p_pass = float(((probe.cand['seed_flags'] & 2) != 0).double().mean().item())
     del probe
     C = int(B / max(p_pass, 1e-3) * 1.15) + 4096
-    pipe = DevicePipeline(eng, C, B)
+    pipe = DevicePipeline(eng, C, B, sort_storms=not args.no_sort)
 
     acc = torch.zeros(3, dtype=torch.float64, device=dev)     # storm-steps, nfev, samples
     short = torch.zeros(1, dtype=torch.int64, device=dev)     # rounds that had < B passing seeds

@@ -1,11 +1,4 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-mkdir -p gpurun_out/r01
-lscpu | grep -E "Model name|^CPU\(s\)|Thread|Core|Socket" > gpurun_out/r01/host_cpu.txt
-python bench.py --steps 20 --warmup 3 > gpurun_out/r01/bench.json 2> gpurun_out/r01/bench.err
-tail -c 3000 gpurun_out/r01/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01/stats -o run -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/r01/stats_bench.json 2>/dev/null
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d gpurun_out/r01/pmc_fetch -o run -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d gpurun_out/r01/pmc_write -o run -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d gpurun_out/r01/pmc_l2 -o run -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-find gpurun_out/r01 -type f | head -30
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+timeout 900 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('100k', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"
+timeout 900 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --storms 10000 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('10k', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"

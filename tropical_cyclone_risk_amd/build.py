@@ -35,7 +35,8 @@ def stale():
 def build(force=False, verbose=False):
     if not (force or stale()):
         return OUT
-    cmd = [hipcc()] + FLAGS + ['-o', OUT, os.path.join(CSRC, 'tcr_abi.hip')]
+    extra = os.environ.get('TCR_HIPCC_FLAGS', '').split()      # tuning experiments, e.g. -DTCR_EMIT_WPS=4
+    cmd = [hipcc()] + FLAGS + extra + ['-o', OUT, os.path.join(CSRC, 'tcr_abi.hip')]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

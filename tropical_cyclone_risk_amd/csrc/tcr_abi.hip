@@ -526,7 +526,7 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
         a.slot = in->slot; a.n_valid = out->n_valid; a.status = out->status; a.n_accept = out->n_accept;
         a.lon = out->lon; a.lat = out->lat; a.v = out->v; a.m = out->m; a.vmax = out->vmax;
         a.envw = out->envw; a.flags = out->flags;
-        const size_t lds = sizeof(double) * ((size_t)max_rk * 17 + 2 * ns);
+        const size_t lds = sizeof(double) * ((size_t)max_rk * 23 + 5 * ns);
         if (a.D.all_affine) hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)n), dim3(kEmitThreads), lds, st, a);
         else hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)n), dim3(kEmitThreads), lds, st, a);
     }

@@ -18,7 +18,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/tcrisk_hip.h"
+
+// Read of an evaluation constant (LDS).  Kept as a hook: making it a volatile access (reload at
+// every use instead of letting the compiler hoist the ~70 constants into VGPRs) was measured and
+// made register allocation worse, not better.
+#define RD(x) (x)
 
 namespace tcr {
 
@@ -93,6 +100,16 @@ struct Cell {
     double w0, w1;
 };
 
+// 16-byte load from *global* memory.  Pointers that travelled through structs / LDS are generic,
+// and a generic (flat_load) access also counts against lgkmcnt, so every LDS wait would stall on
+// the outstanding field gathers; telling the compiler the address space gives global_load.
+typedef double tcr_dbl2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ldg16(const double *p)
+{
+    const tcr_dbl2 v = *(const __attribute__((address_space(1))) tcr_dbl2 *)(p);
+    return make_double2(v.x, v.y);
+}
+
 // fpbisp.f (clamp + interval search) and fpbspl.f (k = 1 weights).
 // Affine axes (ERA5's 1 deg / 0.25 deg grids, CMIP regular grids) need no memory
 // traffic at all: the host has verified that x0 + i*dx reproduces every knot
@@ -100,14 +117,15 @@ struct Cell {
 template <bool AFFINE>
 __device__ __forceinline__ Cell locate_t(const DevAxis &A, double arg)
 {
-    arg = (arg < A.x0) ? A.x0 : arg;
-    arg = (arg > A.xn) ? A.xn : arg;
-    const int n = A.n;
-    int i = (int)((arg - A.x0) * A.inv_step);
+    const double ax0 = RD(A.x0), axn = RD(A.xn);
+    arg = (arg < ax0) ? ax0 : arg;
+    arg = (arg > axn) ? axn : arg;
+    const int n = RD(A.n);
+    int i = (int)((arg - ax0) * RD(A.inv_step));
     i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
     Cell c;
     if (AFFINE) {
-        const double dx = A.dx, x0 = A.x0, rdx = A.rdx;
+        const double dx = RD(A.dx), x0 = ax0, rdx = RD(A.rdx);
         const double xl = x0 + (double)i * dx, xr = x0 + (double)(i + 1) * dx;
         const bool up = (i < n - 2) && (arg >= xr);
         const bool dn = !up && (i > 0) && (arg < xl);
@@ -118,10 +136,10 @@ __device__ __forceinline__ Cell locate_t(const DevAxis &A, double arg)
         c.w0 = 0.0 + rdx * (xr2 - arg);
         c.w1 = rdx * (arg - xl2);
     } else {
-        const double *__restrict__ x = A.x;
+        const double *__restrict__ x = RD(A.x);
         while (i < n - 2 && arg >= x[i + 1]) ++i;
         while (i > 0 && arg < x[i]) --i;
-        const double f = A.rx[i];
+        const double f = RD(A.rx)[i];
         c.i = i;
         c.w0 = 0.0 + f * (x[i + 1] - arg);
         c.w1 = f * (arg - x[i]);
@@ -131,7 +149,7 @@ __device__ __forceinline__ Cell locate_t(const DevAxis &A, double arg)
 
 __device__ __forceinline__ Cell locate(const DevAxis &A, double arg)
 {
-    return A.affine ? locate_t<true>(A, arg) : locate_t<false>(A, arg);
+    return RD(A.affine) ? locate_t<true>(A, arg) : locate_t<false>(A, arg);
 }
 
 // The four corners of NF interleaved fields as 16-byte gathers ...
@@ -147,12 +165,11 @@ __device__ __forceinline__ void gather(const double *__restrict__ base, int nlon
 {
     const double *p00 = base + ((size_t)cy.i * nlon + cx.i) * STRIDE;
     const double *p01 = p00 + (size_t)nlon * STRIDE;
-    const double2 *q00 = reinterpret_cast<const double2 *>(p00);
-    const double2 *q01 = reinterpret_cast<const double2 *>(p01);
-    const double2 *q10 = reinterpret_cast<const double2 *>(p00 + STRIDE);
-    const double2 *q11 = reinterpret_cast<const double2 *>(p01 + STRIDE);
 #pragma unroll
-    for (int k = 0; k < Corners<NF>::NV; ++k) { C.c00[k] = q00[k]; C.c01[k] = q01[k]; C.c10[k] = q10[k]; C.c11[k] = q11[k]; }
+    for (int k = 0; k < Corners<NF>::NV; ++k) {
+        C.c00[k] = ldg16(p00 + 2 * k); C.c01[k] = ldg16(p01 + 2 * k);
+        C.c10[k] = ldg16(p00 + STRIDE + 2 * k); C.c11[k] = ldg16(p01 + STRIDE + 2 * k);
+    }
 }
 
 // ... and their bilinear sums in fpbisp.f's order: (x0,y0), (x0,y1), (x1,y0), (x1,y1),
@@ -192,7 +209,7 @@ __device__ __forceinline__ double ts_at(const tcr_params &P, int i)
 
 __device__ __forceinline__ double ts_k(const EvalK &K, int i)
 {
-    return (i == K.n_steps - 1) ? K.total_time : (double)i * K.tstep;
+    return (i == RD(K.n_steps) - 1) ? RD(K.total_time) : (double)i * RD(K.tstep);
 }
 
 // interp1d(t_s, Fs, axis=1)(t) (scipy/interpolate/_interpolate.py:457-486), split into the
@@ -205,8 +222,8 @@ struct FsBracket {
 
 __device__ __forceinline__ FsBracket fs_bracket(const EvalK &K, double t)
 {
-    const int ns = K.n_steps;
-    int idx = (int)ceil(t * K.inv_tstep);
+    const int ns = RD(K.n_steps);
+    int idx = (int)ceil(t * RD(K.inv_tstep));
     idx = idx < 0 ? 0 : (idx > ns - 1 ? ns - 1 : idx);
     const bool dn = (idx > 0) && (ts_k(K, idx - 1) >= t);
     const bool up = !dn && (idx < ns - 1) && (ts_k(K, idx) < t);
@@ -225,8 +242,8 @@ struct FsPair {
 
 __device__ __forceinline__ void fs_gather(const double *__restrict__ fs, const FsBracket &b, FsPair &p)
 {
-    const double2 *q = reinterpret_cast<const double2 *>(fs + (size_t)b.lo * 4);
-    p.a0 = q[0]; p.a1 = q[1]; p.b0 = q[2]; p.b1 = q[3];
+    const double *q = fs + (size_t)b.lo * 4;
+    p.a0 = ldg16(q); p.a1 = ldg16(q + 2); p.b0 = ldg16(q + 4); p.b1 = ldg16(q + 6);
 }
 
 __device__ __forceinline__ void fs_blend(const FsPair &p, const FsBracket &b, double t, double (&F)[4])
@@ -291,7 +308,7 @@ __device__ __forceinline__ void env_winds(const EvalK &K, const DevSlot &S, cons
     const FsBracket fb = fs_bracket(K, t);
     Corners<14> CW;
     FsPair fp;
-    gather<14, kWindStride>(S.wind, K.wx.n, cx, cy, CW);
+    gather<14, kWindStride>(S.wind, RD(K.wx.n), cx, cy, CW);
     fs_gather(fs, fb, fp);
     double q[14], F[4];
     blend<14>(CW, cx, cy, q);
@@ -310,6 +327,58 @@ struct Rhs {
     double shear, vpot, chi;   // what the ventilation gate needs (coupled_fast.py:238-244)
 };
 
+// Everything of dydt after the lookups: steering, beta-advection, _dvdt, ocean feedback, _dmdt.
+__device__ __forceinline__ void rhs_tail(const EvalK &K, double h_bl, double lat, double v, double m,
+                                         const double (&th)[4], const double (&lb)[2], Rhs &r)
+{
+    {
+        const double du = r.w[0] - r.w[2], dw = r.w[1] - r.w[3];
+        r.shear = sqrt(du * du + dw * dw);
+    }
+    // steering coefficients
+    double c0, c1;
+    {
+        double a0 = (v * 1.94384) * RD(K.m_alpha[0]) + RD(K.y_alpha[0]);
+        double a1 = (v * 1.94384) * RD(K.m_alpha[1]) + RD(K.y_alpha[1]);
+        a0 = np_max(np_min(a0, RD(K.alpha_max[0])), RD(K.alpha_min[0]));
+        a1 = np_max(np_min(a1, RD(K.alpha_max[1])), RD(K.alpha_min[1]));
+        const bool bad = (a0 != a0) || (a1 != a1);
+        a0 = bad ? RD(K.y_alpha[0]) : a0;
+        a1 = bad ? RD(K.y_alpha[1]) : a1;
+        c0 = RD(K.coupled_track) ? a0 : RD(K.steering_coefs[0]);
+        c1 = RD(K.coupled_track) ? a1 : RD(K.steering_coefs[1]);
+    }
+    // beta-advection; |lat| >= 80 -> zero motion and zero winds (bam_track.py:134-135)
+    const bool polar = fabs(lat) >= 80;
+    const double w0 = polar ? 0.0 : r.w[0], w1 = polar ? 0.0 : r.w[1];
+    const double w2 = polar ? 0.0 : r.w[2], w3 = polar ? 0.0 : r.w[3];
+    const double cl = cos(lat * (kPi / 180.0));                            // np.deg2rad
+    double vb0 = (w0 * c0 + w2 * c1) + RD(K.u_beta) * cl;
+    double vb1 = (w1 * c0 + w3 * c1) + (sign_of(lat) * RD(K.v_beta)) * cl;
+    vb0 = polar ? 0.0 : vb0;
+    vb1 = polar ? 0.0 : vb1;
+    r.d[0] = vb0 / RD(K.earth_R) * 180. / kPi / cos(lat * kPi / 180.);
+    r.d[1] = vb1 / RD(K.earth_R) * 180. / kPi;
+    // intensity
+    const double vp = (lb[0] == 1.0) ? 0.0 : th[0];                        // coupled_fast.py:35-58
+    const double h_m = th[2], gam = th[3], bathy = lb[1];
+    const bool no_mix = (bathy >= 0) || (-h_m <= bathy) || (gam == 0);
+    const double uT = sqrt(vb0 * vb0 + vb1 * vb1);
+    const double z = 0.01 * pow(gam, -0.4) * h_m * uT * vp / v;
+    const double zc = np_min(np_max(z, 0.0), 100.0);
+    const double al = no_mix ? 1.0 : 1 - 0.87 * exp(-zc);
+    r.alpha = al;
+    const double beta = 1 - RD(K.epsilon) - RD(K.kappa);
+    const double gamma = RD(K.epsilon) + al * RD(K.kappa);
+    const double m3 = m * m * m;
+    const double dv = 0.5 * RD(K.Ck) / h_bl * (al * beta * (vp * vp) * m3 - (1 - gamma * m3) * (v * v));
+    const double du = w0 - w2, dw = w1 - w3;
+    const double venti = sqrt(du * du + dw * dw) * th[1];
+    r.vpot = vp; r.chi = th[1];
+    r.d[2] = (dv != dv) ? 0.0 : dv;
+    r.d[3] = 0.5 * RD(K.Ck) / h_bl * ((1 - m) * v - venti * m);
+}
+
 // fun(t, y) = Coupled_FAST.dydt (coupled_fast.py:196-207): _calc_steering_coefs (:183-192),
 // _step_bam_track (bam_track.py:131-144) on _env_winds (:116-128), _dvdt (:141-150) with
 // _get_current_vpot (:54-58), _calc_alpha/_calc_z (:65-94), _dmdt (:175-180).
@@ -327,10 +396,10 @@ __device__ __forceinline__ Rhs rhs_eval(const EvalK &K, const DevSlot &S, const 
     Corners<4> CT;
     Corners<2> CH;
     FsPair fp;
-    gather<14, kWindStride>(S.wind, K.wx.n, wx, wy, CW);
+    gather<14, kWindStride>(S.wind, RD(K.wx.n), wx, wy, CW);
     fs_gather(fs, fb, fp);
-    gather<4, kThermoStride>(S.thermo, K.tx.n, tx, ty, CT);
-    gather<2, kStaticStride>(K.stat, K.hx.n, hx, hy, CH);
+    gather<4, kThermoStride>(S.thermo, RD(K.tx.n), tx, ty, CT);
+    gather<2, kStaticStride>(RD(K.stat), RD(K.hx.n), hx, hy, CH);
     // ---- straight-line math
     Rhs r;
     double q[14], F[4], th[4], lb[2];
@@ -339,52 +408,50 @@ __device__ __forceinline__ Rhs rhs_eval(const EvalK &K, const DevSlot &S, const 
     winds_from_lookups(q, F, lon, t, r.w);
     blend<4>(CT, tx, ty, th);
     blend<2>(CH, hx, hy, lb);
-    {
-        const double du = r.w[0] - r.w[2], dw = r.w[1] - r.w[3];
-        r.shear = sqrt(du * du + dw * dw);
+    rhs_tail(K, h_bl, lat, v, m, th, lb, r);
+    return r;
+}
+
+// Per-lane corner cache for the sequential integrator.  Consecutive RK stage points of a storm
+// mostly fall into the same grid cell (a stage moves a storm by a fraction of a degree), and the
+// cost of a gather was measured to be per lane-request: keeping the last cell's corner data in
+// registers and re-gathering (exec-masked) only when a lane's cell changes cuts the requests per
+// evaluation from 44 to ~15 without changing a single value.  The cache registers are the load
+// destinations the direct path needs anyway.
+struct CornerCache {
+    int wi, wj;                      // cached wind cell (-1 = empty)
+    Corners<14> CW;
+};
+
+__device__ __forceinline__ void cache_reset(CornerCache &C) { C.wi = C.wj = -1; }
+
+template <bool AFFINE>
+__device__ __forceinline__ Rhs rhs_eval_cached(CornerCache &C, const EvalK &K, const DevSlot &S,
+                                               const double *__restrict__ fs, double h_bl, double t,
+                                               double lon, double lat, double v, double m)
+{
+    const Cell wx = locate_t<AFFINE>(K.wx, lon), wy = locate_t<AFFINE>(K.wy, lat);
+    const Cell tx = locate_t<AFFINE>(K.tx, lon), ty = locate_t<AFFINE>(K.ty, lat);
+    const Cell hx = locate_t<AFFINE>(K.hx, lon), hy = locate_t<AFFINE>(K.hy, lat);
+    const FsBracket fb = fs_bracket(K, t);
+    FsPair fp;
+    fs_gather(fs, fb, fp);
+    if (wx.i != C.wi || wy.i != C.wj) {
+        gather<14, kWindStride>(S.wind, RD(K.wx.n), wx, wy, C.CW);
+        C.wi = wx.i; C.wj = wy.i;
     }
-    // steering coefficients
-    double c0, c1;
-    {
-        double a0 = (v * 1.94384) * K.m_alpha[0] + K.y_alpha[0];
-        double a1 = (v * 1.94384) * K.m_alpha[1] + K.y_alpha[1];
-        a0 = np_max(np_min(a0, K.alpha_max[0]), K.alpha_min[0]);
-        a1 = np_max(np_min(a1, K.alpha_max[1]), K.alpha_min[1]);
-        const bool bad = (a0 != a0) || (a1 != a1);
-        a0 = bad ? K.y_alpha[0] : a0;
-        a1 = bad ? K.y_alpha[1] : a1;
-        c0 = K.coupled_track ? a0 : K.steering_coefs[0];
-        c1 = K.coupled_track ? a1 : K.steering_coefs[1];
-    }
-    // beta-advection; |lat| >= 80 -> zero motion and zero winds (bam_track.py:134-135)
-    const bool polar = fabs(lat) >= 80;
-    const double w0 = polar ? 0.0 : r.w[0], w1 = polar ? 0.0 : r.w[1];
-    const double w2 = polar ? 0.0 : r.w[2], w3 = polar ? 0.0 : r.w[3];
-    const double cl = cos(lat * (kPi / 180.0));                            // np.deg2rad
-    double vb0 = (w0 * c0 + w2 * c1) + K.u_beta * cl;
-    double vb1 = (w1 * c0 + w3 * c1) + (sign_of(lat) * K.v_beta) * cl;
-    vb0 = polar ? 0.0 : vb0;
-    vb1 = polar ? 0.0 : vb1;
-    r.d[0] = vb0 / K.earth_R * 180. / kPi / cos(lat * kPi / 180.);
-    r.d[1] = vb1 / K.earth_R * 180. / kPi;
-    // intensity
-    const double vp = (lb[0] == 1.0) ? 0.0 : th[0];                        // coupled_fast.py:35-58
-    const double h_m = th[2], gam = th[3], bathy = lb[1];
-    const bool no_mix = (bathy >= 0) || (-h_m <= bathy) || (gam == 0);
-    const double uT = sqrt(vb0 * vb0 + vb1 * vb1);
-    const double z = 0.01 * pow(gam, -0.4) * h_m * uT * vp / v;
-    const double zc = np_min(np_max(z, 0.0), 100.0);
-    const double al = no_mix ? 1.0 : 1 - 0.87 * exp(-zc);
-    r.alpha = al;
-    const double beta = 1 - K.epsilon - K.kappa;
-    const double gamma = K.epsilon + al * K.kappa;
-    const double m3 = m * m * m;
-    const double dv = 0.5 * K.Ck / h_bl * (al * beta * (vp * vp) * m3 - (1 - gamma * m3) * (v * v));
-    const double du = w0 - w2, dw = w1 - w3;
-    const double venti = sqrt(du * du + dw * dw) * th[1];
-    r.vpot = vp; r.chi = th[1];
-    r.d[2] = (dv != dv) ? 0.0 : dv;
-    r.d[3] = 0.5 * K.Ck / h_bl * ((1 - m) * v - venti * m);
+    Corners<4> CT;
+    Corners<2> CH;
+    gather<4, kThermoStride>(S.thermo, RD(K.tx.n), tx, ty, CT);
+    gather<2, kStaticStride>(RD(K.stat), RD(K.hx.n), hx, hy, CH);
+    Rhs r;
+    double q[14], F[4], th[4], lb[2];
+    blend<14>(C.CW, wx, wy, q);
+    fs_blend(fp, fb, t, F);
+    winds_from_lookups(q, F, lon, t, r.w);
+    blend<4>(CT, tx, ty, th);
+    blend<2>(CH, hx, hy, lb);
+    rhs_tail(K, h_bl, lat, v, m, th, lb, r);
     return r;
 }
 

@@ -102,18 +102,25 @@ __global__ __launch_bounds__(kFsThreads) void k_fourier_periodic(tcr_params P, i
     }
     __syncthreads();
     double *out = fs + storm * ns * 4;
-    for (int p = threadIdx.x; p < ns * 4; p += kFsThreads) {
-        const int k = p >> 2, s = p & 3;
-        double acc = 0.0;
+    // one thread = one output sample, all four series: the table entry of harmonic h is shared by
+    // the four series (4 independent accumulators, 1 table read + 4 broadcast reads per harmonic)
+    for (int k = threadIdx.x; k < ns; k += kFsThreads) {
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
         int j = 0;                               // (n * k) mod period, built incrementally
         const int kk = k % period;
         for (int h = 0; h < N; ++h) {
             j += kk; if (j >= period) j -= period;
-            const double2 a = tab[j], b = ph[s * N + h];
-            const double term = P.fs_wgt[h] * (a.x * b.y + a.y * b.x);
-            acc = (h == 0) ? term : acc + term;
+            const double2 a = tab[j];
+            const double wgt = P.fs_wgt[h];
+            const double2 b0 = ph[h], b1 = ph[N + h], b2 = ph[2 * N + h], b3 = ph[3 * N + h];
+            const double t0 = wgt * (a.x * b0.y + a.y * b0.x), t1 = wgt * (a.x * b1.y + a.y * b1.x);
+            const double t2 = wgt * (a.x * b2.y + a.y * b2.x), t3 = wgt * (a.x * b3.y + a.y * b3.x);
+            acc0 = (h == 0) ? t0 : acc0 + t0; acc1 = (h == 0) ? t1 : acc1 + t1;
+            acc2 = (h == 0) ? t2 : acc2 + t2; acc3 = (h == 0) ? t3 : acc3 + t3;
         }
-        out[p] = P.fs_amp * acc;
+        double2 *o = reinterpret_cast<double2 *>(out + (size_t)k * 4);
+        o[0] = make_double2(P.fs_amp * acc0, P.fs_amp * acc1);
+        o[1] = make_double2(P.fs_amp * acc2, P.fs_amp * acc3);
     }
 }
 
@@ -205,6 +212,8 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
     double y[4] = {0, 0, 0, 0}, f[4] = {0, 0, 0, 0}, yn[4] = {0, 0, 0, 0};
     double e[5] = {0, 0, 0, 0, 0};          // evaluation point: t, lon, lat, v, m
     double t = 0, h = 0, ha = 0, h_abs = 0, t_new = 0, g = 0;
+    CornerCache CC;
+    cache_reset(CC);
 
     auto finalize = [&]() {
         a.n_valid[sid] = next_out;
@@ -261,6 +270,7 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
                     t = 0.0;
                     e[0] = 0.0; e[1] = y[0]; e[2] = y[1]; e[3] = y[2]; e[4] = y[3];
                     active = true; fresh = true;
+                    cache_reset(CC);
                 }
             }
         }
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
         for (int slot = 0; slot < 6; ++slot) {
             const bool live = active && !(fresh && slot >= 2);
             Rhs r{};
-            if (live) r = rhs_eval<AFFINE>(K, S, fs, h_bl, e[0], e[1], e[2], e[3], e[4]);
+            if (live) r = rhs_eval_cached<AFFINE>(CC, K, S, fs, h_bl, e[0], e[1], e[2], e[3], e[4]);
             if (live && !fresh) {
                 // rk_step (rk.py:62-70): K[s] = fun(...); next stage input dy = dot(K[:s].T, a[:s]) * h
                 ++nfev;
@@ -420,15 +430,18 @@ __device__ __forceinline__ double haversine_km(const tcr_params &P, double lon1,
 }
 
 constexpr int kEmitThreads = 128;
-constexpr int kEmitMaxSamples = 1024;      // LDS staging of one storm's lon/lat/v (n_steps <= this)
+#ifndef TCR_EMIT_WPS
+#define TCR_EMIT_WPS 2     // waves per SIMD k_emit is register-budgeted for (it is a throughput kernel)
+#endif
 
 template <bool AFFINE>
-__global__ __launch_bounds__(kEmitThreads) void k_emit(EArgs a)
+__global__ __launch_bounds__(kEmitThreads, TCR_EMIT_WPS) void k_emit(EArgs a)
 {
-    extern __shared__ double esh[];        // t_new[max_rk_steps], lon[ns], lat[ns], Q[max_rk_steps][16]
+    // LDS: per accepted step {t_new, t_old, h, y_old[4], Q[16]} = 23 doubles; per sample {lon, lat, v, us, vs}
+    extern __shared__ double esh[];
     __shared__ EvalK K;
-    __shared__ double s_best[kEmitThreads];
-    __shared__ int s_any[kEmitThreads];
+    __shared__ double s_best[kEmitThreads / 64];
+    __shared__ int s_any[kEmitThreads / 64];
     __shared__ double s_v2d[2];
     const tcr_params &P = a.P;
     const int64_t sid = blockIdx.x;
@@ -437,62 +450,75 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(EArgs a)
     const int status = a.status[sid];
     int nst = a.n_accept[sid];
     nst = nst < a.max_rk_steps ? nst : a.max_rk_steps;
-    double *s_tnew = esh, *s_lon = esh + a.max_rk_steps, *s_lat = s_lon + ns, *s_Q = s_lat + ns;
+    double *s_step = esh;                                   // [max_rk_steps][23]
+    double *s_lon = esh + (size_t)a.max_rk_steps * 23, *s_lat = s_lon + ns, *s_v = s_lat + ns;
+    double *s_us = s_v + ns, *s_vs = s_us + ns;
     const double *srec = a.srec + sid * (int64_t)a.max_rk_steps * kStepRec;
     const double *fs = a.fs + sid * ns * 4;
     const DevSlot S = a.D.slots[a.slot[sid]];
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
-    for (int j = threadIdx.x; j < nst; j += kEmitThreads) s_tnew[j] = srec[(size_t)j * kStepRec + 2];
-    // dense output Q = K^T P per accepted step (rk.py:179-181): one (step, component, power) per thread
-    for (int p = threadIdx.x; p < nst * 16; p += kEmitThreads) {
-        const int j = p >> 4, i = (p >> 2) & 3, k = p & 3;
-        const double *kr = srec + (size_t)j * kStepRec + 8;
-        double acc = 0.0;
-        for (int q = 0; q < 7; ++q) acc += kr[q * 4 + i] * RK_P[q][k];
-        s_Q[p] = acc;
+    // stage t_new, t_old, h, y_old and the dense-output matrix Q = K^T P (rk.py:179-181)
+    for (int p = threadIdx.x; p < nst * 23; p += kEmitThreads) {
+        const int j = p / 23, c = p - j * 23;
+        const double *rj = srec + (size_t)j * kStepRec;
+        double val;
+        if (c == 0) val = rj[2];
+        else if (c == 1) val = rj[0];
+        else if (c == 2) val = rj[1];
+        else if (c < 7) val = rj[4 + (c - 3)];
+        else {
+            const int i = (c - 7) >> 2, k = (c - 7) & 3;
+            double acc = 0.0;
+            for (int q = 0; q < 7; ++q) acc += rj[8 + q * 4 + i] * RK_P[q][k];
+            val = acc;
+        }
+        s_step[p] = val;
     }
     if (threadIdx.x == 0) make_eval_k(P, a.D, K);
     __syncthreads();
 
-    // ---- pass 1: dense output + env winds per sample
+    // ---- pass 1: dense output + env winds per valid sample; NaN padding beyond
     const double step_out = P.total_time / (double)(ns - 1);
     const double t2d = 2 * 86400.0;
     int any15 = 0;
-    for (int i = threadIdx.x; i < ns; i += kEmitThreads) {
+    for (int i0 = 0; i0 < ns; i0 += kEmitThreads) {
+        const int i = i0 + threadIdx.x;
         double lon = nan, lat = nan, v = nan, m = nan, w[4] = {nan, nan, nan, nan};
-        if (i < n) {
-            const double te = ts_at(P, i);
+        const bool valid = i < n;
+        double te = 0.0, ye[4] = {0.0, 0.0, 0.0, 0.0};
+        if (valid) {
+            te = ts_at(P, i);
             // the sample belongs to the first accepted step whose end is >= te
             int lo = 0, hi = nst - 1;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_tnew[mid] >= te) hi = mid; else lo = mid + 1; }
-            const double2 *q = reinterpret_cast<const double2 *>(srec + (size_t)lo * kStepRec);
-            const double2 th = q[0];                 // t_old, h
-            const double x = (te - th.x) / th.y;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_step[mid * 23] >= te) hi = mid; else lo = mid + 1; }
+            const double *st = s_step + lo * 23;
+            const double hh = st[2];
+            const double x = (te - st[1]) / hh;
             const double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
-            const double2 y01 = q[2], y23 = q[3];
-            const double yo[4] = {y01.x, y01.y, y23.x, y23.y};
-            double ye[4];
             for (int c = 0; c < 4; ++c) {
-                const double *Q = s_Q + lo * 16 + c * 4;
+                const double *Q = st + 7 + c * 4;
                 double acc = 0.0;
                 acc += Q[0] * p1; acc += Q[1] * p2; acc += Q[2] * p3; acc += Q[3] * p4;
-                ye[c] = th.y * acc + yo[c];
+                ye[c] = hh * acc + st[3 + c];
             }
-            lon = ye[0]; lat = ye[1]; v = ye[2]; m = ye[3];
-            env_winds<AFFINE>(K, S, fs, lon, lat, te, w);
-            if (v >= P.v_thresh) any15 = 1;
         }
-        s_lon[i] = lon; s_lat[i] = lat;
-        const size_t o = (size_t)sid * ns + i;
-        a.lon[o] = lon; a.lat[o] = lat; a.v[o] = v; a.m[o] = m;
-        double2 *eo = reinterpret_cast<double2 *>(a.envw + o * 4);
-        eo[0] = make_double2(w[0], w[1]);
-        eo[1] = make_double2(w[2], w[3]);
-        // np.interp(2 d, res.t, v) needs v at the two samples bracketing 2 d (or the last one)
-        if (i < n) {
+        if (valid) {
+            env_winds<AFFINE>(K, S, fs, ye[0], ye[1], te, w);
+            lon = ye[0]; lat = ye[1]; v = ye[2]; m = ye[3];
+            if (v >= P.v_thresh) any15 = 1;
+            s_lon[i] = lon; s_lat[i] = lat; s_v[i] = v;
+            s_us[i] = w[0] - w[2]; s_vs[i] = w[1] - w[3];
+            // np.interp(2 d, res.t, v) needs v at the two samples bracketing 2 d (or the last one)
             const int j2 = (int)floor(t2d / step_out);
             if (t2d >= ts_at(P, n - 1)) { if (i == n - 1) s_v2d[0] = s_v2d[1] = v; }
             else { if (i == j2) s_v2d[0] = v; if (i == j2 + 1) s_v2d[1] = v; }
+        }
+        if (i < ns) {
+            const size_t o = (size_t)sid * ns + i;
+            a.lon[o] = lon; a.lat[o] = lat; a.v[o] = v; a.m[o] = m;
+            double2 *eo = reinterpret_cast<double2 *>(a.envw + o * 4);
+            eo[0] = make_double2(w[0], w[1]);
+            eo[1] = make_double2(w[2], w[3]);
         }
     }
     __syncthreads();
@@ -502,10 +528,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(EArgs a)
     for (int i = threadIdx.x; i < ns; i += kEmitThreads) {
         double vm = nan;
         if (i < n && n > 1) {
-            const size_t o = (size_t)sid * ns + i;
-            const double lon = s_lon[i], lat = s_lat[i], v = a.v[o];
-            const double2 *eo = reinterpret_cast<const double2 *>(a.envw + o * 4);
-            const double2 w01 = eo[0], w23 = eo[1];
+            const double lon = s_lon[i], lat = s_lat[i], v = s_v[i];
             // linear extrapolation at both ends (sphere.py:66-69)
             const double lom = (i == 0) ? 2 * lon - s_lon[1] : s_lon[i - 1];
             const double lam = (i == 0) ? 2 * lat - s_lat[1] : s_lat[i - 1];
@@ -515,8 +538,8 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(EArgs a)
             const double dlat = 0.5 * (sign_of(lap - lam) * haversine_km(P, lon, lap, lon, lam));
             const double ut = dlon * 1000. / P.dt_out, vt = dlat * 1000. / P.dt_out;
             const double G = fmin(1., 0.8 + 0.35 * (1. + tanh((lat - 35.) / 10.)));
-            const double Ui = G * ut + 0.1 * (w01.x - w23.x) * v / 15.;
-            const double Vi = G * vt + 0.1 * (w01.y - w23.y) * v / 15.;
+            const double Ui = G * ut + 0.1 * s_us[i] * v / 15.;
+            const double Vi = G * vt + 0.1 * s_vs[i] * v / 15.;
             const double mag = sqrt(Ui * Ui + Vi * Vi);
             const double fac = np_min((v * 0.50) / mag, 1.0);
             const double th = atan2(-Ui, Vi);
@@ -527,17 +550,15 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(EArgs a)
         }
         a.vmax[(size_t)sid * ns + i] = vm;
     }
-    s_best[threadIdx.x] = best;
-    s_any[threadIdx.x] = any15;
-    __syncthreads();
-    for (int s = kEmitThreads / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            s_best[threadIdx.x] = fmax(s_best[threadIdx.x], s_best[threadIdx.x + s]);
-            s_any[threadIdx.x] |= s_any[threadIdx.x + s];
-        }
-        __syncthreads();
+    // ---- accept flags: wave reductions, then one thread
+    for (int off = 32; off > 0; off >>= 1) {
+        best = fmax(best, __shfl_down(best, off));
+        any15 |= __shfl_down(any15, off);
     }
+    if ((threadIdx.x & 63) == 0) { s_best[threadIdx.x >> 6] = best; s_any[threadIdx.x >> 6] = any15; }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        for (int wv = 1; wv < kEmitThreads / 64; ++wv) { best = fmax(best, s_best[wv]); any15 |= s_any[wv]; }
         int fl = 0;
         if (n > 0 && status != TCR_STATUS_GATED) {
             double v2d;
@@ -546,18 +567,15 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(EArgs a)
                 const int j = (int)floor(t2d / step_out);
                 v2d = (s_v2d[1] - s_v2d[0]) / (ts_at(P, j + 1) - ts_at(P, j)) * (t2d - ts_at(P, j)) + s_v2d[0];
             }
-            if (s_any[0] && v2d >= P.v_2d_thresh) {
+            if (any15 && v2d >= P.v_2d_thresh) {
                 fl |= TCR_FLAG_IS_TC;
-                if (n > 1 && s_best[0] >= P.vmax_thresh) fl |= TCR_FLAG_ACCEPTED;
+                if (n > 1 && best >= P.vmax_thresh) fl |= TCR_FLAG_ACCEPTED;
             }
         }
         a.flags[sid] = fl;
     }
 }
 
-// ---------------------------------------------------------------------------
-// Probe: dydt / _env_winds / _calc_alpha at arbitrary points of one slot with one
-// forcing table (parity tests of the seam's leaf methods).
 template <bool AFFINE>
 __global__ __launch_bounds__(64) void k_probe_rhs(tcr_params P, DevFields D, int slot, double h_bl, const double *fs,
                             int64_t n, const double *t, const double *lon, const double *lat,

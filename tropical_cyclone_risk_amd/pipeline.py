@@ -20,7 +20,7 @@ I32 = torch.int32
 
 
 class DevicePipeline:
-    def __init__(self, engine, max_candidates, max_storms, device=None):
+    def __init__(self, engine, max_candidates, max_storms, device=None, sort_storms=False):
         self.eng = engine
         self.dev = torch.device('cuda', engine.device) if device is None else device
         self.C, self.B = int(max_candidates), int(max_storms)
@@ -40,6 +40,7 @@ class DevicePipeline:
         self.n_passed = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.acc_idx = z(self.B, dtype=I32)
         self.n_accepted = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.sort_storms = sort_storms
 
     # raw pointers -----------------------------------------------------------
     @staticmethod
@@ -79,6 +80,14 @@ class DevicePipeline:
         L, h, st = self.eng.L, self.eng.h, C.c_void_p(self._stream())
         self.eng._ck(L.tcr_compact_dev(h, self.n_cand, self.cand['seed_flags'].data_ptr(), 2, n_take,
                                        self.cand_idx.data_ptr(), self.n_passed.data_ptr(), st))
+        if self.sort_storms:
+            # Optional locality order (month slot, then 2-degree cell).  Measured on MI355X at 100k
+            # storms: k_integrate 2.40 -> 2.25 ms, but the sort itself costs more than that, so it
+            # is off by default; with it, dense order is no longer candidate order.
+            ci = self.cand_idx[:n_take].long()
+            key = (self.cand['slot'][ci].long() << 32) | \
+                  ((self.cand['lat0'][ci] * 0.5 + 64).long() << 16) | (self.cand['lon0'][ci] * 0.5 + 256).long()
+            self.cand_idx[:n_take] = self.cand_idx[:n_take][torch.argsort(key)]
         src, dst = self._seeds_struct(self.cand, self.n_cand), self._seeds_struct(self.storms, n_take)
         self.eng._ck(L.tcr_gather_seeds_dev(h, C.byref(src), self.cand_idx.data_ptr(), n_take, C.byref(dst), st))
         self.n_storms = n_take
