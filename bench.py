@@ -39,7 +39,7 @@ def main():
     ap.add_argument('--storms', type=int, default=100_000, help='storms integrated per GPU per step')
     ap.add_argument('--basin', default='GL')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-sort', action='store_true', help='keep the dense batch in candidate order')
+    ap.add_argument('--sort', action='store_true', help='locality-sort the dense batch (see pipeline.py)')
     ap.add_argument('--cpu-budget', type=float, default=12.0)
     ap.add_argument('--traffic', type=float, default=None,
                     help='HBM bytes per integrate launch from a separate rocprofv3 --pmc pass (see profiles/)')
@@ -72,11 +72,10 @@ def main():
     p_pass = float(((probe.cand['seed_flags'] & 2) != 0).double().mean().item())
     del probe
     C = int(B / max(p_pass, 1e-3) * 1.15) + 4096
-    pipe = DevicePipeline(eng, C, B, sort_storms=not args.no_sort)
+    pipe = DevicePipeline(eng, C, B, sort_storms=args.sort)
 
-    acc = torch.zeros(3, dtype=torch.float64, device=dev)     # storm-steps, nfev, samples
+    acc = torch.zeros(4, dtype=torch.int64, device=dev)       # storm-steps, nfev, samples, accepted (tcr_stats_dev)
     short = torch.zeros(1, dtype=torch.int64, device=dev)     # rounds that had < B passing seeds
-    n_acc_total = torch.zeros(1, dtype=torch.int64, device=dev)
     row = 9 * ns
     cap = B
     packed = [torch.empty(cap, row, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
@@ -89,10 +88,7 @@ def main():
         pipe.seed_round(year, D.round_block(k, C, rank, world))
         pipe.select_passed(B)
         pipe.integrate(B)
-        nv = pipe.tracks['n_valid'][:B]
-        acc[0] += (nv - 1).clamp_min(0).sum()
-        acc[1] += pipe.tracks['nfev'][:B].sum()
-        acc[2] += nv.sum()
+        pipe.add_stats(acc)
         short.add_((pipe.n_passed < B).long())
         if world > 1:
             # all-gather of this batch's final (accepted) tracks, overlapped with the next
@@ -107,9 +103,6 @@ def main():
             counts = D.allgather_counts(pipe.n_accepted)
             _, fin = D.allgather_rows(packed[slot], None, counts=[min(c, cap) for c in counts], async_op=True)
             pending[slot] = fin
-        else:
-            pipe.select_accepted()
-            n_acc_total.add_(pipe.n_accepted)
 
     def drain():
         nonlocal gathered_rows
@@ -123,7 +116,7 @@ def main():
     for k in range(args.warmup):
         step(k)
     drain()
-    acc.zero_(); short.zero_(); n_acc_total.zero_()
+    acc.zero_(); short.zero_()
     D.barrier(); torch.cuda.synchronize()
     eng.timing_enable(True)          # resets the event record: only the K timed steps count
     gathered_rows = 0
@@ -138,7 +131,7 @@ def main():
     ms = (eng.L and eng.timing_sum())
     if world > 1:
         D.allreduce_sum_(acc)
-    steps_total, nfev_total, samples_total = (float(x) for x in acc.tolist())
+    steps_total, nfev_total, samples_total, accepted_total = (float(x) for x in acc.tolist())
     n_short = int(short.item())
     value = steps_total / dt
 
@@ -179,7 +172,7 @@ def main():
                        'n_steps_out': ns, 'rounds_short_of_storms': n_short,
                        'storm_steps_per_storm': steps_total / (B * args.steps * world),
                        'rhs_per_storm_step': nfev_total / max(steps_total, 1),
-                       'accepted_fraction': (float(n_acc_total.item()) / (B * args.steps)) if world == 1 else None,
+                       'accepted_fraction': accepted_total / (B * args.steps * world),
                        'allgather_rows': gathered_rows if world > 1 else None},
             'roofline': roof,
             'cpu_baseline': cpu,

@@ -151,7 +151,7 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in_dev, const tcr_tracks *
  * (experiment_seed, year, candidate index).  Device buffers (all [n]):
  * lon0, lat0, v0, m0, h_bl, slot, phases as tcr_storms; basin_idx (sorted-id
  * index), seed_flags bit0 = counts toward n_seeds (compute.py:165-167),
- * bit1 = passed the PI gate (compute.py:168). */
+ * bit1 = passed the PI gate (compute.py:168).  phases may be NULL (see tcr_gather_seeds_dev). */
 typedef struct {
     int64_t n;
     double *lon0, *lat0, *v0, *m0, *h_bl;
@@ -171,9 +171,16 @@ int tcr_seed_host(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t 
  * order, first max_out of them -> idx; *count = how many matched (device scalar). */
 int tcr_compact_dev(tcr_ctx *ctx, int64_t n, const int32_t *flags_dev, int32_t mask, int64_t max_out,
                     int32_t *idx_dev, int64_t *count_dev, void *stream);
-/* dense storm batch dst[r] = src[idx[r]], r < n_out (seed rows incl. their 4*n_series phases) */
+/* dense storm batch dst[r] = src[idx[r]], r < n_out.  If src_dev->phases is NULL (tcr_seed_dev was
+ * asked not to write them: most candidates never pass) the 4*n_series Fourier phases of the selected
+ * candidates are drawn here from the same Philox stream (candidate = cand0 + idx[r]). */
 int tcr_gather_seeds_dev(tcr_ctx *ctx, const tcr_seeds *src_dev, const int32_t *idx_dev, int64_t n_out,
-                         const tcr_seeds *dst_dev, void *stream);
+                         const tcr_seeds *dst_dev, uint64_t experiment_seed, int32_t year, int64_t cand0,
+                         void *stream);
+/* sums over a finished batch, for throughput accounting and round control: out_dev[0] = storm-steps
+ * (sum of max(n_valid-1, 0)), [1] = RHS evaluations, [2] = output samples, [3] = accepted tracks;
+ * the four uint64 counters are ADDED to (zero them first). */
+int tcr_stats_dev(tcr_ctx *ctx, int64_t n, const tcr_tracks *tracks_dev, uint64_t *out_dev, void *stream);
 /* survivor records for the all-gather of final tracks (compute.py:233-242 concatenation):
  * packed[r] = { lon[ns], lat[ns], v[ns], m[ns], vmax[ns], envw[ns][4] } of track idx[r],
  * r < min(*count_dev, cap). */

@@ -697,7 +697,7 @@ int tcr_compact_dev(tcr_ctx *ctx, int64_t n, const int32_t *flags, int32_t mask,
 }
 
 int tcr_gather_seeds_dev(tcr_ctx *ctx, const tcr_seeds *src, const int32_t *idx, int64_t n_out,
-                         const tcr_seeds *dst, void *stream_)
+                         const tcr_seeds *dst, uint64_t experiment_seed, int32_t year, int64_t cand0, void *stream_)
 {
     if (!ctx) return -1;
     if (!ctx->have_prm) return fail(ctx, "tcr_params_set has not been called");
@@ -707,8 +707,24 @@ int tcr_gather_seeds_dev(tcr_ctx *ctx, const tcr_seeds *src, const int32_t *idx,
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
     GatherSeedArgs a{};
     a.src = *src; a.dst = *dst; a.idx = idx; a.n_out = n_out; a.phases_per_storm = 4 * ctx->prm.n_series;
+    a.seed = experiment_seed; a.year = year; a.cand0 = cand0;
     const int64_t threads = n_out * 64;
     hipLaunchKernelGGL(k_gather_seeds, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+int tcr_stats_dev(tcr_ctx *ctx, int64_t n, const tcr_tracks *t, uint64_t *out, void *stream_)
+{
+    if (!ctx) return -1;
+    if (!t || !out) return fail(ctx, "tcr_stats_dev: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n <= 0) return 0;
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(k_stats, dim3((unsigned)blocks), dim3(256), 0, st, n, t->n_valid, t->nfev, t->flags,
+                       reinterpret_cast<unsigned long long *>(out));
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }

@@ -7,6 +7,7 @@
 // what makes the result independent of batch size and GPU count, so compaction
 // is a scan, not an atomic append.
 #include "tcr_device.h"
+#include "tcr_seed.hip"
 
 namespace tcr {
 
@@ -95,6 +96,9 @@ struct GatherSeedArgs {
     const int32_t *idx;
     int64_t n_out;
     int phases_per_storm;
+    uint64_t seed;
+    int32_t year;
+    int64_t cand0;
 };
 
 __global__ __launch_bounds__(256) void k_gather_seeds(GatherSeedArgs a)
@@ -111,9 +115,35 @@ __global__ __launch_bounds__(256) void k_gather_seeds(GatherSeedArgs a)
         if (a.dst.basin_idx) a.dst.basin_idx[row] = a.src.basin_idx[j];
         if (a.dst.seed_flags) a.dst.seed_flags[row] = a.src.seed_flags[j];
     }
-    const double *sp = a.src.phases + (size_t)j * a.phases_per_storm;
     double *dp = a.dst.phases + (size_t)row * a.phases_per_storm;
-    for (int k = lane; k < a.phases_per_storm; k += 64) dp[k] = sp[k];
+    if (a.src.phases) {
+        const double *sp = a.src.phases + (size_t)j * a.phases_per_storm;
+        for (int k = lane; k < a.phases_per_storm; k += 64) dp[k] = sp[k];
+    } else {
+        for (int k = lane; k < a.phases_per_storm; k += 64) dp[k] = phase_at(a.seed, a.year, a.cand0 + j, k);
+    }
+}
+
+// Sums over a finished batch (throughput accounting / round control): one atomic per workgroup.
+__global__ __launch_bounds__(256) void k_stats(int64_t n, const int32_t *__restrict__ n_valid,
+                                               const int32_t *__restrict__ nfev, const int32_t *__restrict__ flags,
+                                               unsigned long long *__restrict__ out)
+{
+    __shared__ unsigned long long s[4][4];
+    unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int nv = n_valid[i];
+        a0 += nv > 1 ? nv - 1 : 0;
+        a1 += nfev[i];
+        a2 += nv;
+        a3 += (flags[i] & TCR_FLAG_ACCEPTED) ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        a0 += __shfl_down(a0, off); a1 += __shfl_down(a1, off); a2 += __shfl_down(a2, off); a3 += __shfl_down(a3, off);
+    }
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; s[w][0] = a0; s[w][1] = a1; s[w][2] = a2; s[w][3] = a3; }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(out + threadIdx.x, s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x]);
 }
 
 // Pack selected tracks into fixed-size survivor records for the all-gather:

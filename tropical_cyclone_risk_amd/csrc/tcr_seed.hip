@@ -12,6 +12,7 @@
 // U(lat)]* while the run-basin mask < 1e-2 (:146-148), month (:151), U for the
 // low-latitude filter (:165), N(0,1) for v0 (:172), then the 60 Fourier phases
 // gen_f consumes inside gen_track (bam_track.py:27).
+#pragma once
 #include "tcr_device.h"
 
 namespace tcr {
@@ -43,6 +44,24 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 
 // two uniforms in [0,1) with 53 random bits each (NumPy's legacy double recipe)
+__device__ __forceinline__ void uniform2_raw(uint64_t seed, int32_t year, int64_t cand, uint32_t purpose,
+                                             uint32_t idx, double &u0, double &u1)
+{
+    uint32_t o[4];
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ ((uint32_t)year * 0x9E3779B9u);
+    philox4x32_10((uint32_t)cand, (uint32_t)((uint64_t)cand >> 32), purpose, idx, k0, k1, o);
+    u0 = ((double)(o[0] >> 5) * 67108864.0 + (double)(o[1] >> 6)) / 9007199254740992.0;
+    u1 = ((double)(o[2] >> 5) * 67108864.0 + (double)(o[3] >> 6)) / 9007199254740992.0;
+}
+
+// the 4*N Fourier phases of one candidate (purpose 2), element k
+__device__ __forceinline__ double phase_at(uint64_t seed, int32_t year, int64_t cand, int k)
+{
+    double p0, p1;
+    uniform2_raw(seed, year, cand, 2u, (uint32_t)(k >> 1), p0, p1);
+    return (k & 1) ? p1 : p0;
+}
+
 __device__ __forceinline__ void uniform2(const SeedArgs &a, int64_t cand, uint32_t purpose, uint32_t idx,
                                          double &u0, double &u1)
 {
@@ -148,6 +167,7 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a)
     a.out.basin_idx[i] = bidx;
     a.out.seed_flags[i] = flags;
     const int N = P.n_series;
+    if (!a.out.phases) return;               // drawn later, only for the candidates that pass
     double *ph = a.out.phases + (size_t)i * 4 * N;
     for (int k = 0; k < 4 * N; k += 2) {
         double p0, p1;

@@ -26,10 +26,11 @@ class DevicePipeline:
         self.C, self.B = int(max_candidates), int(max_storms)
         ns, N = engine.n_steps, engine.n_series
         z = lambda *shape, dtype=F64: torch.empty(*shape, dtype=dtype, device=self.dev)
-        seeds = lambda n: dict(n=n, lon0=z(n), lat0=z(n), v0=z(n), m0=z(n), h_bl=z(n),
-                               slot=z(n, dtype=I32), phases=z(n, 4 * N),
-                               basin_idx=z(n, dtype=I32), seed_flags=z(n, dtype=I32))
-        self.cand = seeds(self.C)             # one seeding round
+        seeds = lambda n, ph=True: dict(n=n, lon0=z(n), lat0=z(n), v0=z(n), m0=z(n), h_bl=z(n),
+                                        slot=z(n, dtype=I32), phases=z(n, 4 * N) if ph else None,
+                                        basin_idx=z(n, dtype=I32), seed_flags=z(n, dtype=I32))
+        # candidates carry no Fourier phases: they are drawn at selection time, only for seeds that pass
+        self.cand = seeds(self.C, ph=False)   # one seeding round
         self.storms = seeds(self.B)           # the candidates that passed, dense
         self.tracks = dict(lon=z(self.B, ns), lat=z(self.B, ns), v=z(self.B, ns), m=z(self.B, ns),
                            vmax=z(self.B, ns), envw=z(self.B, ns, 4),
@@ -49,8 +50,8 @@ class DevicePipeline:
 
     def _seeds_struct(self, d, n=None):
         s = _lib.Seeds(int(d['n'] if n is None else n),
-                       *[d[k].data_ptr() for k in ('lon0', 'lat0', 'v0', 'm0', 'h_bl', 'slot', 'phases',
-                                                    'basin_idx', 'seed_flags')])
+                       *[(d[k].data_ptr() if d[k] is not None else None)
+                         for k in ('lon0', 'lat0', 'v0', 'm0', 'h_bl', 'slot', 'phases', 'basin_idx', 'seed_flags')])
         return s
 
     def _tracks_struct(self):
@@ -71,6 +72,7 @@ class DevicePipeline:
         self.eng._ck(self.eng.L.tcr_seed_dev(self.eng.h, C.c_uint64(seed), int(year), int(cand0),
                                              C.byref(s), C.c_void_p(self._stream())))
         self.n_cand = n
+        self._round = (seed, int(year), int(cand0))
 
     def select_passed(self, n_take=None):
         """Dense batch of the first n_take candidates whose seed passed (flag bit 1),
@@ -89,7 +91,9 @@ class DevicePipeline:
                   ((self.cand['lat0'][ci] * 0.5 + 64).long() << 16) | (self.cand['lon0'][ci] * 0.5 + 256).long()
             self.cand_idx[:n_take] = self.cand_idx[:n_take][torch.argsort(key)]
         src, dst = self._seeds_struct(self.cand, self.n_cand), self._seeds_struct(self.storms, n_take)
-        self.eng._ck(L.tcr_gather_seeds_dev(h, C.byref(src), self.cand_idx.data_ptr(), n_take, C.byref(dst), st))
+        seed, year, cand0 = self._round
+        self.eng._ck(L.tcr_gather_seeds_dev(h, C.byref(src), self.cand_idx.data_ptr(), n_take, C.byref(dst),
+                                            C.c_uint64(seed), year, cand0, st))
         self.n_storms = n_take
 
     def load_storms(self, storms):
@@ -115,6 +119,12 @@ class DevicePipeline:
         self.eng._ck(self.eng.L.tcr_integrate_dev(self.eng.h, C.byref(si), C.byref(so),
                                                   C.c_void_p(self._stream())))
         self.n_done = n
+
+    def add_stats(self, counters):
+        """counters (uint64/int64 tensor [4]) += storm-steps, RHS evaluations, samples, accepted."""
+        so = self._tracks_struct()
+        self.eng._ck(self.eng.L.tcr_stats_dev(self.eng.h, self.n_done, C.byref(so), counters.data_ptr(),
+                                              C.c_void_p(self._stream())))
 
     def select_accepted(self):
         """Indices (dense-batch order == candidate order) of accepted tracks → self.acc_idx."""
