@@ -55,6 +55,7 @@ def main():
     rank, world, local = D.init_from_env()
     if world != args.gpus and rank == 0:
         print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world), file=sys.stderr)
+    local = D.local_device(local)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     year = 2000

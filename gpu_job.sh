@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-timeout 900 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('100k', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['config']['accepted_fraction'])"
-timeout 900 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --storms 10000 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('10k', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "two_grid" -s 2>&1 | grep -E "passed|failed|storms,|clean:|Error|assert" | head -30
+export TCR_DIST_BACKEND=gloo
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 3 --warmup 1 --storms 20000 2>&1 | tail -4

@@ -131,3 +131,24 @@ def test_empty_and_single(engines):
     assert out['status'][0] == 1 and out['n_valid'][0] == 1
     assert out['lon'][0, 0] == 310.0 and np.isnan(out['lon'][0, 1:]).all()
     assert np.isnan(out['vmax'][0]).all() and not out['accepted'][0]
+
+
+@pytest.mark.parametrize('shape,basin', [('gfdl', 'WP'), ('gaussian', 'EP'), ('gaussian', 'GL')])
+def test_two_grid_and_nonuniform_fields(built_lib, shape, basin):
+    """GFDL-shaped fields: wind grid (2 x 2.5 deg) differs from the thermo grid (1 x 1.25 deg)
+    (bam_track.py:82-83); 'gaussian' adds non-uniform latitudes, which takes the general
+    knot-search path of tcr_device.h (`locate_t<false>`) instead of the affine fast path."""
+    from oracle import c_oracle
+    from tropical_cyclone_risk_amd import synthetic
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    env = synthetic.make_env(shape, seed=7)
+    storms = synthetic.draw_storm_inputs(1500, basin, seed=91)
+    eng = TCEngine(basin, device=0).stage_env(env)
+    got = eng.integrate(storms)
+    eng.close()
+    ref = c_oracle.run_ensemble(env, basin, storms)
+    exposed = ref['flicker'] > 0
+    print('%s/%s: %d storms, %d exposed, %d samples' % (shape, basin, len(exposed), exposed.sum(), ref['n_valid'].sum()))
+    for key in ('n_accept', 'n_reject'):
+        assert np.array_equal(got[key][~exposed], ref[key][~exposed]), key
+    _check('%s-%s' % (shape, basin), got, ref, exposed)

@@ -33,11 +33,19 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # TCR_DIST_BACKEND=gloo lets several ranks share one GPU for functional tests
+            backend = os.environ.get('TCR_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def local_device(local):
+    """GPU index of this rank: LOCAL_RANK, folded onto the visible devices when ranks
+    deliberately share GPUs (functional tests on a 1-GPU box)."""
+    n = torch.cuda.device_count()
+    return int(local) % n if n else 0
 
 
 def world():

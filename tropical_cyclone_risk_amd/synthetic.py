@@ -136,11 +136,15 @@ def make_env(shape='era5', seed=20250614, wind_scale=0.7, zero_cov_patch=False):
         lon = np.arange(360, dtype=np.float64)
         lat = np.linspace(-90.0, 90.0, 181)
         wlon, wlat = lon.copy(), lat.copy()
-    elif shape == 'gfdl':
+    elif shape in ('gfdl', 'gaussian'):
         lon = np.arange(288, dtype=np.float64) * 1.25 + 0.625
         lat = np.linspace(-89.5, 89.5, 180)
         wlon = np.arange(144, dtype=np.float64) * 2.5 + 1.25
         wlat = np.linspace(-89.0, 89.0, 90)
+        if shape == 'gaussian':
+            # non-uniform latitudes (Gaussian-grid-like): exercises the general knot search
+            lat = lat + 0.2 * np.sin(np.deg2rad(lat) * 3.0)
+            wlat = wlat + 0.35 * np.sin(np.deg2rad(wlat) * 3.0)
     else:
         raise ValueError('unknown synthetic shape %r' % (shape,))
     hlat = np.linspace(-90.0, 90.0, 721)
