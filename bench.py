@@ -40,6 +40,9 @@ def main():
     ap.add_argument('--basin', default='GL')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sort', action='store_true', help='locality-sort the dense batch (see pipeline.py)')
+    ap.add_argument('--streams', type=int, default=4,
+                    help='HIP streams the steps are round-robined over (each with its own context and buffers): '
+                         'the low-occupancy tail of one batch overlaps the next batch')
     ap.add_argument('--cpu-budget', type=float, default=12.0)
     ap.add_argument('--traffic', type=float, default=None,
                     help='HBM bytes per integrate launch from a separate rocprofv3 --pmc pass (see profiles/)')
@@ -61,7 +64,10 @@ def main():
     year = 2000
 
     env = synthetic.make_env('era5')
-    eng = TCEngine(args.basin, device=local).stage_env(env)
+    n_str = max(1, args.streams)
+    engs = [TCEngine(args.basin, device=local).stage_env(env) for _ in range(n_str)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_str)]
+    eng = engs[0]
     B = args.storms
     ns = eng.n_steps
 
@@ -73,10 +79,11 @@ def main():
     p_pass = float(((probe.cand['seed_flags'] & 2) != 0).double().mean().item())
     del probe
     C = int(B / max(p_pass, 1e-3) * 1.15) + 4096
-    pipe = DevicePipeline(eng, C, B, sort_storms=args.sort)
+    pipes = [DevicePipeline(e, C, B, sort_storms=args.sort) for e in engs]
+    pipe = pipes[0]
 
     acc = torch.zeros(4, dtype=torch.int64, device=dev)       # storm-steps, nfev, samples, accepted (tcr_stats_dev)
-    short = torch.zeros(1, dtype=torch.int64, device=dev)     # rounds that had < B passing seeds
+    short = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(n_str)]   # rounds with < B passing seeds
     row = 9 * ns
     cap = B
     packed = [torch.empty(cap, row, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
@@ -84,13 +91,17 @@ def main():
     gathered_rows = 0
 
     def step(k):
+        with torch.cuda.stream(streams[k % n_str]):
+            _step(k, pipes[k % n_str])
+
+    def _step(k, pipe):
         # warm-up steps run exactly the same code; the accumulators are zeroed after them
         nonlocal gathered_rows
         pipe.seed_round(year, D.round_block(k, C, rank, world))
         pipe.select_passed(B)
         pipe.integrate(B)
         pipe.add_stats(acc)
-        short.add_((pipe.n_passed < B).long())
+        short[k % n_str].add_((pipe.n_passed < B).long())
         if world > 1:
             # all-gather of this batch's final (accepted) tracks, overlapped with the next
             # batch's compute: packing goes to a double buffer, RCCL runs on its own stream
@@ -113,27 +124,40 @@ def main():
                 gathered_rows += rows.shape[0]
                 pending[s] = None
 
-    eng.timing_enable(True)
-    for k in range(args.warmup):
+    for e in engs:
+        e.timing_enable(True)
+    w_eff = max(args.warmup, n_str)          # every stream runs the full step at least once untimed
+    for k in range(w_eff):
         step(k)
     drain()
-    acc.zero_(); short.zero_()
+    torch.cuda.synchronize()
+    acc.zero_()
+    for t in short:
+        t.zero_()
     D.barrier(); torch.cuda.synchronize()
-    eng.timing_enable(True)          # resets the event record: only the K timed steps count
+    for e in engs:
+        e.timing_enable(True)        # resets the event record: only the K timed steps count
     gathered_rows = 0
     t0 = time.perf_counter()
-    for k in range(args.warmup, args.warmup + args.steps):
+    for k in range(w_eff, w_eff + args.steps):
         step(k)
     drain()
     torch.cuda.synchronize(); D.barrier()
     dt = time.perf_counter() - t0
     dt = D.max_over_ranks(dt, dev)
 
-    ms = (eng.L and eng.timing_sum())
+    ms = dict(fourier_ms=0.0, integrate_ms=0.0, post_ms=0.0, calls=0)
+    for e in engs:
+        try:
+            m1 = e.timing_sum()
+        except Exception:
+            continue                 # a stream that saw no timed step
+        for kk in ms:
+            ms[kk] += m1[kk]
     if world > 1:
         D.allreduce_sum_(acc)
     steps_total, nfev_total, samples_total, accepted_total = (float(x) for x in acc.tolist())
-    n_short = int(short.item())
+    n_short = int(sum(int(t.item()) for t in short))
     value = steps_total / dt
 
     # ---- roofline of the dominant kernel (k_integrate): algorithmic bytes per launch
@@ -170,7 +194,7 @@ def main():
                                    '(1 deg thermo/wind, 0.25 deg land/bathymetry), 15-day tracks, hourly output, '
                                    'device-side seeding, fp64' % (args.basin, B),
                        'storms_per_gpu': B, 'candidates_per_round': C, 'seed_pass_rate': p_pass,
-                       'n_steps_out': ns, 'rounds_short_of_storms': n_short,
+                       'n_steps_out': ns, 'rounds_short_of_storms': n_short, 'streams': n_str, 'warmup_effective': w_eff,
                        'storm_steps_per_storm': steps_total / (B * args.steps * world),
                        'rhs_per_storm_step': nfev_total / max(steps_total, 1),
                        'accepted_fraction': accepted_total / (B * args.steps * world),

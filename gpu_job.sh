@@ -1,4 +1,7 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "two_grid" -s 2>&1 | grep -E "passed|failed|storms,|clean:|Error|assert" | head -30
-export TCR_DIST_BACKEND=gloo
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 3 --warmup 1 --storms 20000 2>&1 | tail -4
+for st in 4 6 8; do
+timeout 900 python bench.py --steps 24 --warmup 3 --no-cpu-baseline --streams $st 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('streams $st 100k', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"
+done
+for st in 4 8; do
+timeout 900 python bench.py --steps 24 --warmup 3 --no-cpu-baseline --storms 10000 --streams $st 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('streams $st 10k', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"
+done
