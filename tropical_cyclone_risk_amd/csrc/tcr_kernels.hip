@@ -97,8 +97,10 @@ __global__ __launch_bounds__(kFsThreads) void k_fourier_periodic(tcr_params P, i
     const int64_t storm = blockIdx.x;
     for (int j = threadIdx.x; j < period; j += kFsThreads) tab[j] = sc_table[j];
     if (threadIdx.x < 4 * N) {
+        // amplitude-weighted phase factors: n^-1.5 * (sin, cos)(2π x)
         const double x = phases[storm * 4 * N + threadIdx.x];
-        ph[threadIdx.x] = make_double2(sinpi(2.0 * x), cospi(2.0 * x));
+        const double wgt = P.fs_wgt[threadIdx.x % N];
+        ph[threadIdx.x] = make_double2(wgt * sinpi(2.0 * x), wgt * cospi(2.0 * x));
     }
     __syncthreads();
     double *out = fs + storm * ns * 4;
@@ -111,12 +113,10 @@ __global__ __launch_bounds__(kFsThreads) void k_fourier_periodic(tcr_params P, i
         for (int h = 0; h < N; ++h) {            // (fully unrolling this loop was measured 2x slower)
             j += kk; if (j >= period) j -= period;
             const double2 a = tab[j];
-            const double wgt = P.fs_wgt[h];
             const double2 b0 = ph[h], b1 = ph[N + h], b2 = ph[2 * N + h], b3 = ph[3 * N + h];
-            const double t0 = wgt * (a.x * b0.y + a.y * b0.x), t1 = wgt * (a.x * b1.y + a.y * b1.x);
-            const double t2 = wgt * (a.x * b2.y + a.y * b2.x), t3 = wgt * (a.x * b3.y + a.y * b3.x);
-            acc0 = (h == 0) ? t0 : acc0 + t0; acc1 = (h == 0) ? t1 : acc1 + t1;
-            acc2 = (h == 0) ? t2 : acc2 + t2; acc3 = (h == 0) ? t3 : acc3 + t3;
+            // sin(A + B) = sinA cosB + cosA sinB, accumulated with explicit FMAs (2 per term)
+            acc0 = fma(a.x, b0.y, fma(a.y, b0.x, acc0)); acc1 = fma(a.x, b1.y, fma(a.y, b1.x, acc1));
+            acc2 = fma(a.x, b2.y, fma(a.y, b2.x, acc2)); acc3 = fma(a.x, b3.y, fma(a.y, b3.x, acc3));
         }
         double2 *o = reinterpret_cast<double2 *>(out + (size_t)k * 4);
         o[0] = make_double2(P.fs_amp * acc0, P.fs_amp * acc1);
