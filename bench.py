@@ -146,14 +146,32 @@ def main():
     dt = time.perf_counter() - t0
     dt = D.max_over_ranks(dt, dev)
 
-    ms = dict(fourier_ms=0.0, integrate_ms=0.0, post_ms=0.0, calls=0)
-    for e in engs:
-        try:
-            m1 = e.timing_sum()
-        except Exception:
-            continue                 # a stream that saw no timed step
-        for kk in ms:
-            ms[kk] += m1[kk]
+    def sum_timings():
+        tot = dict(fourier_ms=0.0, integrate_ms=0.0, post_ms=0.0, calls=0)
+        for e in engs:
+            try:
+                m1 = e.timing_sum()
+            except Exception:
+                continue             # a stream that saw no timed step
+            for kk in tot:
+                tot[kk] += m1[kk]
+        return tot
+    ms = sum_timings()
+    # The same kernels once more, one launch at a time on one stream (after the timed region, not
+    # part of `value`): with several streams the event-bracketed duration of a launch includes the
+    # time it shared the GPU with other batches, so the per-kernel roofline is quoted both ways.
+    iso = None
+    if n_str > 1:
+        acc_keep = acc.clone()
+        for e in engs:
+            e.timing_enable(True)
+        for k in range(w_eff + args.steps, w_eff + args.steps + 3):
+            with torch.cuda.stream(streams[0]):
+                _step(k, pipes[0])
+            torch.cuda.synchronize()
+        iso = sum_timings()
+        iso_counts = (acc - acc_keep).tolist()
+        acc.copy_(acc_keep)
     if world > 1:
         D.allreduce_sum_(acc)
     steps_total, nfev_total, samples_total, accepted_total = (float(x) for x in acc.tolist())
@@ -179,6 +197,14 @@ def main():
                           frac=emit_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           algorithmic_bytes_per_launch=emit_bytes, launch_ms=e_ms,
                           traffic=measured_traffic('tcr::k_emit<true>', B)))
+    if iso and iso['calls']:
+        ik, ie = iso['integrate_ms'] / iso['calls'], iso['post_ms'] / iso['calls']
+        ib = BYTES_PER_RHS * iso_counts[1] / iso['calls']
+        eb = BYTES_PER_SAMPLE * iso_counts[2] / iso['calls']
+        roof['isolated'] = dict(note='same kernels, one batch at a time on one stream, after the timed region',
+                                kernel_ms=dict(fourier=iso['fourier_ms'] / iso['calls'], integrate=ik, emit=ie),
+                                achieved=ib / (ik * 1e-3) / 1e9, frac=ib / (ik * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                emit_achieved=eb / (ie * 1e-3) / 1e9, emit_frac=eb / (ie * 1e-3) / 1e9 / HBM_PEAK_GBS)
 
     out = None
     if rank == 0:
