@@ -171,12 +171,13 @@ int tcr_seed_host(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t 
  * order, first max_out of them -> idx; *count = how many matched (device scalar). */
 int tcr_compact_dev(tcr_ctx *ctx, int64_t n, const int32_t *flags_dev, int32_t mask, int64_t max_out,
                     int32_t *idx_dev, int64_t *count_dev, void *stream);
-/* dense storm batch dst[r] = src[idx[r]], r < n_out.  If src_dev->phases is NULL (tcr_seed_dev was
+/* dense storm batch dst[r] = src[idx[r]], r < min(n_out, *count_dev) (count_dev, the device scalar
+ * written by tcr_compact_dev, may be NULL = all n_out rows are valid).  If src_dev->phases is NULL (tcr_seed_dev was
  * asked not to write them: most candidates never pass) the 4*n_series Fourier phases of the selected
  * candidates are drawn here from the same Philox stream (candidate = cand0 + idx[r]). */
 int tcr_gather_seeds_dev(tcr_ctx *ctx, const tcr_seeds *src_dev, const int32_t *idx_dev, int64_t n_out,
-                         const tcr_seeds *dst_dev, uint64_t experiment_seed, int32_t year, int64_t cand0,
-                         void *stream);
+                         const int64_t *count_dev, const tcr_seeds *dst_dev, uint64_t experiment_seed,
+                         int32_t year, int64_t cand0, void *stream);
 /* sums over a finished batch, for throughput accounting and round control: out_dev[0] = storm-steps
  * (sum of max(n_valid-1, 0)), [1] = RHS evaluations, [2] = output samples, [3] = accepted tracks;
  * the four uint64 counters are ADDED to (zero them first). */

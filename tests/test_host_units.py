@@ -70,3 +70,34 @@ def test_namelist_overlay(tmp_path):
         assert namelist.tracks_per_year == 123 and namelist.exp_name == 'x'
     finally:
         namelist.tracks_per_year, namelist.exp_name = old
+
+
+def test_track_file_schema_roundtrip(tmp_path):
+    """Output file: the reference's variables / dimensions (compute.py:250-264, README "Model
+    Output"), duplicate-name suffixing (compute.py:52-58), round trip through the NetCDF writer."""
+    import types
+    from tropical_cyclone_risk_amd import io as tio, namelist
+    from tropical_cyclone_risk_amd.basins import TC_Basin
+    nl = types.SimpleNamespace(**{k: getattr(namelist, k) for k in dir(namelist) if not k.startswith('__')})
+    nl.output_directory = str(tmp_path); nl.exp_name = 'unit'; nl.start_year, nl.end_year = 2001, 2002
+    rng = np.random.default_rng(0)
+    ns = 361
+
+    def fake_year(n):
+        lon = rng.random((n, ns)); lon[:, 200:] = np.nan
+        return (lon, lon + 1, lon + 2, lon + 3, lon + 4, rng.random((n, ns, 4)), rng.integers(1, 13, n).astype(float),
+                np.array(['NA', 'EP'] * (n // 2), dtype='U2'), rng.integers(0, 9, (7, 12)).astype(float))
+    out = [fake_year(4), fake_year(6)]
+    fn = tio.write_tracks(out, [2001, 2002], TC_Basin('NA'), nl)
+    assert os.path.basename(fn) == 'tracks_NA_era5_200101_200212.nc'
+    fn2 = tio.write_tracks(out, [2001, 2002], TC_Basin('NA'), nl)
+    assert fn2.endswith('_e0.nc')
+    d = tio.read_tracks(fn)
+    for k in ('lon_trks', 'lat_trks', 'u250_trks', 'v250_trks', 'u850_trks', 'v850_trks', 'v_trks', 'm_trks',
+              'vmax_trks', 'tc_month', 'tc_basins', 'tc_years', 'seeds_per_month', 'time', 'year', 'basin', 'month'):
+        assert k in d, k
+    assert d['lon_trks'].shape == (10, ns) and d['seeds_per_month'].shape == (2, 7, 12)
+    assert np.array_equal(d['lon_trks'], np.concatenate([out[0][0], out[1][0]]), equal_nan=True)
+    assert np.array_equal(d['u850_trks'], np.concatenate([out[0][5][:, :, 2], out[1][5][:, :, 2]]))
+    assert list(d['tc_basins'][:2]) == ['NA', 'EP'] and list(d['basin']) == ['AU', 'EP', 'NA', 'NI', 'SI', 'SP', 'WP']
+    assert list(d['tc_years']) == [2001] * 4 + [2002] * 6 and d['time'][1] == 3600.0

@@ -81,3 +81,19 @@ def test_run_tracks_end_to_end(golden_env, built_lib):
     n_valid = (~np.isnan(lon)).sum(axis=1)
     for i in range(40):
         assert np.isnan(lon[i, n_valid[i]:]).all() and np.isnan(vmax[i, n_valid[i]:]).all()
+
+
+@pytest.mark.gpu
+def test_run_downscaling_writes_reference_schema(golden_env, built_lib, tmp_path):
+    """run_downscaling (compute.py:216-270): years loop + concatenation + track file."""
+    import types
+    from tropical_cyclone_risk_amd import compute, io as tio, namelist
+    nl = types.SimpleNamespace(**{k: getattr(namelist, k) for k in dir(namelist) if not k.startswith('__')})
+    nl.output_directory = str(tmp_path); nl.exp_name = 'gpu'; nl.start_year, nl.end_year = 2010, 2011
+    nl.tracks_per_year = 6; nl.gpu_candidate_round = 4096
+    fn = compute.run_downscaling('NA', env=golden_env, nl=nl)
+    d = tio.read_tracks(fn)
+    assert d['lon_trks'].shape == (12, 361) and d['seeds_per_month'].shape == (2, 7, 12)
+    assert list(d['tc_years']) == [2010] * 6 + [2011] * 6
+    assert (np.nanmax(d['vmax_trks'], axis=1) >= 18).all()
+    assert not np.array_equal(d['lon_trks'][:6], d['lon_trks'][6:], equal_nan=True)   # years differ

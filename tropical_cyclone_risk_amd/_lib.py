@@ -77,6 +77,32 @@ class TcrError(RuntimeError):
 _lib = None
 
 
+def _pin_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64;
+    libtcrisk_hip.so is linked against the system ROCm.  If this library initialised the system
+    runtime first and torch then brought up its bundled one, the second bring-up fails ("No HIP GPUs
+    are available").  Both have the same SONAME, so loading torch's copies first (when torch is
+    installed but not imported yet) makes the dynamic loader resolve our dependency to them too."""
+    import importlib.util
+    import sys
+    if 'torch' in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except Exception:
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), 'lib')
+    for name in ('libhsa-runtime64.so', 'libamdhip64.so'):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def lib():
     """Load the shared library (once).  Fails loudly if it has not been built."""
     global _lib
@@ -87,6 +113,7 @@ def lib():
             'libtcrisk_hip.so not found at %s — build it with '
             '`python -c "import __graft_entry__ as g; g.build()"` or '
             '`python -m tropical_cyclone_risk_amd.build`; there is no CPU fallback.' % LIB_PATH)
+    _pin_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.tcr_abi_version.restype = C.c_int
     L.tcr_last_error.restype = C.c_char_p
@@ -112,7 +139,7 @@ def lib():
     L.tcr_timing_sum.argtypes = [C.c_void_p, DP, C.POINTER(C.c_int64)]
     L.tcr_compact_dev.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64,
                                   C.c_void_p, C.c_void_p, C.c_void_p]
-    L.tcr_gather_seeds_dev.argtypes = [C.c_void_p, C.POINTER(Seeds), C.c_void_p, C.c_int64,
+    L.tcr_gather_seeds_dev.argtypes = [C.c_void_p, C.POINTER(Seeds), C.c_void_p, C.c_int64, C.c_void_p,
                                        C.POINTER(Seeds), C.c_uint64, C.c_int32, C.c_int64, C.c_void_p]
     L.tcr_stats_dev.argtypes = [C.c_void_p, C.c_int64, C.POINTER(Tracks), C.c_void_p, C.c_void_p]
     L.tcr_pack_tracks_dev.argtypes = [C.c_void_p, C.POINTER(Tracks), C.c_void_p, C.c_void_p,

@@ -697,7 +697,8 @@ int tcr_compact_dev(tcr_ctx *ctx, int64_t n, const int32_t *flags, int32_t mask,
 }
 
 int tcr_gather_seeds_dev(tcr_ctx *ctx, const tcr_seeds *src, const int32_t *idx, int64_t n_out,
-                         const tcr_seeds *dst, uint64_t experiment_seed, int32_t year, int64_t cand0, void *stream_)
+                         const int64_t *count, const tcr_seeds *dst, uint64_t experiment_seed, int32_t year,
+                         int64_t cand0, void *stream_)
 {
     if (!ctx) return -1;
     if (!ctx->have_prm) return fail(ctx, "tcr_params_set has not been called");
@@ -707,7 +708,7 @@ int tcr_gather_seeds_dev(tcr_ctx *ctx, const tcr_seeds *src, const int32_t *idx,
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
     GatherSeedArgs a{};
     a.src = *src; a.dst = *dst; a.idx = idx; a.n_out = n_out; a.phases_per_storm = 4 * ctx->prm.n_series;
-    a.seed = experiment_seed; a.year = year; a.cand0 = cand0;
+    a.seed = experiment_seed; a.year = year; a.cand0 = cand0; a.count = count;
     const int64_t threads = n_out * 64;
     hipLaunchKernelGGL(k_gather_seeds, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
     HIPCHK(ctx, hipGetLastError());

@@ -99,6 +99,7 @@ struct GatherSeedArgs {
     uint64_t seed;
     int32_t year;
     int64_t cand0;
+    const int64_t *count;       // device scalar from tcr_compact_dev: rows >= *count are not valid (NULL: all are)
 };
 
 __global__ __launch_bounds__(256) void k_gather_seeds(GatherSeedArgs a)
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void k_gather_seeds(GatherSeedArgs a)
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t row = gid / 64;           // one wave per output row: lanes copy the phases
     const int lane = (int)(gid & 63);
-    if (row >= a.n_out) return;
+    if (row >= a.n_out || (a.count && row >= *a.count)) return;
     const int32_t j = a.idx[row];
     if (lane == 0) {
         a.dst.lon0[row] = a.src.lon0[j]; a.dst.lat0[row] = a.src.lat0[j];

@@ -4,8 +4,10 @@ Output schema = the reference's (`util/compute.py:250-264`, README "Model Output
 ``lon_trks, lat_trks, u250_trks, v250_trks, u850_trks, v850_trks, v_trks, m_trks,
 vmax_trks [n_trk, time]``, ``tc_month, tc_basins, tc_years [n_trk]``,
 ``seeds_per_month [year, basin, month]`` with coords ``n_trk, time, year, basin, month``.
-NetCDF through xarray when it is installed; otherwise a ``.npz`` with the same
-variable names (neither build nor bench container has xarray / netCDF4).
+NetCDF-4 through xarray when it is installed (as the reference writes it); otherwise
+NetCDF-3 classic through ``scipy.io.netcdf_file`` — same variables, dimensions and
+coordinates, readable by ``xarray.open_dataset`` (neither the build nor the bench container
+has xarray / netCDF4 / h5py; SciPy is part of the image).
 """
 import os
 
@@ -55,19 +57,67 @@ def assemble(out, years, nl):
     return data, coords
 
 
+TWO_D = ['lon_trks', 'lat_trks', 'u250_trks', 'v250_trks', 'u850_trks', 'v850_trks', 'v_trks', 'm_trks', 'vmax_trks']
+
+
+def _write_netcdf3(fn, data, coords):
+    """The reference's Dataset (compute.py:250-264) in NetCDF-3 classic.  Strings (tc_basins,
+    basin) become fixed-width char arrays with a trailing `string2` dimension, which is how
+    xarray itself encodes them in this format."""
+    from scipy.io import netcdf_file
+    with netcdf_file(fn, 'w', version=2) as f:
+        for dim in ('n_trk', 'time', 'year', 'basin', 'month'):
+            f.createDimension(dim, len(coords[dim]))
+        f.createDimension('string2', 2)
+
+        def put(name, arr, dims, dtype=None):
+            arr = np.asarray(arr)
+            v = f.createVariable(name, dtype or arr.dtype.char, dims)
+            v[:] = arr
+            return v
+        put('n_trk', coords['n_trk'].astype(np.int32), ('n_trk',))
+        put('time', coords['time'].astype(np.float64), ('time',))
+        put('year', coords['year'].astype(np.int32), ('year',))
+        put('month', coords['month'].astype(np.int32), ('month',))
+        chars = lambda a: np.array([list(str(x).ljust(2)[:2]) for x in a], dtype='S1').reshape(len(a), 2)
+        put('basin', chars(coords['basin']), ('basin', 'string2'), 'c')
+        for k in TWO_D:
+            put(k, data[k].astype(np.float64), ('n_trk', 'time'))
+        put('tc_month', data['tc_month'].astype(np.float64), ('n_trk',))
+        put('tc_years', data['tc_years'].astype(np.int32), ('n_trk',))
+        put('tc_basins', chars(data['tc_basins']), ('n_trk', 'string2'), 'c')
+        put('seeds_per_month', data['seeds_per_month'].astype(np.float64), ('year', 'basin', 'month'))
+
+
+def read_tracks(fn):
+    """Read a track file written by write_tracks (either flavour) into plain NumPy arrays."""
+    xr = _try_xarray()
+    if xr is not None:
+        ds = xr.open_dataset(fn)
+        return {k: np.asarray(ds[k]) for k in list(ds.data_vars) + list(ds.coords)}
+    from scipy.io import netcdf_file
+    out = {}
+    with netcdf_file(fn, 'r', mmap=False) as f:
+        for k, v in f.variables.items():
+            a = np.array(v[:])
+            if a.dtype.kind == 'S' and a.ndim == 2:
+                a = np.array([b''.join(r).decode().strip() for r in a])
+            out[k] = a
+    return out
+
+
 def write_tracks(out, years, b, nl, out_dir=None):
     data, coords = assemble(out, years, nl)
     xr = _try_xarray()
-    fn = fn_tracks_duplicates(get_fn_tracks(b, nl, out_dir, 'nc' if xr is not None else 'npz'))
+    fn = fn_tracks_duplicates(get_fn_tracks(b, nl, out_dir, 'nc'))
     os.makedirs(os.path.dirname(fn), exist_ok=True)
     if xr is not None:
-        two = ['lon_trks', 'lat_trks', 'u250_trks', 'v250_trks', 'u850_trks', 'v850_trks', 'v_trks', 'm_trks', 'vmax_trks']
-        dv = {k: (['n_trk', 'time'], data[k]) for k in two}
+        dv = {k: (['n_trk', 'time'], data[k]) for k in TWO_D}
         dv.update({k: (['n_trk'], data[k]) for k in ('tc_month', 'tc_basins', 'tc_years')})
         dv['seeds_per_month'] = (['year', 'basin', 'month'], data['seeds_per_month'])
         xr.Dataset(data_vars=dv, coords={k: list(v) if k in ('basin',) else v for k, v in coords.items()}).to_netcdf(fn, mode='w')
     else:
-        np.savez_compressed(fn, **data, **{'coord_' + k: v for k, v in coords.items()})
+        _write_netcdf3(fn, data, coords)
     return fn
 
 

@@ -92,8 +92,8 @@ class DevicePipeline:
             self.cand_idx[:n_take] = self.cand_idx[:n_take][torch.argsort(key)]
         src, dst = self._seeds_struct(self.cand, self.n_cand), self._seeds_struct(self.storms, n_take)
         seed, year, cand0 = self._round
-        self.eng._ck(L.tcr_gather_seeds_dev(h, C.byref(src), self.cand_idx.data_ptr(), n_take, C.byref(dst),
-                                            C.c_uint64(seed), year, cand0, st))
+        self.eng._ck(L.tcr_gather_seeds_dev(h, C.byref(src), self.cand_idx.data_ptr(), n_take,
+                                            self.n_passed.data_ptr(), C.byref(dst), C.c_uint64(seed), year, cand0, st))
         self.n_storms = n_take
 
     def load_storms(self, storms):
