@@ -185,3 +185,61 @@ def test_other_output_grids(golden_env, built_lib, dt_out, days, T_days):
         assert np.abs(Fs[i] - c_oracle.fourier_table(storms['phases'][i], prm)).max() < 5e-14
     exposed = ref['flicker'] > 0
     _check('dt%d-%dd' % (dt_out, days), got, ref, exposed)
+
+
+def test_full_size_ensemble_properties(golden_env, built_lib):
+    """BASELINE's full size (100 000 storms, GL, device-seeded) through size-independent properties:
+      * launch-shape invariance: the same batch integrated with a different number of persistent
+        waves (different storm-to-lane assignment and queue order) is bitwise identical;
+      * batch-composition invariance: a storm integrated inside the 100k batch equals the same
+        storm integrated in a small batch, bitwise;
+      * structure: NaN padding exactly beyond n_valid, accepted => is_tc, sample 0 == the seed;
+      * a random 1 500-storm subsample agrees with the C oracle within the stated tolerance."""
+    import torch
+    from oracle import c_oracle
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    from tropical_cyclone_risk_amd.pipeline import DevicePipeline
+    B = 100_000
+    eng = TCEngine('GL', device=0).stage_env(golden_env)
+    pipe = DevicePipeline(eng, 560_000, B)
+    pipe.seed_round(2005, 0)
+    pipe.select_passed(B)
+    assert int(pipe.n_passed.item()) >= B
+    pipe.integrate(B)
+    a = pipe.host_tracks()
+    os.environ['TCR_WAVES'] = '700'
+    try:
+        pipe.integrate(B)
+        b = pipe.host_tracks()
+    finally:
+        del os.environ['TCR_WAVES']
+    for k in ('lon', 'lat', 'v', 'm', 'vmax', 'envw'):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    for k in ('n_valid', 'status', 'flags', 'nfev', 'n_accept', 'n_reject'):
+        assert np.array_equal(a[k], b[k]), k
+    # structure
+    ns = eng.n_steps
+    idx = np.arange(ns)[None, :]
+    valid = idx < a['n_valid'][:, None]
+    for k in ('lon', 'lat', 'v', 'm'):
+        assert np.array_equal(np.isnan(a[k]), ~valid), k
+    assert np.array_equal(np.isnan(a['envw'][:, :, 0]), ~valid)
+    assert not (a['accepted'] & ~a['is_tc']).any()
+    seeds = {k: pipe.storms[k][:B].cpu().numpy() for k in ('lon0', 'lat0', 'v0', 'm0', 'h_bl', 'slot')}
+    alive = a['n_valid'] > 0
+    assert np.array_equal(a['lon'][alive, 0], seeds['lon0'][alive]) and np.array_equal(a['v'][alive, 0], seeds['v0'][alive])
+    # subsample: small-batch bitwise equality + oracle tolerance
+    rng = np.random.default_rng(3)
+    sub = np.sort(rng.choice(B, 1500, replace=False))
+    storms = dict(lon=seeds['lon0'][sub], lat=seeds['lat0'][sub], v0=seeds['v0'][sub], m0=seeds['m0'][sub],
+                  h_bl=seeds['h_bl'][sub], month=seeds['slot'][sub] + 1,
+                  phases=pipe.storms['phases'][:B].cpu().numpy()[sub].reshape(len(sub), 4, -1))
+    small = eng.integrate(storms)
+    for k in ('lon', 'lat', 'v', 'm', 'vmax', 'envw'):
+        assert np.array_equal(small[k], a[k][sub], equal_nan=True), k
+    eng.close()
+    ref = c_oracle.run_ensemble(golden_env, 'GL', storms)
+    exposed = ref['flicker'] > 0
+    print('full size: %d storm-steps, %.1f %% accepted, %d of 1500 sampled storms flicker-exposed'
+          % (np.clip(a['n_valid'] - 1, 0, None).sum(), 100 * a['accepted'].mean(), exposed.sum()))
+    _check('full-size-sample', small, ref, exposed)
