@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TCR_ABI_VERSION 1
+#define TCR_ABI_VERSION 2
 #define TCR_NW 4            /* ua250, va250, ua850, va850  (track/env_wind.py:22-26) */
 #define TCR_NCOV 10         /* packed lower triangle (0,0),(1,0),(1,1),(2,0)..(3,3) (env_wind.py:31-42) */
 #define TCR_MAX_SERIES 32
@@ -106,6 +106,13 @@ typedef struct {
     int32_t *flags;                         /* TCR_FLAG_* */
     int32_t *nfev;                          /* RHS evaluations (res.nfev) */
     int32_t *n_accept, *n_reject;           /* accepted steps / rejected attempts */
+    /* Optional (may be NULL), [n]: padding state of the plane rows.  The NaN padding is 2/3 of
+     * the plane bytes; a caller that reuses the same plane buffers batch after batch passes this
+     * array with them, initialised to -1 ("unknown").  On entry pad_state[r] = k >= 0 promises
+     * that row r of every plane is already NaN from sample k on, so only [n_valid, k) needs
+     * re-padding; on return pad_state[r] = n_valid[r].  The planes come out bit-identical to a
+     * full padding.  NULL or -1: the whole tail is written. */
+    int32_t *pad_state;
 } tcr_tracks;
 
 /* ---- lifecycle ----------------------------------------------------------- */
@@ -208,6 +215,13 @@ int tcr_timing_enable(tcr_ctx *ctx, int on);
 int tcr_timing_last(tcr_ctx *ctx, double ms[3]);
 /* sums over every timed call since tcr_timing_enable(ctx, 1); *n_calls = how many */
 int tcr_timing_sum(tcr_ctx *ctx, double ms[3], int64_t *n_calls);
+/* Occupancy accounting of the last tcr_integrate_* call (synchronises the device first is the
+ * caller's job): k_integrate runs as a chain of passes (tail compaction); for each pass p
+ * out[5p..5p+4] = { queue requests, storms parked for pass p+1, wave cycles, live-lane cycles,
+ * wave wall-clock ticks at 100 MHz }.  One cycle = one RK45 step attempt (six evaluations of
+ * the reference's ode_rhs, intensity/coupled_fast.py:150-209) of up to 64 storms; live-lane
+ * cycles / (64 x wave cycles) is the lane utilisation.  Returns the number of passes. */
+int tcr_integrate_pass_stats(tcr_ctx *ctx, int64_t *out, int max_passes);
 int tcr_sync(tcr_ctx *ctx, void *stream);
 
 #ifdef __cplusplus

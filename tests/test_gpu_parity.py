@@ -243,3 +243,30 @@ def test_full_size_ensemble_properties(golden_env, built_lib):
     print('full size: %d storm-steps, %.1f %% accepted, %d of 1500 sampled storms flicker-exposed'
           % (np.clip(a['n_valid'] - 1, 0, None).sum(), 100 * a['accepted'].mean(), exposed.sum()))
     _check('full-size-sample', small, ref, exposed)
+
+
+def test_pad_state_reuse_is_bit_identical(golden_env, built_lib):
+    """tcr_tracks.pad_state (tcrisk_hip.h): re-using the plane buffers batch after batch, with only the
+    stale part of each row re-padded, must give the planes a full NaN padding gives, bit for bit."""
+    import torch
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    from tropical_cyclone_risk_amd.pipeline import DevicePipeline
+    B = 4000
+    eng = TCEngine('GL', device=0).stage_env(golden_env)
+    reused = DevicePipeline(eng, 40_000, B)
+    assert int(reused.tracks['pad_state'].min().item()) == -1
+    keys = ('lon', 'lat', 'v', 'm', 'vmax', 'envw')
+    for year in (2001, 2002, 2003):
+        reused.seed_round(year, 0); reused.select_passed(B); reused.integrate(B)
+        got = reused.host_tracks()
+        assert torch.equal(reused.tracks['pad_state'][:B].cpu(), torch.as_tensor(got['n_valid']))
+        fresh = DevicePipeline(eng, 40_000, B)
+        for k in keys:                       # poison: a fresh buffer holds garbage, not NaN
+            fresh.tracks[k].fill_(123.0)
+        fresh.seed_round(year, 0); fresh.select_passed(B); fresh.integrate(B)
+        ref = fresh.host_tracks()
+        for k in keys:
+            assert np.array_equal(got[k], ref[k], equal_nan=True), (year, k)
+        assert np.array_equal(got['flags'], ref['flags'])
+        del fresh
+    eng.close()

@@ -15,7 +15,7 @@ CSRC = os.path.join(PKG, 'csrc')
 OUT = os.path.join(PKG, 'libtcrisk_hip.so')
 SOURCES = ['tcr_abi.hip', 'tcr_kernels.hip', 'tcr_seed.hip', 'tcr_device.h',
            os.path.join('..', '..', 'include', 'tcrisk_hip.h')]
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-DTCR_OPAQUE_K', '-fPIC', '-shared']
 
 
 def hipcc():

@@ -69,7 +69,11 @@ struct tcr_ctx {
     size_t fs_cap = 0, srec_cap = 0;
     int32_t *d_tiles = nullptr;
     size_t tiles_cap = 0;
-    unsigned long long *d_queue = nullptr;      // storm queue head of k_integrate
+    unsigned long long *d_queue = nullptr;      // work-queue heads and parked-storm counts of k_integrate's passes
+    uint16_t *d_sidx = nullptr;                 // sample -> accepted-step map (k_dense -> k_emit)
+    size_t sidx_cap = 0;
+    double *d_park[2] = {nullptr, nullptr};     // ping-pong lists of parked storms
+    size_t park_cap[2] = {0, 0};
     double2 *d_sc_table = nullptr;              // one period of (sin, cos)(2π j / period)
     int fs_period = 0;                          // 0: direct Fourier kernel
     int cu_count = 256;
@@ -244,6 +248,23 @@ unsigned integrate_waves(const tcr_ctx *ctx, int64_t n)
     return (unsigned)(waves < 1 ? 1 : waves);
 }
 
+// Tail compaction of k_integrate: a wave parks its storms once fewer than this many lanes are
+// live and the queue is empty (TCR_PARK=0 disables the chain: one launch runs every storm to its end).
+constexpr size_t kQueueWords = 5 * kMaxPasses;     // heads, parked counts, 3 occupancy counters per pass
+unsigned park_final_waves()               // a pass this small runs to the end
+{
+    if (const char *e = getenv("TCR_PARK_FINAL")) { const long v = atol(e); if (v > 0) return (unsigned)v; }
+    return 8;
+}
+int park_threshold()
+{
+    if (const char *e = getenv("TCR_PARK")) {
+        const long v = atol(e);
+        return v <= 0 ? 0 : (v > 63 ? 63 : (int)v);
+    }
+    return 32;
+}
+
 struct DevBuf {
     std::vector<void *> ptrs;
     ~DevBuf() { for (void *p : ptrs) (void)hipFree(p); }
@@ -290,7 +311,7 @@ int tcr_ctx_create(int device, tcr_ctx **out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->cu_count = prop.multiProcessorCount;
-    if (hipMalloc(reinterpret_cast<void **>(&ctx->d_queue), 256) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void **>(&ctx->d_queue), kQueueWords * sizeof(unsigned long long)) != hipSuccess) {
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return fail(nullptr, "tcr_ctx_create: hipMalloc failed");
@@ -311,7 +332,7 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_run_mask); (void)hipFree(ctx->d_basin_masks);
     (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_srec);
     for (auto &ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
-    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sc_table);
+    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -480,6 +501,25 @@ int tcr_timing_last(tcr_ctx *ctx, double ms[3])
     return 0;
 }
 
+int tcr_integrate_pass_stats(tcr_ctx *ctx, int64_t *out, int max_passes)
+{
+    if (!ctx || !out) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    unsigned long long h[kQueueWords];
+    HIPCHK(ctx, hipMemcpy(h, ctx->d_queue, sizeof(h), hipMemcpyDeviceToHost));
+    int np = 0;
+    for (int p = 0; p < kMaxPasses && p < max_passes; ++p) {
+        if (h[2 * kMaxPasses + 3 * p] == 0 && h[p] == 0) break;
+        out[5 * p + 0] = (int64_t)h[p];                               // items requested from the queue (>= items)
+        out[5 * p + 1] = (int64_t)h[kMaxPasses + p];                  // storms parked for the next pass
+        out[5 * p + 2] = (int64_t)h[2 * kMaxPasses + 3 * p + 0];      // wave cycles
+        out[5 * p + 3] = (int64_t)h[2 * kMaxPasses + 3 * p + 1];      // live-lane cycles
+        out[5 * p + 4] = (int64_t)h[2 * kMaxPasses + 3 * p + 2];      // wave wall-clock ticks (100 MHz)
+        ++np;
+    }
+    return np;
+}
+
 int tcr_sync(tcr_ctx *ctx, void *stream)
 {
     if (!ctx) return -1;
@@ -501,6 +541,12 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
     if (grow(ctx, &ctx->d_fs, &ctx->fs_cap, (size_t)n * ns * 4)) return -1;
     const int max_rk = P.max_rk_steps > 0 ? P.max_rk_steps : 64;
     if (grow(ctx, &ctx->d_srec, &ctx->srec_cap, (size_t)n * max_rk * kStepRec)) return -1;
+    if (max_rk > 65535) return fail(ctx, "tcr_params.max_rk_steps must be <= 65535");
+    {
+        double *p = reinterpret_cast<double *>(ctx->d_sidx);        // [n][n_steps] uint16: step of each sample
+        if (grow(ctx, &p, &ctx->sidx_cap, ((size_t)n * ns * sizeof(uint16_t) + 7) / 8)) { ctx->d_sidx = nullptr; return -1; }
+        ctx->d_sidx = reinterpret_cast<uint16_t *>(p);
+    }
 
     hipEvent_t *ev = nullptr;
     if (ctx->timing && timing_events(ctx, &ev)) return -1;
@@ -515,9 +561,25 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
         a.n_valid = out->n_valid; a.status = out->status; a.nfev = out->nfev;
         a.n_accept = out->n_accept; a.n_reject = out->n_reject;
         a.queue = ctx->d_queue;
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), st));
-        if (a.D.all_affine) hipLaunchKernelGGL(k_integrate<true>, dim3(integrate_waves(ctx, n)), dim3(kWave), 0, st, a);
-        else hipLaunchKernelGGL(k_integrate<false>, dim3(integrate_waves(ctx, n)), dim3(kWave), 0, st, a);
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, kQueueWords * sizeof(unsigned long long), st));
+        // Chain of launches with tail compaction (k_integrate): a pass parks the storms of waves that
+        // fall under `thr` live lanes, the next pass needs at most waves*(thr-1)/64 waves for them.
+        unsigned waves = integrate_waves(ctx, n);
+        const int thr = park_threshold();
+        const unsigned final_waves = park_final_waves();
+        if (thr > 0 && grow(ctx, &ctx->d_park[0], &ctx->park_cap[0], (size_t)waves * kWave * kParkRec)) return -1;
+        if (thr > 0 && grow(ctx, &ctx->d_park[1], &ctx->park_cap[1], (size_t)waves * kWave * kParkRec)) return -1;
+        for (int pass = 0; pass < kMaxPasses; ++pass) {
+            const bool last = thr <= 0 || waves <= final_waves || pass == kMaxPasses - 1;
+            a.pass = pass;
+            a.threshold = last ? 0 : thr;
+            a.park_in = ctx->d_park[(pass + 1) & 1];
+            a.park_out = ctx->d_park[pass & 1];
+            if (a.D.all_affine) hipLaunchKernelGGL(k_integrate<true>, dim3(waves), dim3(kWave), 0, st, a);
+            else hipLaunchKernelGGL(k_integrate<false>, dim3(waves), dim3(kWave), 0, st, a);
+            if (last) break;
+            waves = (unsigned)(((size_t)waves * (size_t)(thr - 1) + kWave - 1) / kWave);
+        }
     }
     if (ev) HIPCHK(ctx, hipEventRecord(ev[2], st));
     {
@@ -525,10 +587,15 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
         a.P = P; a.D = dev_fields(ctx); a.n = n; a.max_rk_steps = max_rk; a.srec = ctx->d_srec; a.fs = ctx->d_fs;
         a.slot = in->slot; a.n_valid = out->n_valid; a.status = out->status; a.n_accept = out->n_accept;
         a.lon = out->lon; a.lat = out->lat; a.v = out->v; a.m = out->m; a.vmax = out->vmax;
-        a.envw = out->envw; a.flags = out->flags;
-        const size_t lds = sizeof(double) * ((size_t)max_rk * 23 + 5 * ns);
-        if (a.D.all_affine) hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)n), dim3(kEmitThreads), lds, st, a);
-        else hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)n), dim3(kEmitThreads), lds, st, a);
+        a.envw = out->envw; a.flags = out->flags; a.pad_state = out->pad_state;
+        const unsigned chunks = (unsigned)((ns + kPostThreads - 1) / kPostThreads);
+        hipLaunchKernelGGL(k_dense, dim3((unsigned)n), dim3(kWave), 0, st, a, ctx->d_sidx);
+        if (a.D.all_affine) hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
+        else hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
+        hipLaunchKernelGGL(k_vmax, dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, P, out->n_valid,
+                           out->lon, out->lat, out->v, out->envw, out->vmax, out->flags);
+        hipLaunchKernelGGL(k_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, n, out->n_valid,
+                           out->status, out->v, out->flags, out->pad_state);
     }
     if (ev) HIPCHK(ctx, hipEventRecord(ev[3], st));
     HIPCHK(ctx, hipGetLastError());

@@ -39,9 +39,17 @@ struct KArgs {
     double *fs;              // [n][n_steps][4]
     double *srec;            // [n][max_rk_steps][kStepRec] accepted-step records
     int32_t *n_valid, *status, *nfev, *n_accept, *n_reject;
-    unsigned long long *queue;   // next storm index to hand out (zeroed before the launch)
+    unsigned long long *queue;   // [kMaxPasses] work-queue heads, [kMaxPasses] parked-storm counts, then per pass
+                                 // {wave cycles, live-lane cycles, wave clock ticks} (all zeroed before pass 0)
     int max_rk_steps;
+    // multi-pass tail compaction (see k_integrate)
+    int pass;                    // 0: storms come fresh from the batch; >0: from the list parked by pass-1
+    int threshold;               // park the wave's storms and exit once fewer lanes than this are live (0: run to the end)
+    const double *park_in;       // [.. ][kParkRec] list written by the previous pass
+    double *park_out;            // list this pass writes
 };
+constexpr int kMaxPasses = 16;
+constexpr int kParkRec = 16;     // doubles per parked storm: t, h, t_new, ha, g, y[4], f[4], 6 x int32
 
 // ---------------------------------------------------------------------------
 // gen_f (track/bam_track.py:23-31), direct form: one thread per (storm, sample),
@@ -195,6 +203,9 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
     const tcr_params &P = a.P;
     const DevFields &D = a.D;
     const int lane = threadIdx.x;
+    const long long n_items = a.pass == 0 ? (long long)a.n : (long long)a.queue[kMaxPasses + a.pass - 1];
+    if (a.pass > 0 && (long long)blockIdx.x * kWave >= n_items) return;     // the list fits the first waves
+    unsigned long long *const q_head = a.queue + a.pass;
     if (lane == 0) make_eval_k(P, D, K);
     __syncthreads();
     const int ns = P.n_steps;
@@ -248,40 +259,94 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
         attempt_setup();
     };
 
+    // occupancy accounting lives in LDS (lane 0 only): the kernel has no register to spare
+    __shared__ unsigned long long occ[3];
+    if (lane == 0) { occ[0] = 0; occ[1] = 0; occ[2] = wall_clock64(); }
     for (;;) {
         // ---- cycle boundary: refill idle lanes from the storm queue (wave-aggregated atomic)
         const unsigned long long want = __ballot(!active && !exhausted);
         if (want) {
             const int leader = __ffsll((long long)want) - 1;
             unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(a.queue, (unsigned long long)__popcll(want));
+            if (lane == leader) base = atomicAdd(q_head, (unsigned long long)__popcll(want));
             base = __shfl(base, leader);
             if (!active && !exhausted) {
-                sid = (long long)(base + (unsigned long long)__popcll(want & ((1ull << lane) - 1ull)));
-                if (sid >= a.n) {
+                const long long item = (long long)(base + (unsigned long long)__popcll(want & ((1ull << lane) - 1ull)));
+                if (item >= n_items) {
                     exhausted = true;
                 } else {
+                    if (a.pass == 0) {
+                        sid = item;
+                        y[0] = a.lon0[sid]; y[1] = a.lat0[sid]; y[2] = a.v0[sid]; y[3] = a.m0[sid];
+                        status = kRunning; nfev = 0; nacc = 0; nrej = 0; next_out = 0;
+                        t = 0.0;
+                        e[0] = 0.0; e[1] = y[0]; e[2] = y[1]; e[3] = y[2]; e[4] = y[3];
+                        fresh = true;
+                    } else {
+                        // restore a parked storm: the state between two attempts of _step_impl
+                        const double2 *r = reinterpret_cast<const double2 *>(a.park_in + (size_t)item * kParkRec);
+                        const double2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7];
+                        t = r0.x; h = r0.y; t_new = r1.x; ha = r1.y; g = r2.x;
+                        y[0] = r2.y; y[1] = r3.x; y[2] = r3.y; y[3] = r4.x;
+                        f[0] = r4.y; f[1] = r5.x; f[2] = r5.y; f[3] = r6.x;
+                        sid = __double_as_longlong(r6.y);
+                        const long long c0 = __double_as_longlong(r7.x), c1 = __double_as_longlong(r7.y);
+                        nfev = (int)(c0 & 0xffffffffll); nacc = (int)(c0 >> 32);
+                        nrej = (int)(c1 & 0x7fffffffll); rejected = (c1 >> 31) & 1; next_out = (int)(c1 >> 32);
+                        status = kRunning;
+                        // stage-2 input exactly as attempt_setup left it
+                        for (int i = 0; i < 4; ++i) {
+                            KS(0, i) = f[i];
+                            const double dy = 0.0 + f[i] * A10;
+                            e[1 + i] = y[i] + dy * h;
+                        }
+                        e[0] = t + RK_C[1] * h;
+                        fresh = false;
+                    }
                     S = D.slots[a.slot[sid]];
                     fs = a.fs + sid * ns * 4;
                     srec = a.srec + sid * (long long)a.max_rk_steps * kStepRec;
                     h_bl = a.h_bl[sid];
-                    y[0] = a.lon0[sid]; y[1] = a.lat0[sid]; y[2] = a.v0[sid]; y[3] = a.m0[sid];
-                    status = kRunning; nfev = 0; nacc = 0; nrej = 0; next_out = 0;
-                    t = 0.0;
-                    e[0] = 0.0; e[1] = y[0]; e[2] = y[1]; e[3] = y[2]; e[4] = y[3];
-                    active = true; fresh = true;
+                    active = true;
                     cache_reset(CC);
                 }
             }
         }
-        if (!__ballot(active)) break;
+        const unsigned long long live_mask = __ballot(active);
+        if (a.threshold > 0 && live_mask && !__ballot(fresh) && __popcll(live_mask) < a.threshold) {
+            // queue empty (every idle lane tried it) and the wave is mostly idle: park and exit
+            const int leader = __ffsll((long long)live_mask) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(a.queue + kMaxPasses + a.pass, (unsigned long long)__popcll(live_mask));
+            base = __shfl(base, leader);
+            if (active) {
+                const size_t item = (size_t)(base + (unsigned long long)__popcll(live_mask & ((1ull << lane) - 1ull)));
+                double2 *o = reinterpret_cast<double2 *>(a.park_out + item * kParkRec);
+                const long long c0 = (long long)(unsigned)nfev | ((long long)nacc << 32);
+                const long long c1 = (long long)(unsigned)nrej | ((long long)(rejected ? 1 : 0) << 31) | ((long long)next_out << 32);
+                o[0] = make_double2(t, h); o[1] = make_double2(t_new, ha); o[2] = make_double2(g, y[0]);
+                o[3] = make_double2(y[1], y[2]); o[4] = make_double2(y[3], f[0]); o[5] = make_double2(f[1], f[2]);
+                o[6] = make_double2(f[3], __longlong_as_double(sid));
+                o[7] = make_double2(__longlong_as_double(c0), __longlong_as_double(c1));
+            }
+            break;
+        }
+        if (!live_mask) break;
+        if (lane == 0) { occ[0] += 1; occ[1] += (unsigned long long)__popcll(live_mask); }
 
         // ---- six evaluation slots
 #pragma unroll 1
         for (int slot = 0; slot < 6; ++slot) {
             const bool live = active && !(fresh && slot >= 2);
             Rhs r{};
-            if (live) r = rhs_eval_cached<AFFINE>(CC, K, S, fs, h_bl, e[0], e[1], e[2], e[3], e[4]);
+#ifdef TCR_OPAQUE_K
+            int koff = 0;
+            asm volatile("" : "+s"(koff));      // opaque per iteration: the ~100 EvalK constants stay in LDS instead of being hoisted into registers
+            const EvalK &Kq = *reinterpret_cast<const EvalK *>(reinterpret_cast<const char *>(&K) + koff);
+#else
+            const EvalK &Kq = K;
+#endif
+            if (live) r = rhs_eval_cached<AFFINE>(CC, Kq, S, fs, h_bl, e[0], e[1], e[2], e[3], e[4]);
             if (live && !fresh) {
                 // rk_step (rk.py:62-70): K[s] = fun(...); next stage input dy = dot(K[:s].T, a[:s]) * h
                 ++nfev;
@@ -393,19 +458,28 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
         }
         fresh = false;
     }
+    if (lane == 0) {       // occupancy accounting of this pass (tcr_integrate_pass_stats)
+        unsigned long long *st = a.queue + 2 * kMaxPasses + 3 * a.pass;
+        atomicAdd(st + 0, occ[0]);
+        atomicAdd(st + 1, occ[1]);
+        atomicAdd(st + 2, wall_clock64() - occ[2]);
+    }
 #undef KS
 }
 
 // ---------------------------------------------------------------------------
-// k_emit: everything of run_tracks that is independent per output sample, fused:
-//   * t_eval emission from the dense output of the step that contains the sample
-//     (ivp.py:706-723, rk.py:552-574),
-//   * the env-wind recompute at every emitted sample (util/compute.py:201-202),
-//   * axi_to_max_wind (wind/tc_wind.py:6-21 with util/sphere.py:15-30,58-83),
-//   * accept tests 1 and 2 (compute.py:185-189, 205),
-//   * the reference's per-variable [n_tracks][n_steps] planes with NaN padding
-//     (compute.py:124-133), written coalesced.
-// One workgroup per storm; a thread owns samples tid, tid+T, ...
+// Post-processing: everything of run_tracks that is independent per output sample, as four
+// loop-free kernels split by register footprint (a fused one-workgroup-per-storm kernel was
+// measured first: it ran everything at the occupancy of the gather-heavy part, idled at its
+// barriers, and let the compiler hoist ~100 libm constants into registers around its loops):
+//   k_dense  wave per storm, lane per (accepted step, component): dense-output matrix Q = K^T P
+//            (rk.py:179-181) and the sample -> step map of t_eval emission (ivp.py:706-723);
+//   k_emit   thread per sample slot: dense output (rk.py:552-574), the env-wind recompute at
+//            every emitted sample (util/compute.py:201-202), NaN padding of the reference's
+//            [n_tracks][n_steps] planes (compute.py:124-133), "any v >= 15" of accept test 1;
+//   k_vmax   thread per sample: axi_to_max_wind (wind/tc_wind.py:6-21 with
+//            util/sphere.py:15-30,58-83), "any vmax >= threshold" of accept test 2;
+//   k_flags  thread per storm: accept tests 1 and 2 (compute.py:185-189, 205).
 struct EArgs {
     tcr_params P;
     DevFields D;
@@ -417,20 +491,117 @@ struct EArgs {
     const int32_t *n_valid, *status, *n_accept;
     double *lon, *lat, *v, *m, *vmax, *envw;
     int32_t *flags;
+    const int32_t *pad_state;    // rows are already NaN from this sample on (NULL / <0: unknown), see tcrisk_hip.h
 };
+constexpr int kBitAny15 = 1 << 8, kBitVmax = 1 << 9;     // scratch bits in flags[] between the kernels
+constexpr int kPostThreads = 128;
+#ifndef TCR_EMIT_WPS
+#define TCR_EMIT_WPS 3     // waves per SIMD k_emit is register-budgeted for (<= 168 VGPRs)
+#endif
 
-__device__ __forceinline__ double haversine_km(const tcr_params &P, double lon1, double lat1,
-                                               double lon2, double lat2)
+// k_dense: one wave per storm, lane = (accepted step j, state component c).  Replaces the seven
+// stage derivatives K[q][c] of the step record by row c of the dense-output matrix
+// Q = K^T P (rk.py:179-181) — in place: every lane has loaded its K column before any lane
+// stores (one wave, lock step) — and tells every hourly sample which step it belongs to.
+__global__ __launch_bounds__(kWave) void k_dense(EArgs a, uint16_t *__restrict__ sidx)
 {
-    const double d = kPi / 180.0;
-    lon1 *= d; lat1 *= d; lon2 *= d; lat2 *= d;
-    const double sa = sin((lat2 - lat1) / 2), sb = sin((lon2 - lon1) / 2);
-    const double aa = sa * sa + cos(lat1) * cos(lat2) * (sb * sb);
-    return (P.earth_R / 1000.) * (2 * asin(sqrt(aa)));
+    const tcr_params &P = a.P;
+    const int64_t sid = blockIdx.x;
+    const int ns = P.n_steps;
+    const int n = a.n_valid[sid];
+    int nst = a.n_accept[sid];
+    nst = nst < a.max_rk_steps ? nst : a.max_rk_steps;
+    if (threadIdx.x == 0) a.flags[sid] = 0;
+    const int c = threadIdx.x & 3;
+    for (int j0 = 0; j0 < nst; j0 += kWave / 4) {
+        const int j = j0 + (threadIdx.x >> 2);
+        const bool on = j < nst;
+        double *rj = const_cast<double *>(a.srec) + (sid * (int64_t)a.max_rk_steps + (on ? j : 0)) * kStepRec;
+        double kq[7];
+        for (int q = 0; q < 7; ++q) kq[q] = rj[8 + q * 4 + c];
+        const double t_old = rj[0], t_new = rj[2];
+        double Q[4];
+        for (int k = 0; k < 4; ++k) {
+            double acc = 0.0;
+            for (int q = 0; q < 7; ++q) acc += kq[q] * RK_P[q][k];
+            Q[k] = acc;
+        }
+        // (all loads of the wave are complete here: Q depends on them)
+        if (on) {
+            double2 *o = reinterpret_cast<double2 *>(rj + 8 + c * 4);
+            o[0] = make_double2(Q[0], Q[1]);
+            o[1] = make_double2(Q[2], Q[3]);
+            if (c == 0) {
+                // samples of this step: t_old < ts <= t_new (the first step also owns ts = 0)
+                const int i_lo = (j == 0) ? 0 : samples_upto(P, t_old);
+                int i_hi = samples_upto(P, t_new);
+                i_hi = i_hi < n ? i_hi : n;
+                for (int i = i_lo; i < i_hi; ++i) sidx[(size_t)sid * ns + i] = (uint16_t)j;
+            }
+        }
+    }
 }
 
-// The two haversine calls of calc_translational_speed (sphere.py:71-76) have either equal latitudes
-// or equal longitudes; the vanishing term is sin(0)^2 = 0 exactly, so dropping it is bit-identical.
+// k_emit: thread per sample slot.  Valid sample: dense output of its step (rk.py:552-574), env
+// winds there, planes written; the rest of the row is NaN padding.
+template <bool AFFINE>
+__global__ __launch_bounds__(kPostThreads, TCR_EMIT_WPS) void k_emit(EArgs a, const uint16_t *__restrict__ sidx)
+{
+    __shared__ EvalK K;
+    const tcr_params &P = a.P;
+    const int64_t sid = blockIdx.x;
+    const int ns = P.n_steps;
+    const int i = blockIdx.y * kPostThreads + threadIdx.x;
+    const int n = a.n_valid[sid];
+    const size_t o = (size_t)sid * ns + i;
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    const bool live_block = (int)(blockIdx.y * kPostThreads) < n;
+    if (live_block) {
+        if (threadIdx.x == 0) make_eval_k(P, a.D, K);
+        __syncthreads();
+    }
+    if (i < n) {
+        const double *st = a.srec + (sid * (int64_t)a.max_rk_steps + sidx[o]) * kStepRec;
+        const double2 *s2 = reinterpret_cast<const double2 *>(st);
+        const double2 h0 = s2[0], y01 = s2[2], y23 = s2[3];
+        const double te = ts_at(P, i);
+        const double hh = h0.y;
+        const double x = (te - h0.x) / hh;
+        const double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
+        const double y0[4] = {y01.x, y01.y, y23.x, y23.y};
+        double ye[4];
+        for (int c = 0; c < 4; ++c) {
+            const double2 qa = s2[4 + 2 * c], qb = s2[5 + 2 * c];
+            double acc = 0.0;
+            acc += qa.x * p1; acc += qa.y * p2; acc += qb.x * p3; acc += qb.y * p4;
+            ye[c] = hh * acc + y0[c];
+        }
+        const DevSlot S = a.D.slots[a.slot[sid]];
+        double w[4];
+        env_winds<AFFINE>(K, S, a.fs + sid * ns * 4, ye[0], ye[1], te, w);
+        a.lon[o] = ye[0]; a.lat[o] = ye[1]; a.v[o] = ye[2]; a.m[o] = ye[3];
+        double2 *eo = reinterpret_cast<double2 *>(a.envw + o * 4);
+        eo[0] = make_double2(w[0], w[1]);
+        eo[1] = make_double2(w[2], w[3]);
+        if (__ballot(ye[2] >= P.v_thresh) && (threadIdx.x & 63) == (__ffsll((long long)__ballot(true)) - 1))
+            atomicOr(a.flags + sid, kBitAny15);
+    } else {
+        // NaN padding, only where the row is not known to be padded already
+        int pad_to = a.pad_state ? a.pad_state[sid] : ns;
+        pad_to = (pad_to < 0 || pad_to > ns) ? ns : pad_to;
+        if (i < pad_to) {
+            a.lon[o] = nan; a.lat[o] = nan; a.v[o] = nan; a.m[o] = nan; a.vmax[o] = nan;
+            double2 *eo = reinterpret_cast<double2 *>(a.envw + o * 4);
+            eo[0] = make_double2(nan, nan);
+            eo[1] = make_double2(nan, nan);
+        }
+    }
+}
+
+// The two haversine calls of calc_translational_speed (sphere.py:71-76, haversine :15-30) have
+// either equal latitudes or equal longitudes.  The vanishing term is sin(0)^2 = 0 (same
+// latitude) or cos(lat1)*cos(lat2)*sin(0)^2 = +-0 (same longitude, latitudes finite), and
+// x + (+-0) = x for x >= 0, so dropping it — and with it two cosines — is bit-identical.
 __device__ __forceinline__ double haversine_same_lat_km(const tcr_params &P, double lon1, double lon2, double lat)
 {
     const double d = kPi / 180.0;
@@ -445,155 +616,88 @@ __device__ __forceinline__ double haversine_same_lon_km(const tcr_params &P, dou
     const double d = kPi / 180.0;
     lat1 *= d; lat2 *= d;
     const double sa = sin((lat2 - lat1) / 2);
-    const double aa = sa * sa + cos(lat1) * cos(lat2) * 0.0;
+    const double aa = sa * sa;
     return (P.earth_R / 1000.) * (2 * asin(sqrt(aa)));
 }
 
-constexpr int kEmitThreads = 128;
-#ifndef TCR_EMIT_WPS
-#define TCR_EMIT_WPS 2     // waves per SIMD k_emit is register-budgeted for (it is a throughput kernel)
+// k_vmax: translation speed by centred differences -> vmax.
+// tc_wind.py:17-20 turns (Ui, Vi) into an angle and back: th = arctan2(-Ui, Vi),
+// ug = v*(-sin th) + Ui*fac, vg = v*cos th + Vi*fac.  -sin(th) = Ui/|U| and cos(th) = Vi/|U| with
+// |U| = sqrt(Ui^2 + Vi^2), which the function has just computed, so the three transcendental calls
+// reduce to two divisions (|U| = 0: th = -0, i.e. (0, 1)); differs from libm's round trip by ~1 ulp.
+#ifndef TCR_VMAX_WPS
+#define TCR_VMAX_WPS 4
 #endif
-
-template <bool AFFINE>
-__global__ __launch_bounds__(kEmitThreads, TCR_EMIT_WPS) void k_emit(EArgs a)
+__global__ __launch_bounds__(kPostThreads, TCR_VMAX_WPS) void k_vmax(tcr_params P, const int32_t *__restrict__ n_valid,
+                                                                     const double *__restrict__ plon,
+                                                                     const double *__restrict__ plat,
+                                                                     const double *__restrict__ pv,
+                                                                     const double *__restrict__ penvw,
+                                                                     double *__restrict__ pvmax, int32_t *__restrict__ flags)
 {
-    // LDS: per accepted step {t_new, t_old, h, y_old[4], Q[16]} = 23 doubles; per sample {lon, lat, v, us, vs}
-    extern __shared__ double esh[];
-    __shared__ EvalK K;
-    __shared__ double s_best[kEmitThreads / 64];
-    __shared__ int s_any[kEmitThreads / 64];
-    __shared__ double s_v2d[2];
-    const tcr_params &P = a.P;
     const int64_t sid = blockIdx.x;
     const int ns = P.n_steps;
-    const int n = a.n_valid[sid];
-    const int status = a.status[sid];
-    int nst = a.n_accept[sid];
-    nst = nst < a.max_rk_steps ? nst : a.max_rk_steps;
-    double *s_step = esh;                                   // [max_rk_steps][23]
-    double *s_lon = esh + (size_t)a.max_rk_steps * 23, *s_lat = s_lon + ns, *s_v = s_lat + ns;
-    double *s_us = s_v + ns, *s_vs = s_us + ns;
-    const double *srec = a.srec + sid * (int64_t)a.max_rk_steps * kStepRec;
-    const double *fs = a.fs + sid * ns * 4;
-    const DevSlot S = a.D.slots[a.slot[sid]];
-    const double nan = __longlong_as_double(0x7ff8000000000000LL);
-    // stage t_new, t_old, h, y_old and the dense-output matrix Q = K^T P (rk.py:179-181)
-    for (int p = threadIdx.x; p < nst * 23; p += kEmitThreads) {
-        const int j = p / 23, c = p - j * 23;
-        const double *rj = srec + (size_t)j * kStepRec;
-        double val;
-        if (c == 0) val = rj[2];
-        else if (c == 1) val = rj[0];
-        else if (c == 2) val = rj[1];
-        else if (c < 7) val = rj[4 + (c - 3)];
+    const int i = blockIdx.y * kPostThreads + threadIdx.x;
+    const int n = n_valid[sid];
+    if (i >= n) return;                       // padding was written by k_emit
+    const size_t o = (size_t)sid * ns + i;
+    if (n <= 1) { pvmax[o] = __longlong_as_double(0x7ff8000000000000LL); return; }
+    const double *lo_ = plon + (size_t)sid * ns, *la_ = plat + (size_t)sid * ns;
+    const double lon = lo_[i], lat = la_[i], v = pv[o];
+    const double2 *ew = reinterpret_cast<const double2 *>(penvw + o * 4);
+    const double2 e0 = ew[0], e1 = ew[1];
+    const double us = e0.x - e1.x, vs = e0.y - e1.y;
+    // linear extrapolation at both ends (sphere.py:66-69)
+    const double lom = (i == 0) ? 2 * lon - lo_[1] : lo_[i - 1];
+    const double lam = (i == 0) ? 2 * lat - la_[1] : la_[i - 1];
+    const double lop = (i == n - 1) ? 2 * lon - lo_[n - 2] : lo_[i + 1];
+    const double lap = (i == n - 1) ? 2 * lat - la_[n - 2] : la_[i + 1];
+    const double dlon = 0.5 * (sign_of(lop - lom) * haversine_same_lat_km(P, lop, lom, lat));
+    const double dlat = 0.5 * (sign_of(lap - lam) * haversine_same_lon_km(P, lap, lam));
+    const double ut = dlon * 1000. / P.dt_out, vt = dlat * 1000. / P.dt_out;
+    const double G = fmin(1., 0.8 + 0.35 * (1. + tanh((lat - 35.) / 10.)));
+    const double Ui = G * ut + 0.1 * us * v / 15.;
+    const double Vi = G * vt + 0.1 * vs * v / 15.;
+    const double mag = sqrt(Ui * Ui + Vi * Vi);
+    const double fac = np_min((v * 0.50) / mag, 1.0);
+    const double msin = (mag == 0.0) ? 0.0 : Ui / mag;      // -sin(arctan2(-Ui, Vi))
+    const double mcos = (mag == 0.0) ? 1.0 : Vi / mag;      //  cos(arctan2(-Ui, Vi))
+    const double ug = v * msin + Ui * fac;
+    const double vg = v * mcos + Vi * fac;
+    const double vm = sqrt(ug * ug + vg * vg);
+    pvmax[o] = vm;
+    if (__ballot(vm >= P.vmax_thresh) && (threadIdx.x & 63) == (__ffsll((long long)__ballot(true)) - 1))
+        atomicOr(flags + sid, kBitVmax);
+}
+
+__global__ __launch_bounds__(256) void k_flags(tcr_params P, int64_t n_storms, const int32_t *__restrict__ n_valid,
+                                               const int32_t *__restrict__ status, const double *__restrict__ pv,
+                                               int32_t *__restrict__ flags, int32_t *__restrict__ pad_state)
+{
+    const int64_t sid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sid >= n_storms) return;
+    const int ns = P.n_steps;
+    const int n = n_valid[sid];
+    if (pad_state) pad_state[sid] = n;         // every k_emit block of the row has read the old value
+    const int bits = flags[sid];
+    int fl = 0;
+    if (n > 0 && status[sid] != TCR_STATUS_GATED) {
+        // np.interp(2 d, res.t, v) (compute.py:186-188)
+        const double step_out = P.total_time / (double)(ns - 1);
+        const double t2d = 2 * 86400.0;
+        const double *v = pv + (size_t)sid * ns;
+        double v2d;
+        if (t2d >= ts_at(P, n - 1)) v2d = v[n - 1];
         else {
-            const int i = (c - 7) >> 2, k = (c - 7) & 3;
-            double acc = 0.0;
-            for (int q = 0; q < 7; ++q) acc += rj[8 + q * 4 + i] * RK_P[q][k];
-            val = acc;
+            const int j = (int)floor(t2d / step_out);
+            v2d = (v[j + 1] - v[j]) / (ts_at(P, j + 1) - ts_at(P, j)) * (t2d - ts_at(P, j)) + v[j];
         }
-        s_step[p] = val;
-    }
-    if (threadIdx.x == 0) make_eval_k(P, a.D, K);
-    __syncthreads();
-
-    // ---- pass 1: dense output + env winds per valid sample; NaN padding beyond
-    const double step_out = P.total_time / (double)(ns - 1);
-    const double t2d = 2 * 86400.0;
-    int any15 = 0;
-    for (int i0 = 0; i0 < ns; i0 += kEmitThreads) {
-        const int i = i0 + threadIdx.x;
-        double lon = nan, lat = nan, v = nan, m = nan, w[4] = {nan, nan, nan, nan};
-        const bool valid = i < n;
-        double te = 0.0, ye[4] = {0.0, 0.0, 0.0, 0.0};
-        if (valid) {
-            te = ts_at(P, i);
-            // the sample belongs to the first accepted step whose end is >= te
-            int lo = 0, hi = nst - 1;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_step[mid * 23] >= te) hi = mid; else lo = mid + 1; }
-            const double *st = s_step + lo * 23;
-            const double hh = st[2];
-            const double x = (te - st[1]) / hh;
-            const double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
-            for (int c = 0; c < 4; ++c) {
-                const double *Q = st + 7 + c * 4;
-                double acc = 0.0;
-                acc += Q[0] * p1; acc += Q[1] * p2; acc += Q[2] * p3; acc += Q[3] * p4;
-                ye[c] = hh * acc + st[3 + c];
-            }
-        }
-        if (valid) {
-            env_winds<AFFINE>(K, S, fs, ye[0], ye[1], te, w);
-            lon = ye[0]; lat = ye[1]; v = ye[2]; m = ye[3];
-            if (v >= P.v_thresh) any15 = 1;
-            s_lon[i] = lon; s_lat[i] = lat; s_v[i] = v;
-            s_us[i] = w[0] - w[2]; s_vs[i] = w[1] - w[3];
-            // np.interp(2 d, res.t, v) needs v at the two samples bracketing 2 d (or the last one)
-            const int j2 = (int)floor(t2d / step_out);
-            if (t2d >= ts_at(P, n - 1)) { if (i == n - 1) s_v2d[0] = s_v2d[1] = v; }
-            else { if (i == j2) s_v2d[0] = v; if (i == j2 + 1) s_v2d[1] = v; }
-        }
-        if (i < ns) {
-            const size_t o = (size_t)sid * ns + i;
-            a.lon[o] = lon; a.lat[o] = lat; a.v[o] = v; a.m[o] = m;
-            double2 *eo = reinterpret_cast<double2 *>(a.envw + o * 4);
-            eo[0] = make_double2(w[0], w[1]);
-            eo[1] = make_double2(w[2], w[3]);
+        if ((bits & kBitAny15) && v2d >= P.v_2d_thresh) {
+            fl |= TCR_FLAG_IS_TC;
+            if (n > 1 && (bits & kBitVmax)) fl |= TCR_FLAG_ACCEPTED;
         }
     }
-    __syncthreads();
-
-    // ---- pass 2: translation speed by centred differences -> vmax (needs the neighbours)
-    double best = -INFINITY;
-    for (int i = threadIdx.x; i < ns; i += kEmitThreads) {
-        double vm = nan;
-        if (i < n && n > 1) {
-            const double lon = s_lon[i], lat = s_lat[i], v = s_v[i];
-            // linear extrapolation at both ends (sphere.py:66-69)
-            const double lom = (i == 0) ? 2 * lon - s_lon[1] : s_lon[i - 1];
-            const double lam = (i == 0) ? 2 * lat - s_lat[1] : s_lat[i - 1];
-            const double lop = (i == n - 1) ? 2 * lon - s_lon[n - 2] : s_lon[i + 1];
-            const double lap = (i == n - 1) ? 2 * lat - s_lat[n - 2] : s_lat[i + 1];
-            const double dlon = 0.5 * (sign_of(lop - lom) * haversine_same_lat_km(P, lop, lom, lat));
-            const double dlat = 0.5 * (sign_of(lap - lam) * haversine_same_lon_km(P, lap, lam));
-            const double ut = dlon * 1000. / P.dt_out, vt = dlat * 1000. / P.dt_out;
-            const double G = fmin(1., 0.8 + 0.35 * (1. + tanh((lat - 35.) / 10.)));
-            const double Ui = G * ut + 0.1 * s_us[i] * v / 15.;
-            const double Vi = G * vt + 0.1 * s_vs[i] * v / 15.;
-            const double mag = sqrt(Ui * Ui + Vi * Vi);
-            const double fac = np_min((v * 0.50) / mag, 1.0);
-            const double th = atan2(-Ui, Vi);
-            const double ug = v * -sin(th) + Ui * fac;
-            const double vg = v * cos(th) + Vi * fac;
-            vm = sqrt(ug * ug + vg * vg);
-            if (vm > best) best = vm;
-        }
-        a.vmax[(size_t)sid * ns + i] = vm;
-    }
-    // ---- accept flags: wave reductions, then one thread
-    for (int off = 32; off > 0; off >>= 1) {
-        best = fmax(best, __shfl_down(best, off));
-        any15 |= __shfl_down(any15, off);
-    }
-    if ((threadIdx.x & 63) == 0) { s_best[threadIdx.x >> 6] = best; s_any[threadIdx.x >> 6] = any15; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int wv = 1; wv < kEmitThreads / 64; ++wv) { best = fmax(best, s_best[wv]); any15 |= s_any[wv]; }
-        int fl = 0;
-        if (n > 0 && status != TCR_STATUS_GATED) {
-            double v2d;
-            if (t2d >= ts_at(P, n - 1)) v2d = s_v2d[0];
-            else {
-                const int j = (int)floor(t2d / step_out);
-                v2d = (s_v2d[1] - s_v2d[0]) / (ts_at(P, j + 1) - ts_at(P, j)) * (t2d - ts_at(P, j)) + s_v2d[0];
-            }
-            if (any15 && v2d >= P.v_2d_thresh) {
-                fl |= TCR_FLAG_IS_TC;
-                if (n > 1 && best >= P.vmax_thresh) fl |= TCR_FLAG_ACCEPTED;
-            }
-        }
-        a.flags[sid] = fl;
-    }
+    flags[sid] = fl;
 }
 
 template <bool AFFINE>

@@ -36,7 +36,9 @@ class DevicePipeline:
                            vmax=z(self.B, ns), envw=z(self.B, ns, 4),
                            n_valid=z(self.B, dtype=I32), status=z(self.B, dtype=I32),
                            flags=z(self.B, dtype=I32), nfev=z(self.B, dtype=I32),
-                           n_accept=z(self.B, dtype=I32), n_reject=z(self.B, dtype=I32))
+                           n_accept=z(self.B, dtype=I32), n_reject=z(self.B, dtype=I32),
+                           # rows of the planes are NaN from this sample on (-1: unknown), tcrisk_hip.h
+                           pad_state=torch.full((self.B,), -1, dtype=I32, device=self.dev))
         self.cand_idx = z(self.C, dtype=I32)  # candidate index of each dense storm
         self.n_passed = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.acc_idx = z(self.B, dtype=I32)
@@ -57,7 +59,7 @@ class DevicePipeline:
     def _tracks_struct(self):
         t = self.tracks
         return _lib.Tracks(*[t[k].data_ptr() for k in ('lon', 'lat', 'v', 'm', 'vmax', 'envw', 'n_valid',
-                                                        'status', 'flags', 'nfev', 'n_accept', 'n_reject')])
+                                                        'status', 'flags', 'nfev', 'n_accept', 'n_reject', 'pad_state')])
 
     def _stream(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
