@@ -75,6 +75,8 @@ struct tcr_ctx {
     double *d_park[2] = {nullptr, nullptr};     // ping-pong lists of parked storms
     size_t park_cap[2] = {0, 0};
     double2 *d_sc_table = nullptr;              // one period of (sin, cos)(2π j / period)
+    double2 *d_pf = nullptr;                    // weighted phase factors [n][n_series][4] of the periodic Fourier kernel
+    size_t pf_cap = 0;
     int fs_period = 0;                          // 0: direct Fourier kernel
     int cu_count = 256;
     // timing: four events per timed tcr_integrate_dev call since tcr_timing_enable(ctx, 1)
@@ -222,9 +224,16 @@ int launch_fourier(tcr_ctx *ctx, int64_t n, const double *phases, double *fs, hi
 {
     const tcr_params &P = ctx->prm;
     if (ctx->fs_period > 0) {
-        const size_t lds = sizeof(double2) * ((size_t)ctx->fs_period + 4 * (size_t)P.n_series);
+        const size_t lds = sizeof(double2) * (size_t)ctx->fs_period;
+        const int64_t nf = n * 4 * (int64_t)P.n_series;
+        {
+            double *p = reinterpret_cast<double *>(ctx->d_pf);
+            if (grow(ctx, &p, &ctx->pf_cap, (size_t)nf * 2)) { ctx->d_pf = nullptr; return -1; }
+            ctx->d_pf = reinterpret_cast<double2 *>(p);
+        }
+        hipLaunchKernelGGL(k_phase_factors, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, P, n, phases, ctx->d_pf);
         hipLaunchKernelGGL(k_fourier_periodic, dim3((unsigned)n), dim3(kFsThreads), lds, st, P, n,
-                           ctx->fs_period, ctx->d_sc_table, phases, fs);
+                           ctx->fs_period, ctx->d_sc_table, ctx->d_pf, fs);
     } else {
         const int64_t total = n * (int64_t)P.n_steps;
         hipLaunchKernelGGL(k_fourier_direct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, n, phases, fs);
@@ -332,7 +341,7 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_run_mask); (void)hipFree(ctx->d_basin_masks);
     (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_srec);
     for (auto &ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
-    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table);
+    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;

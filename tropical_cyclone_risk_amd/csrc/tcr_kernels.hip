@@ -91,44 +91,73 @@ __global__ __launch_bounds__(256) void k_fourier_direct(tcr_params P, int64_t n,
 // sincospi instead of 21 660 sines.  It evaluates the same series the reference
 // does; the values differ from NumPy's only by the rounding of NumPy's own argument
 // 2π·(n t/T + x) (|Δ| ~ 1e-14, tests/test_gpu_parity.py states the bound).
-// One workgroup per storm; thread = (sample, series) pairs, coalesced stores.
+//
+// k_phase_factors: amplitude-weighted phase factors n^-1.5 * (sin, cos)(2π x), laid out
+// [storm][harmonic][series] so that one harmonic of a storm is one 64-byte scalar load.
+__global__ __launch_bounds__(256) void k_phase_factors(tcr_params P, int64_t n, const double *__restrict__ phases,
+                                                       double2 *__restrict__ pf)
+{
+    const int N = P.n_series;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * 4 * N) return;
+    const int64_t storm = gid / (4 * N);
+    const int r = (int)(gid - storm * 4 * N), s = r / N, h = r - s * N;      // phases are [storm][series][harmonic]
+    const double x = phases[gid];
+    const double wgt = P.fs_wgt[h];
+    pf[storm * 4 * N + h * 4 + s] = make_double2(wgt * sinpi(2.0 * x), wgt * cospi(2.0 * x));
+}
+
+// k_fourier_periodic: one workgroup per storm; a thread owns three output samples and all four
+// series of them, harmonics in the outer loop.  The phase factors of a harmonic are the same for
+// the whole workgroup, so they are scalar loads (SGPR operands of the FMAs) and the only LDS
+// traffic is one table entry per (sample, harmonic) — the first version read the factors from
+// LDS as well and was LDS-issue bound.
 constexpr int kFsThreads = 128;
+constexpr int kFsPerThread = 3;
 
 __global__ __launch_bounds__(kFsThreads) void k_fourier_periodic(tcr_params P, int64_t n, int period,
                                                                   const double2 *__restrict__ sc_table,
-                                                                  const double *__restrict__ phases,
+                                                                  const double2 *__restrict__ pf,
                                                                   double *__restrict__ fs)
 {
-    extern __shared__ double2 lds[];            // [period] table, then [4*N] (sin, cos)(2π x)
+    extern __shared__ double2 lds[];            // [period] one period of (sin, cos)
     const int N = P.n_series, ns = P.n_steps;
-    double2 *tab = lds, *ph = lds + period;
+    double2 *tab = lds;
     const int64_t storm = blockIdx.x;
     for (int j = threadIdx.x; j < period; j += kFsThreads) tab[j] = sc_table[j];
-    if (threadIdx.x < 4 * N) {
-        // amplitude-weighted phase factors: n^-1.5 * (sin, cos)(2π x)
-        const double x = phases[storm * 4 * N + threadIdx.x];
-        const double wgt = P.fs_wgt[threadIdx.x % N];
-        ph[threadIdx.x] = make_double2(wgt * sinpi(2.0 * x), wgt * cospi(2.0 * x));
-    }
     __syncthreads();
+    // (persistent workgroups that stage the table once were measured slower: 0.51 vs 0.37 ms)
+    const double2 *__restrict__ pfs = pf + storm * 4 * N;       // wave-uniform
     double *out = fs + storm * ns * 4;
-    // one thread = one output sample, all four series: the table entry of harmonic h is shared by
-    // the four series (4 independent accumulators, 1 table read + 4 broadcast reads per harmonic)
-    for (int k = threadIdx.x; k < ns; k += kFsThreads) {
-        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-        int j = 0;                               // (n * k) mod period, built incrementally
-        const int kk = k % period;
-        for (int h = 0; h < N; ++h) {            // (fully unrolling this loop was measured 2x slower)
-            j += kk; if (j >= period) j -= period;
-            const double2 a = tab[j];
-            const double2 b0 = ph[h], b1 = ph[N + h], b2 = ph[2 * N + h], b3 = ph[3 * N + h];
-            // sin(A + B) = sinA cosB + cosA sinB, accumulated with explicit FMAs (2 per term)
-            acc0 = fma(a.x, b0.y, fma(a.y, b0.x, acc0)); acc1 = fma(a.x, b1.y, fma(a.y, b1.x, acc1));
-            acc2 = fma(a.x, b2.y, fma(a.y, b2.x, acc2)); acc3 = fma(a.x, b3.y, fma(a.y, b3.x, acc3));
+    for (int base = 0; base < ns; base += kFsThreads * kFsPerThread) {
+        int kk[kFsPerThread], j[kFsPerThread];
+        double acc[kFsPerThread][4];
+#pragma unroll
+        for (int u = 0; u < kFsPerThread; ++u) {
+            kk[u] = (base + u * kFsThreads + (int)threadIdx.x) % period;
+            j[u] = 0;                                            // (n * k) mod period, built incrementally
+            acc[u][0] = acc[u][1] = acc[u][2] = acc[u][3] = 0.0;
         }
-        double2 *o = reinterpret_cast<double2 *>(out + (size_t)k * 4);
-        o[0] = make_double2(P.fs_amp * acc0, P.fs_amp * acc1);
-        o[1] = make_double2(P.fs_amp * acc2, P.fs_amp * acc3);
+        for (int h = 0; h < N; ++h) {
+            const double2 b0 = pfs[h * 4 + 0], b1 = pfs[h * 4 + 1], b2 = pfs[h * 4 + 2], b3 = pfs[h * 4 + 3];
+#pragma unroll
+            for (int u = 0; u < kFsPerThread; ++u) {
+                j[u] += kk[u]; if (j[u] >= period) j[u] -= period;
+                const double2 a = tab[j[u]];
+                // sin(A + B) = sinA cosB + cosA sinB, accumulated with explicit FMAs (2 per term)
+                acc[u][0] = fma(a.x, b0.y, fma(a.y, b0.x, acc[u][0])); acc[u][1] = fma(a.x, b1.y, fma(a.y, b1.x, acc[u][1]));
+                acc[u][2] = fma(a.x, b2.y, fma(a.y, b2.x, acc[u][2])); acc[u][3] = fma(a.x, b3.y, fma(a.y, b3.x, acc[u][3]));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kFsPerThread; ++u) {
+            const int k = base + u * kFsThreads + (int)threadIdx.x;
+            if (k < ns) {
+                double2 *o = reinterpret_cast<double2 *>(out + (size_t)k * 4);
+                o[0] = make_double2(P.fs_amp * acc[u][0], P.fs_amp * acc[u][1]);
+                o[1] = make_double2(P.fs_amp * acc[u][2], P.fs_amp * acc[u][3]);
+            }
+        }
     }
 }
 
