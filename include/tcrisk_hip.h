@@ -217,8 +217,8 @@ int tcr_timing_last(tcr_ctx *ctx, double ms[3]);
 int tcr_timing_sum(tcr_ctx *ctx, double ms[3], int64_t *n_calls);
 /* Occupancy accounting of the last tcr_integrate_* call (synchronises the device first is the
  * caller's job): k_integrate runs as a chain of passes (tail compaction); for each pass p
- * out[5p..5p+4] = { queue requests, storms parked for pass p+1, wave cycles, live-lane cycles,
- * wave wall-clock ticks at 100 MHz }.  One cycle = one RK45 step attempt (six evaluations of
+ * out[6p..6p+5] = { queue requests, storms parked for pass p+1, wave cycles, live-lane cycles,
+ * wave wall-clock ticks at 100 MHz, wave shader-clock ticks }.  One cycle = one RK45 step attempt (six evaluations of
  * the reference's ode_rhs, intensity/coupled_fast.py:150-209) of up to 64 storms; live-lane
  * cycles / (64 x wave cycles) is the lane utilisation.  Returns the number of passes. */
 int tcr_integrate_pass_stats(tcr_ctx *ctx, int64_t *out, int max_passes);

@@ -259,7 +259,7 @@ unsigned integrate_waves(const tcr_ctx *ctx, int64_t n)
 
 // Tail compaction of k_integrate: a wave parks its storms once fewer than this many lanes are
 // live and the queue is empty (TCR_PARK=0 disables the chain: one launch runs every storm to its end).
-constexpr size_t kQueueWords = 5 * kMaxPasses;     // heads, parked counts, 3 occupancy counters per pass
+constexpr size_t kQueueWords = 6 * kMaxPasses;     // heads, parked counts, 4 occupancy counters per pass
 unsigned park_final_waves()               // a pass this small runs to the end
 {
     if (const char *e = getenv("TCR_PARK_FINAL")) { const long v = atol(e); if (v > 0) return (unsigned)v; }
@@ -518,12 +518,13 @@ int tcr_integrate_pass_stats(tcr_ctx *ctx, int64_t *out, int max_passes)
     HIPCHK(ctx, hipMemcpy(h, ctx->d_queue, sizeof(h), hipMemcpyDeviceToHost));
     int np = 0;
     for (int p = 0; p < kMaxPasses && p < max_passes; ++p) {
-        if (h[2 * kMaxPasses + 3 * p] == 0 && h[p] == 0) break;
-        out[5 * p + 0] = (int64_t)h[p];                               // items requested from the queue (>= items)
-        out[5 * p + 1] = (int64_t)h[kMaxPasses + p];                  // storms parked for the next pass
-        out[5 * p + 2] = (int64_t)h[2 * kMaxPasses + 3 * p + 0];      // wave cycles
-        out[5 * p + 3] = (int64_t)h[2 * kMaxPasses + 3 * p + 1];      // live-lane cycles
-        out[5 * p + 4] = (int64_t)h[2 * kMaxPasses + 3 * p + 2];      // wave wall-clock ticks (100 MHz)
+        if (h[2 * kMaxPasses + 4 * p] == 0 && h[p] == 0) break;
+        out[6 * p + 0] = (int64_t)h[p];                               // items requested from the queue (>= items)
+        out[6 * p + 1] = (int64_t)h[kMaxPasses + p];                  // storms parked for the next pass
+        out[6 * p + 2] = (int64_t)h[2 * kMaxPasses + 4 * p + 0];      // wave cycles
+        out[6 * p + 3] = (int64_t)h[2 * kMaxPasses + 4 * p + 1];      // live-lane cycles
+        out[6 * p + 4] = (int64_t)h[2 * kMaxPasses + 4 * p + 2];      // wave wall-clock ticks (100 MHz)
+        out[6 * p + 5] = (int64_t)h[2 * kMaxPasses + 4 * p + 3];      // wave shader-clock ticks
         ++np;
     }
     return np;
@@ -601,8 +602,6 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
         hipLaunchKernelGGL(k_dense, dim3((unsigned)n), dim3(kWave), 0, st, a, ctx->d_sidx);
         if (a.D.all_affine) hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
         else hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
-        hipLaunchKernelGGL(k_vmax, dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, P, out->n_valid,
-                           out->lon, out->lat, out->v, out->envw, out->vmax, out->flags);
         hipLaunchKernelGGL(k_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, n, out->n_valid,
                            out->status, out->v, out->flags, out->pad_state);
     }

@@ -40,7 +40,7 @@ struct KArgs {
     double *srec;            // [n][max_rk_steps][kStepRec] accepted-step records
     int32_t *n_valid, *status, *nfev, *n_accept, *n_reject;
     unsigned long long *queue;   // [kMaxPasses] work-queue heads, [kMaxPasses] parked-storm counts, then per pass
-                                 // {wave cycles, live-lane cycles, wave clock ticks} (all zeroed before pass 0)
+                                 // {wave cycles, live-lane cycles, wave wall-clock ticks, wave shader-clock ticks} (all zeroed before pass 0)
     int max_rk_steps;
     // multi-pass tail compaction (see k_integrate)
     int pass;                    // 0: storms come fresh from the batch; >0: from the list parked by pass-1
@@ -289,8 +289,8 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
     };
 
     // occupancy accounting lives in LDS (lane 0 only): the kernel has no register to spare
-    __shared__ unsigned long long occ[3];
-    if (lane == 0) { occ[0] = 0; occ[1] = 0; occ[2] = wall_clock64(); }
+    __shared__ unsigned long long occ[4];
+    if (lane == 0) { occ[0] = 0; occ[1] = 0; occ[2] = wall_clock64(); occ[3] = clock64(); }
     for (;;) {
         // ---- cycle boundary: refill idle lanes from the storm queue (wave-aggregated atomic)
         const unsigned long long want = __ballot(!active && !exhausted);
@@ -488,26 +488,26 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
         fresh = false;
     }
     if (lane == 0) {       // occupancy accounting of this pass (tcr_integrate_pass_stats)
-        unsigned long long *st = a.queue + 2 * kMaxPasses + 3 * a.pass;
+        unsigned long long *st = a.queue + 2 * kMaxPasses + 4 * a.pass;
         atomicAdd(st + 0, occ[0]);
         atomicAdd(st + 1, occ[1]);
         atomicAdd(st + 2, wall_clock64() - occ[2]);
+        atomicAdd(st + 3, (unsigned long long)clock64() - occ[3]);
     }
 #undef KS
 }
 
 // ---------------------------------------------------------------------------
-// Post-processing: everything of run_tracks that is independent per output sample, as four
+// Post-processing: everything of run_tracks that is independent per output sample, as three
 // loop-free kernels split by register footprint (a fused one-workgroup-per-storm kernel was
 // measured first: it ran everything at the occupancy of the gather-heavy part, idled at its
 // barriers, and let the compiler hoist ~100 libm constants into registers around its loops):
 //   k_dense  wave per storm, lane per (accepted step, component): dense-output matrix Q = K^T P
 //            (rk.py:179-181) and the sample -> step map of t_eval emission (ivp.py:706-723);
 //   k_emit   thread per sample slot: dense output (rk.py:552-574), the env-wind recompute at
-//            every emitted sample (util/compute.py:201-202), NaN padding of the reference's
-//            [n_tracks][n_steps] planes (compute.py:124-133), "any v >= 15" of accept test 1;
-//   k_vmax   thread per sample: axi_to_max_wind (wind/tc_wind.py:6-21 with
-//            util/sphere.py:15-30,58-83), "any vmax >= threshold" of accept test 2;
+//            every emitted sample (util/compute.py:201-202), axi_to_max_wind (wind/tc_wind.py:6-21
+//            with util/sphere.py:15-30,58-83), NaN padding of the reference's [n_tracks][n_steps]
+//            planes (compute.py:124-133), "any v >= 15" / "any vmax >= threshold" bits;
 //   k_flags  thread per storm: accept tests 1 and 2 (compute.py:185-189, 205).
 struct EArgs {
     tcr_params P;
@@ -571,62 +571,6 @@ __global__ __launch_bounds__(kWave) void k_dense(EArgs a, uint16_t *__restrict__
     }
 }
 
-// k_emit: thread per sample slot.  Valid sample: dense output of its step (rk.py:552-574), env
-// winds there, planes written; the rest of the row is NaN padding.
-template <bool AFFINE>
-__global__ __launch_bounds__(kPostThreads, TCR_EMIT_WPS) void k_emit(EArgs a, const uint16_t *__restrict__ sidx)
-{
-    __shared__ EvalK K;
-    const tcr_params &P = a.P;
-    const int64_t sid = blockIdx.x;
-    const int ns = P.n_steps;
-    const int i = blockIdx.y * kPostThreads + threadIdx.x;
-    const int n = a.n_valid[sid];
-    const size_t o = (size_t)sid * ns + i;
-    const double nan = __longlong_as_double(0x7ff8000000000000LL);
-    const bool live_block = (int)(blockIdx.y * kPostThreads) < n;
-    if (live_block) {
-        if (threadIdx.x == 0) make_eval_k(P, a.D, K);
-        __syncthreads();
-    }
-    if (i < n) {
-        const double *st = a.srec + (sid * (int64_t)a.max_rk_steps + sidx[o]) * kStepRec;
-        const double2 *s2 = reinterpret_cast<const double2 *>(st);
-        const double2 h0 = s2[0], y01 = s2[2], y23 = s2[3];
-        const double te = ts_at(P, i);
-        const double hh = h0.y;
-        const double x = (te - h0.x) / hh;
-        const double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
-        const double y0[4] = {y01.x, y01.y, y23.x, y23.y};
-        double ye[4];
-        for (int c = 0; c < 4; ++c) {
-            const double2 qa = s2[4 + 2 * c], qb = s2[5 + 2 * c];
-            double acc = 0.0;
-            acc += qa.x * p1; acc += qa.y * p2; acc += qb.x * p3; acc += qb.y * p4;
-            ye[c] = hh * acc + y0[c];
-        }
-        const DevSlot S = a.D.slots[a.slot[sid]];
-        double w[4];
-        env_winds<AFFINE>(K, S, a.fs + sid * ns * 4, ye[0], ye[1], te, w);
-        a.lon[o] = ye[0]; a.lat[o] = ye[1]; a.v[o] = ye[2]; a.m[o] = ye[3];
-        double2 *eo = reinterpret_cast<double2 *>(a.envw + o * 4);
-        eo[0] = make_double2(w[0], w[1]);
-        eo[1] = make_double2(w[2], w[3]);
-        if (__ballot(ye[2] >= P.v_thresh) && (threadIdx.x & 63) == (__ffsll((long long)__ballot(true)) - 1))
-            atomicOr(a.flags + sid, kBitAny15);
-    } else {
-        // NaN padding, only where the row is not known to be padded already
-        int pad_to = a.pad_state ? a.pad_state[sid] : ns;
-        pad_to = (pad_to < 0 || pad_to > ns) ? ns : pad_to;
-        if (i < pad_to) {
-            a.lon[o] = nan; a.lat[o] = nan; a.v[o] = nan; a.m[o] = nan; a.vmax[o] = nan;
-            double2 *eo = reinterpret_cast<double2 *>(a.envw + o * 4);
-            eo[0] = make_double2(nan, nan);
-            eo[1] = make_double2(nan, nan);
-        }
-    }
-}
-
 // The two haversine calls of calc_translational_speed (sphere.py:71-76, haversine :15-30) have
 // either equal latitudes or equal longitudes.  The vanishing term is sin(0)^2 = 0 (same
 // latitude) or cos(lat1)*cos(lat2)*sin(0)^2 = +-0 (same longitude, latitudes finite), and
@@ -649,38 +593,14 @@ __device__ __forceinline__ double haversine_same_lon_km(const tcr_params &P, dou
     return (P.earth_R / 1000.) * (2 * asin(sqrt(aa)));
 }
 
-// k_vmax: translation speed by centred differences -> vmax.
+// axi_to_max_wind (wind/tc_wind.py:6-21) for one sample, given its neighbours along the track.
 // tc_wind.py:17-20 turns (Ui, Vi) into an angle and back: th = arctan2(-Ui, Vi),
 // ug = v*(-sin th) + Ui*fac, vg = v*cos th + Vi*fac.  -sin(th) = Ui/|U| and cos(th) = Vi/|U| with
 // |U| = sqrt(Ui^2 + Vi^2), which the function has just computed, so the three transcendental calls
 // reduce to two divisions (|U| = 0: th = -0, i.e. (0, 1)); differs from libm's round trip by ~1 ulp.
-#ifndef TCR_VMAX_WPS
-#define TCR_VMAX_WPS 4
-#endif
-__global__ __launch_bounds__(kPostThreads, TCR_VMAX_WPS) void k_vmax(tcr_params P, const int32_t *__restrict__ n_valid,
-                                                                     const double *__restrict__ plon,
-                                                                     const double *__restrict__ plat,
-                                                                     const double *__restrict__ pv,
-                                                                     const double *__restrict__ penvw,
-                                                                     double *__restrict__ pvmax, int32_t *__restrict__ flags)
+__device__ __forceinline__ double vmax_at(const tcr_params &P, double lon, double lat, double v, double us, double vs,
+                                          double lom, double lam, double lop, double lap)
 {
-    const int64_t sid = blockIdx.x;
-    const int ns = P.n_steps;
-    const int i = blockIdx.y * kPostThreads + threadIdx.x;
-    const int n = n_valid[sid];
-    if (i >= n) return;                       // padding was written by k_emit
-    const size_t o = (size_t)sid * ns + i;
-    if (n <= 1) { pvmax[o] = __longlong_as_double(0x7ff8000000000000LL); return; }
-    const double *lo_ = plon + (size_t)sid * ns, *la_ = plat + (size_t)sid * ns;
-    const double lon = lo_[i], lat = la_[i], v = pv[o];
-    const double2 *ew = reinterpret_cast<const double2 *>(penvw + o * 4);
-    const double2 e0 = ew[0], e1 = ew[1];
-    const double us = e0.x - e1.x, vs = e0.y - e1.y;
-    // linear extrapolation at both ends (sphere.py:66-69)
-    const double lom = (i == 0) ? 2 * lon - lo_[1] : lo_[i - 1];
-    const double lam = (i == 0) ? 2 * lat - la_[1] : la_[i - 1];
-    const double lop = (i == n - 1) ? 2 * lon - lo_[n - 2] : lo_[i + 1];
-    const double lap = (i == n - 1) ? 2 * lat - la_[n - 2] : la_[i + 1];
     const double dlon = 0.5 * (sign_of(lop - lom) * haversine_same_lat_km(P, lop, lom, lat));
     const double dlat = 0.5 * (sign_of(lap - lam) * haversine_same_lon_km(P, lap, lam));
     const double ut = dlon * 1000. / P.dt_out, vt = dlat * 1000. / P.dt_out;
@@ -693,10 +613,103 @@ __global__ __launch_bounds__(kPostThreads, TCR_VMAX_WPS) void k_vmax(tcr_params 
     const double mcos = (mag == 0.0) ? 1.0 : Vi / mag;      //  cos(arctan2(-Ui, Vi))
     const double ug = v * msin + Ui * fac;
     const double vg = v * mcos + Vi * fac;
-    const double vm = sqrt(ug * ug + vg * vg);
-    pvmax[o] = vm;
-    if (__ballot(vm >= P.vmax_thresh) && (threadIdx.x & 63) == (__ffsll((long long)__ballot(true)) - 1))
-        atomicOr(flags + sid, kBitVmax);
+    return sqrt(ug * ug + vg * vg);
+}
+
+// Dense output of sample i of a storm (rk.py:552-574): y = y_old + h * Q . (x, x^2, x^3, x^4).
+template <int NC>
+__device__ __forceinline__ void dense_at(const tcr_params &P, const double *__restrict__ srec_storm,
+                                         const uint16_t *__restrict__ sidx_storm, int i, double te, double (&ye)[NC])
+{
+    const double2 *s2 = reinterpret_cast<const double2 *>(srec_storm + (size_t)sidx_storm[i] * kStepRec);
+    const double2 h0 = s2[0];
+    const double hh = h0.y;
+    const double x = (te - h0.x) / hh;
+    const double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double2 qa = s2[4 + 2 * c], qb = s2[5 + 2 * c];
+        const double y0 = (c & 1) ? s2[2 + (c >> 1)].y : s2[2 + (c >> 1)].x;
+        double acc = 0.0;
+        acc += qa.x * p1; acc += qa.y * p2; acc += qb.x * p3; acc += qb.y * p4;
+        ye[c] = hh * acc + y0;
+    }
+}
+
+// k_emit: thread per sample slot.  Valid sample: dense output of its step, env winds there,
+// vmax from the neighbouring samples (wave shuffles; the two edge lanes of a wave evaluate their
+// outside neighbour themselves), planes written; the rest of the row is NaN padding.  The gathers
+// make this kernel wait on memory ~60 % of the time, so the transcendental-heavy vmax math of
+// the same sample runs in its shadow (as a kernel of its own it cost 0.34 ms per 100k storms).
+template <bool AFFINE>
+__global__ __launch_bounds__(kPostThreads, TCR_EMIT_WPS) void k_emit(EArgs a, const uint16_t *__restrict__ sidx)
+{
+    __shared__ EvalK K;
+    const tcr_params &P = a.P;
+    const int64_t sid = blockIdx.x;
+    const int ns = P.n_steps;
+    const int i = blockIdx.y * kPostThreads + threadIdx.x;
+    const int n = a.n_valid[sid];
+    const size_t o = (size_t)sid * ns + i;
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    const bool live_block = (int)(blockIdx.y * kPostThreads) < n;
+    if (live_block) {
+        if (threadIdx.x == 0) make_eval_k(P, a.D, K);
+        __syncthreads();
+    }
+    const bool valid = i < n;
+    const double *srec_storm = a.srec + sid * (int64_t)a.max_rk_steps * kStepRec;
+    const uint16_t *sidx_storm = sidx + (size_t)sid * ns;
+    double ye[4] = {0, 0, 0, 0}, w[4] = {0, 0, 0, 0};
+    if (valid) {
+        const double te = ts_at(P, i);
+        dense_at<4>(P, srec_storm, sidx_storm, i, te, ye);
+        const DevSlot S = a.D.slots[a.slot[sid]];
+        env_winds<AFFINE>(K, S, a.fs + sid * ns * 4, ye[0], ye[1], te, w);
+        a.lon[o] = ye[0]; a.lat[o] = ye[1]; a.v[o] = ye[2]; a.m[o] = ye[3];
+        double2 *eo = reinterpret_cast<double2 *>(a.envw + o * 4);
+        eo[0] = make_double2(w[0], w[1]);
+        eo[1] = make_double2(w[2], w[3]);
+    }
+    // neighbours along the track: lanes +-1, except across the wave's edges
+    const int lane = threadIdx.x & 63;
+    double lom = __shfl_up(ye[0], 1), lam = __shfl_up(ye[1], 1);
+    double lop = __shfl_down(ye[0], 1), lap = __shfl_down(ye[1], 1);
+    if (valid && n > 1) {
+        if (lane == 0 && i > 0) {
+            double q[2];
+            dense_at<2>(P, srec_storm, sidx_storm, i - 1, ts_at(P, i - 1), q);
+            lom = q[0]; lam = q[1];
+        }
+        if (lane == 63 && i < n - 1) {
+            double q[2];
+            dense_at<2>(P, srec_storm, sidx_storm, i + 1, ts_at(P, i + 1), q);
+            lop = q[0]; lap = q[1];
+        }
+        // linear extrapolation at both ends (sphere.py:66-69): the neighbour on the other side is
+        // sample 1 / n-2, i.e. lop / lom of this very lane
+        const double lop_in = lop, lap_in = lap, lom_in = lom, lam_in = lam;
+        if (i == 0) { lom = 2 * ye[0] - lop_in; lam = 2 * ye[1] - lap_in; }
+        if (i == n - 1) { lop = 2 * ye[0] - lom_in; lap = 2 * ye[1] - lam_in; }
+        const double vm = vmax_at(P, ye[0], ye[1], ye[2], w[0] - w[2], w[1] - w[3], lom, lam, lop, lap);
+        a.vmax[o] = vm;
+        const bool hit_v = ye[2] >= P.v_thresh, hit_vm = vm >= P.vmax_thresh;
+        const int bits = (__ballot(hit_v) ? kBitAny15 : 0) | (__ballot(hit_vm) ? kBitVmax : 0);
+        if (bits && lane == (__ffsll((long long)__ballot(true)) - 1)) atomicOr(a.flags + sid, bits);
+    } else if (valid) {                                   // n == 1: no translation speed, vmax stays NaN
+        a.vmax[o] = nan;
+        if (ye[2] >= P.v_thresh) atomicOr(a.flags + sid, kBitAny15);
+    } else {
+        // NaN padding, only where the row is not known to be padded already
+        int pad_to = a.pad_state ? a.pad_state[sid] : ns;
+        pad_to = (pad_to < 0 || pad_to > ns) ? ns : pad_to;
+        if (i < pad_to) {
+            a.lon[o] = nan; a.lat[o] = nan; a.v[o] = nan; a.m[o] = nan; a.vmax[o] = nan;
+            double2 *eo = reinterpret_cast<double2 *>(a.envw + o * 4);
+            eo[0] = make_double2(nan, nan);
+            eo[1] = make_double2(nan, nan);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_flags(tcr_params P, int64_t n_storms, const int32_t *__restrict__ n_valid,

@@ -254,13 +254,14 @@ class TCEngine:
 
     def pass_stats(self):
         """Occupancy of the last integrate call's k_integrate passes (device must be idle):
-        list of dicts {requests, parked, wave_cycles, lane_cycles, wave_ms}."""
-        buf = (C.c_int64 * (5 * 16))()
+        list of dicts {requests, parked, wave_cycles, lane_cycles, wave_ms, shader_mhz}."""
+        buf = (C.c_int64 * (6 * 16))()
         n = self.L.tcr_integrate_pass_stats(self.h, buf, 16)
         if n < 0:
             self._ck(n)
-        return [dict(requests=buf[5 * p], parked=buf[5 * p + 1], wave_cycles=buf[5 * p + 2],
-                     lane_cycles=buf[5 * p + 3], wave_ms=buf[5 * p + 4] / 1e5) for p in range(n)]
+        return [dict(requests=buf[6 * p], parked=buf[6 * p + 1], wave_cycles=buf[6 * p + 2],
+                     lane_cycles=buf[6 * p + 3], wave_ms=buf[6 * p + 4] / 1e5,
+                     shader_mhz=100.0 * buf[6 * p + 5] / max(1, buf[6 * p + 4])) for p in range(n)]
 
     def sync(self, stream=None):
         self._ck(self.L.tcr_sync(self.h, C.c_void_p(stream or 0)))
