@@ -172,6 +172,7 @@ def main():
         iso = sum_timings()
         iso_counts = (acc - acc_keep).tolist()
         acc.copy_(acc_keep)
+        iso_passes = engs[0].pass_stats()
     if world > 1:
         D.allreduce_sum_(acc)
     steps_total, nfev_total, samples_total, accepted_total = (float(x) for x in acc.tolist())
@@ -205,6 +206,15 @@ def main():
                                 kernel_ms=dict(fourier=iso['fourier_ms'] / iso['calls'], integrate=ik, emit=ie),
                                 achieved=ib / (ik * 1e-3) / 1e9, frac=ib / (ik * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 emit_achieved=eb / (ie * 1e-3) / 1e9, emit_frac=eb / (ie * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        # k_integrate runs as a chain of passes (tail compaction); occupancy of the last isolated batch:
+        # wave_ms = summed wave residency, i.e. SIMD time (one integrator wave owns a SIMD's registers)
+        wc = sum(p['wave_cycles'] for p in iso_passes)
+        simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+        roof['isolated']['integrate_passes'] = dict(
+            passes=len(iso_passes), lane_utilisation=sum(p['lane_cycles'] for p in iso_passes) / max(1, 64 * wc),
+            wave_ms=sum(p['wave_ms'] for p in iso_passes), simds=simds,
+            simd_time_ms=sum(p['wave_ms'] for p in iso_passes) / simds,
+            shader_mhz_pass0=iso_passes[0]['shader_mhz'] if iso_passes else None)
 
     out = None
     if rank == 0:

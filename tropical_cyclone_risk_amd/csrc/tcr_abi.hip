@@ -189,7 +189,7 @@ DevFields dev_fields(const tcr_ctx *ctx)
     DevFields D{};
     D.wg = dev_grid(ctx->wg); D.tg = dev_grid(ctx->tg); D.hg = dev_grid(ctx->hg); D.mg = dev_grid(ctx->mg);
     D.rg = dev_grid(ctx->rg);
-    D.slots = ctx->d_slots; D.stat = ctx->d_stat;
+    D.slots = ctx->d_slots; D.n_slots = (int)ctx->slots.size(); D.stat = ctx->d_stat;
     D.run_mask = ctx->d_run_mask; D.basin_masks = ctx->d_basin_masks;
     D.all_affine = (ctx->wg.affine_lon && ctx->wg.affine_lat && ctx->tg.affine_lon && ctx->tg.affine_lat &&
                     ctx->hg.affine_lon && ctx->hg.affine_lat) ? 1 : 0;

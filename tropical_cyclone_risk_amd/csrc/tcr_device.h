@@ -61,6 +61,7 @@ struct DevSlot {
 struct DevFields {
     DevGrid wg, tg, hg, mg, rg;   // wind, thermo, static hi-res, basin masks, (uncropped) rh grid
     const DevSlot *slots;    // device array
+    int n_slots;
     const double *stat;      // [nlat_h][nlon_h][2]: land, bathy
     const uint8_t *run_mask; // [nlat_m][nlon_m]
     const uint8_t *basin_masks;   // [7][nlat_m][nlon_m]

@@ -524,6 +524,7 @@ struct EArgs {
 };
 constexpr int kBitAny15 = 1 << 8, kBitVmax = 1 << 9;     // scratch bits in flags[] between the kernels
 constexpr int kPostThreads = 128;
+constexpr int kEmitSlotCache = 32;      // field-slot wind pointers kept in LDS by k_emit
 #ifndef TCR_EMIT_WPS
 #define TCR_EMIT_WPS 3     // waves per SIMD k_emit is register-budgeted for (<= 168 VGPRs)
 #endif
@@ -616,12 +617,12 @@ __device__ __forceinline__ double vmax_at(const tcr_params &P, double lon, doubl
     return sqrt(ug * ug + vg * vg);
 }
 
-// Dense output of sample i of a storm (rk.py:552-574): y = y_old + h * Q . (x, x^2, x^3, x^4).
+// Dense output of a sample at time te inside accepted step `step` of a storm (rk.py:552-574):
+// y = y_old + h * Q . (x, x^2, x^3, x^4).
 template <int NC>
-__device__ __forceinline__ void dense_at(const tcr_params &P, const double *__restrict__ srec_storm,
-                                         const uint16_t *__restrict__ sidx_storm, int i, double te, double (&ye)[NC])
+__device__ __forceinline__ void dense_at(const double *__restrict__ srec_storm, int step, double te, double (&ye)[NC])
 {
-    const double2 *s2 = reinterpret_cast<const double2 *>(srec_storm + (size_t)sidx_storm[i] * kStepRec);
+    const double2 *s2 = reinterpret_cast<const double2 *>(srec_storm + (size_t)step * kStepRec);
     const double2 h0 = s2[0];
     const double hh = h0.y;
     const double x = (te - h0.x) / hh;
@@ -645,26 +646,32 @@ template <bool AFFINE>
 __global__ __launch_bounds__(kPostThreads, TCR_EMIT_WPS) void k_emit(EArgs a, const uint16_t *__restrict__ sidx)
 {
     __shared__ EvalK K;
+    __shared__ const double *s_wind[kEmitSlotCache];
     const tcr_params &P = a.P;
     const int64_t sid = blockIdx.x;
     const int ns = P.n_steps;
     const int i = blockIdx.y * kPostThreads + threadIdx.x;
+    // the three per-storm / per-sample indices are independent loads: one round trip, not three
     const int n = a.n_valid[sid];
+    const int slot_id = a.slot[sid];
+    const uint16_t *sidx_storm = sidx + (size_t)sid * ns;
+    const int my_step = (i < ns) ? sidx_storm[i] : 0;          // meaningful only if i < n
     const size_t o = (size_t)sid * ns + i;
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     const bool live_block = (int)(blockIdx.y * kPostThreads) < n;
     if (live_block) {
         if (threadIdx.x == 0) make_eval_k(P, a.D, K);
+        if (threadIdx.x < kEmitSlotCache && (int)threadIdx.x < a.D.n_slots) s_wind[threadIdx.x] = a.D.slots[threadIdx.x].wind;
         __syncthreads();
     }
     const bool valid = i < n;
     const double *srec_storm = a.srec + sid * (int64_t)a.max_rk_steps * kStepRec;
-    const uint16_t *sidx_storm = sidx + (size_t)sid * ns;
     double ye[4] = {0, 0, 0, 0}, w[4] = {0, 0, 0, 0};
     if (valid) {
         const double te = ts_at(P, i);
-        dense_at<4>(P, srec_storm, sidx_storm, i, te, ye);
-        const DevSlot S = a.D.slots[a.slot[sid]];
+        dense_at<4>(srec_storm, my_step, te, ye);
+        DevSlot S{};
+        S.wind = (slot_id < kEmitSlotCache) ? s_wind[slot_id] : a.D.slots[slot_id].wind;
         env_winds<AFFINE>(K, S, a.fs + sid * ns * 4, ye[0], ye[1], te, w);
         a.lon[o] = ye[0]; a.lat[o] = ye[1]; a.v[o] = ye[2]; a.m[o] = ye[3];
         double2 *eo = reinterpret_cast<double2 *>(a.envw + o * 4);
@@ -678,12 +685,12 @@ __global__ __launch_bounds__(kPostThreads, TCR_EMIT_WPS) void k_emit(EArgs a, co
     if (valid && n > 1) {
         if (lane == 0 && i > 0) {
             double q[2];
-            dense_at<2>(P, srec_storm, sidx_storm, i - 1, ts_at(P, i - 1), q);
+            dense_at<2>(srec_storm, sidx_storm[i - 1], ts_at(P, i - 1), q);
             lom = q[0]; lam = q[1];
         }
         if (lane == 63 && i < n - 1) {
             double q[2];
-            dense_at<2>(P, srec_storm, sidx_storm, i + 1, ts_at(P, i + 1), q);
+            dense_at<2>(srec_storm, sidx_storm[i + 1], ts_at(P, i + 1), q);
             lop = q[0]; lap = q[1];
         }
         // linear extrapolation at both ends (sphere.py:66-69): the neighbour on the other side is
