@@ -258,20 +258,23 @@ unsigned integrate_waves(const tcr_ctx *ctx, int64_t n)
 }
 
 // Tail compaction of k_integrate: a wave parks its storms once fewer than this many lanes are
-// live and the queue is empty (TCR_PARK=0 disables the chain: one launch runs every storm to its end).
-constexpr size_t kQueueWords = 6 * kMaxPasses;     // heads, parked counts, 4 occupancy counters per pass
-unsigned park_final_waves()               // a pass this small runs to the end
-{
-    if (const char *e = getenv("TCR_PARK_FINAL")) { const long v = atol(e); if (v > 0) return (unsigned)v; }
-    return 8;
-}
-int park_threshold()
+// live and the queue is empty.  Only worth it when the launch fills the chip (one wave per SIMD):
+// it trades latency of the chain (pass barriers) for SIMD time, and SIMD time is only scarce then.
+// TCR_PARK=0 disables the chain (one launch runs every storm to its end), TCR_PARK=k forces k.
+int park_threshold(const tcr_ctx *ctx, unsigned waves)
 {
     if (const char *e = getenv("TCR_PARK")) {
         const long v = atol(e);
         return v <= 0 ? 0 : (v > 63 ? 63 : (int)v);
     }
-    return 32;
+    return waves >= (unsigned)ctx->cu_count * 4u ? 32 : 0;
+}
+
+constexpr size_t kQueueWords = 6 * kMaxPasses;     // heads, parked counts, 4 occupancy counters per pass
+unsigned park_final_waves()               // a pass this small runs to the end
+{
+    if (const char *e = getenv("TCR_PARK_FINAL")) { const long v = atol(e); if (v > 0) return (unsigned)v; }
+    return 8;
 }
 
 struct DevBuf {
@@ -575,7 +578,7 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
         // Chain of launches with tail compaction (k_integrate): a pass parks the storms of waves that
         // fall under `thr` live lanes, the next pass needs at most waves*(thr-1)/64 waves for them.
         unsigned waves = integrate_waves(ctx, n);
-        const int thr = park_threshold();
+        const int thr = park_threshold(ctx, waves);
         const unsigned final_waves = park_final_waves();
         if (thr > 0 && grow(ctx, &ctx->d_park[0], &ctx->park_cap[0], (size_t)waves * kWave * kParkRec)) return -1;
         if (thr > 0 && grow(ctx, &ctx->d_park[1], &ctx->park_cap[1], (size_t)waves * kWave * kParkRec)) return -1;
