@@ -192,6 +192,11 @@ def main():
     traffic = args.traffic if args.traffic is not None else measured_traffic('tcr::k_integrate<true>', B)
     roof = dict(bound='hbm', kernel='k_integrate', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
                 frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                # a "launch" of k_integrate is the chain of passes of one batch (tail compaction); with several
+                # streams its event-bracketed duration includes time shared with other batches (see `isolated`)
+                sustained=dict(note='algorithmic bytes of all k_integrate launches / wall time of the timed region',
+                               achieved=BYTES_PER_RHS * nfev_total / world / dt / 1e9,
+                               frac=BYTES_PER_RHS * nfev_total / world / dt / 1e9 / HBM_PEAK_GBS),
                 algorithmic_bytes_per_launch=int_bytes, launch_ms=k_ms,
                 kernel_ms=dict(fourier=ms['fourier_ms'] / launches, integrate=k_ms, emit=e_ms),
                 emit=dict(kernel='k_emit', achieved=emit_bytes / (e_ms * 1e-3) / 1e9,
@@ -245,13 +250,14 @@ def main():
 
 
 def measured_traffic(kernel, storms):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/, collected
-    separately from timing as MI355X_MICROARCH.md prescribes); only valid for the profiled size."""
+    """HBM bytes per batch (for k_integrate: summed over the passes of its chain) from the committed
+    rocprofv3 --pmc runs (profiles/, tools/collect_profiles.sh; collected separately from timing as
+    MI355X_MICROARCH.md prescribes); only valid for the profiled size."""
     fn = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm.json')
     if storms != 100_000 or not os.path.exists(fn):
         return None
     try:
-        return json.load(open(fn))['kernels'][kernel]['hbm_bytes_per_launch_raw']
+        return json.load(open(fn))['kernels'][kernel]['hbm_bytes_per_batch_raw']
     except Exception:
         return None
 
