@@ -72,18 +72,20 @@ def allgather_counts(count):
     return [int(x) for x in buf.tolist()]
 
 
-def allgather_rows(rows, count, counts=None, async_op=False):
+def allgather_rows(rows, count, counts=None, async_op=False, concat=True):
     """All-gather variable-length row blocks.
 
     rows  : [cap, width] tensor whose first ``count`` rows are valid (cap may differ
             per rank; only ``max(counts)`` rows are sent)
     Returns (gathered [sum(counts), width] in rank order, counts) — or, with
     ``async_op=True``, (work handle, finish()) where finish() returns that pair.
+    ``concat=False`` skips the compaction copy: the first element is then the list of
+    per-rank views into the receive buffer.
     """
     counts = allgather_counts(count) if counts is None else counts
     w = world()
     if w == 1:
-        out = rows[:counts[0]]
+        out = rows[:counts[0]] if concat else [rows[:counts[0]]]
         return ((None, lambda: (out, counts)) if async_op else (out, counts))
     m = max(counts)
     width = rows.shape[1]
@@ -99,7 +101,7 @@ def allgather_rows(rows, count, counts=None, async_op=False):
         if work is not None and async_op:
             work.wait()
         parts = [recv[r * m: r * m + counts[r]] for r in range(w)]
-        return torch.cat(parts, dim=0), counts
+        return (torch.cat(parts, dim=0) if concat else parts), counts
     return (work, finish) if async_op else finish()
 
 
