@@ -1,4 +1,5 @@
 """Host logic against reference known-answer vectors (tests/golden/units.npz). CPU only."""
+import datetime
 import os
 
 import numpy as np
@@ -101,3 +102,73 @@ def test_track_file_schema_roundtrip(tmp_path):
     assert np.array_equal(d['u850_trks'], np.concatenate([out[0][5][:, :, 2], out[1][5][:, :, 2]]))
     assert list(d['tc_basins'][:2]) == ['NA', 'EP'] and list(d['basin']) == ['AU', 'EP', 'NA', 'NI', 'SI', 'SP', 'WP']
     assert list(d['tc_years']) == [2001] * 4 + [2002] * 6 and d['time'][1] == 3600.0
+
+
+# ---- input-field loader: the reference's file schema, NetCDF-3 round trip
+def _small_env():
+    from tropical_cyclone_risk_amd import synthetic
+    env = synthetic.make_env('gfdl', seed=7)          # two different grids (wind 2x2.5, thermo 1x1.25)
+    # thin the 0.25-degree static grid: the loader does not care and the files stay small
+    env.hlon, env.hlat = env.hlon[::4], env.hlat[::4]
+    env.land, env.bathy = env.land[::4, ::4], env.bathy[::4, ::4]
+    env.basin_masks = {k: v[::4, ::4] for k, v in env.basin_masks.items()}
+    return env
+
+
+@pytest.mark.parametrize('calendar', ['standard', 'noleap'])
+def test_field_loader_round_trip(tmp_path, calendar):
+    from tropical_cyclone_risk_amd import fields, namelist
+    env = _small_env()
+    files = fields.write_reference_files(env, str(tmp_path), 2003, namelist, calendar=calendar)
+    got = fields.load_year_env(2003, namelist, files)
+    for k in ('lon', 'lat', 'wlon', 'wlat', 'hlon', 'hlat', 'land', 'bathy', 'rh_mid', 'wnd_mean', 'wnd_cov', 'mld', 'strat'):
+        np.testing.assert_allclose(getattr(got, k), getattr(env, k), rtol=1e-13, atol=1e-13, err_msg=k)
+    # vmax is stored without the PI_reduc * sqrt(Ck/Cd) factor, chi before compute.py:113-115's transform
+    np.testing.assert_allclose(got.vpot, env.vpot, rtol=1e-13, atol=1e-13)
+    inside = (env.chi > 1e-5 + namelist.chi_fac) & (env.chi < 5)
+    np.testing.assert_allclose(got.chi[inside], env.chi[inside], rtol=1e-12)
+    assert sorted(got.basin_masks) == sorted(env.basin_masks)
+    for b in env.basin_masks:
+        assert np.array_equal(got.basin_masks[b], env.basin_masks[b])
+
+
+def test_field_loader_time_semantics(tmp_path):
+    """Monthly records stamped on the 1st: the 15th of each month is a blend of two records and
+    December falls off the end of the year's slice -> vpot 0, chi 5 -> transform (compute.py:70-71, 108-113)."""
+    from scipy.io import netcdf_file
+    from tropical_cyclone_risk_amd import fields, namelist
+    env = _small_env()
+    files = fields.write_reference_files(env, str(tmp_path), 2003, namelist)
+    fn = str(tmp_path / 'thermo_first.nc')
+    lat, lon = env.lat[::-1], env.lon                       # descending latitude, as ERA5 delivers it
+    days = np.array([(datetime.date(2003, m, 1) - datetime.date(2002, 1, 1)).days for m in range(1, 13)], dtype=float)
+    vm = np.arange(12, dtype=float)[:, None, None] * 10 + np.zeros((12, len(lat), len(lon)))
+    with netcdf_file(fn, 'w', version=2) as f:
+        f.createDimension('time', 12); f.createDimension('lat', len(lat)); f.createDimension('lon', len(lon))
+        v = f.createVariable('time', 'd', ('time',)); v[:] = days; v.units = 'days since 2002-01-01'
+        for name, arr in (('lat', lat), ('lon', lon)):
+            v = f.createVariable(name, 'd', (name,)); v[:] = arr
+        for name in ('vmax', 'rh_mid', 'chi'):
+            v = f.createVariable(name, 'd', ('time', 'lat', 'lon')); v[:] = vm if name == 'vmax' else vm * 0 + 0.7
+    files['thermo'] = fn
+    got = fields.load_year_env(2003, namelist, files)
+    assert np.array_equal(got.lat, env.lat)                 # flipped to ascending
+    fac = namelist.PI_reduc * np.sqrt(namelist.Ck / namelist.Cd)
+    assert abs(got.vpot[0, 3, 3] - fac * 10 * 14 / 31) < 1e-12          # Jan 15 between Jan 1 (0) and Feb 1 (10)
+    assert abs(got.vpot[1, 3, 3] - fac * (10 + 10 * 14 / 28)) < 1e-12
+    assert np.all(got.vpot[11] == 0.0)                                   # Dec 15 is past the last record
+    assert np.allclose(got.chi[11], min(max(np.exp(np.log(5 + 1e-3) + namelist.log_chi_fac) + namelist.chi_fac, 1e-5), 5))
+    assert np.isnan(got.rh_mid[11]).all()
+
+
+def test_field_loader_rejects_hdf5_without_xarray(tmp_path):
+    from tropical_cyclone_risk_amd import fields
+    try:
+        import xarray  # noqa: F401
+        pytest.skip('xarray is installed')
+    except ImportError:
+        pass
+    fn = tmp_path / 'x.nc'
+    fn.write_bytes(b'\x89HDF\r\n\x1a\n' + b'\0' * 64)
+    with pytest.raises(RuntimeError, match='not NetCDF-3'):
+        fields._Dataset(str(fn))

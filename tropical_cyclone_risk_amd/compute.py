@@ -58,7 +58,7 @@ def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000):
         # ---- the data-path collective: all-gather of this round's survivor records
         meta = np.stack([np.asarray(out['acc_cand'], dtype=np.float64), np.asarray(out['acc_month'], dtype=np.float64),
                          np.asarray(out['acc_basin'], dtype=np.float64)], axis=1) if a else np.zeros((0, 3))
-        rows = np.concatenate([np.asarray(out['acc_rows'], dtype=np.float64).reshape(a, -1), meta], axis=1)
+        rows = np.concatenate([np.asarray(out['acc_rows'], dtype=np.float64).reshape(a, 9 * n_steps), meta], axis=1)
         t_rows = torch.from_numpy(np.ascontiguousarray(rows)).to(dev)
         cnt = torch.tensor([a], dtype=torch.int64, device=dev)
         gathered, counts = D.allgather_rows(t_rows, cnt)

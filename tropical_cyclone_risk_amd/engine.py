@@ -157,7 +157,8 @@ class TCEngine:
             self.stage_month(mo, env.wlon, env.wlat, env.wnd_mean[mo], env.wnd_cov[mo], env.lon, env.lat,
                              env.vpot[mo], env.chi[mo], env.mld[mo], env.strat[mo], env.rh_mid[mo])
         if getattr(env, 'basin_masks', None):
-            self.stage_masks(env.hlon, env.hlat, env.basin_masks[self.basin.basin_id], env.basin_masks)
+            self.stage_masks(getattr(env, 'mlon', env.hlon), getattr(env, 'mlat', env.hlat),
+                             env.basin_masks[self.basin.basin_id], env.basin_masks)
         return self
 
     # -------------------------------------------------------------- hot path

@@ -121,13 +121,12 @@ def write_tracks(out, years, b, nl, out_dir=None):
     return fn
 
 
-def load_env(nl):
-    """Environment for run_downscaling.  ``dataset_type = 'SYNTHETIC'`` (or no xarray) selects the
-    regenerated ERA5-shaped fields; real ERA5/CMIP6 input needs xarray + the reference's
-    preprocessed ``env_wnd_*.nc`` / ``thermo_*.nc`` files and is the next row of SURVEY §8f."""
+def load_env(nl, year=None, files=None):
+    """Environment for run_downscaling.  ``dataset_type = 'SYNTHETIC'`` selects the regenerated
+    ERA5-shaped fields; anything else reads the reference's preprocessed files for ``year``
+    (`fields.load_year_env`: thermo_*.nc, env_wnd_*.nc, climatologies, land/bathymetry, basin masks)."""
     from . import synthetic
-    if getattr(nl, 'dataset_type', '').upper() == 'SYNTHETIC' or _try_xarray() is None:
+    if getattr(nl, 'dataset_type', '').upper() == 'SYNTHETIC':
         return synthetic.make_env('era5', seed=getattr(nl, 'gpu_experiment_seed', 20250614))
-    raise NotImplementedError(
-        'reading %s fields needs the NetCDF field loader (SURVEY.md §8 f-1), not built yet; '
-        'set namelist.dataset_type = "SYNTHETIC" to run on regenerated ERA5-shaped fields' % nl.dataset_type)
+    from . import fields
+    return fields.FileEnvironment(nl, files) if year is None else fields.load_year_env(year, nl, files)
