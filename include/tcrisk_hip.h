@@ -195,6 +195,18 @@ int tcr_stats_dev(tcr_ctx *ctx, int64_t n, const tcr_tracks *tracks_dev, uint64_
 int tcr_pack_tracks_dev(tcr_ctx *ctx, const tcr_tracks *src_dev, const int32_t *idx_dev,
                         const int64_t *count_dev, int64_t cap, double *packed_dev, void *stream);
 
+/* ---- preprocessing next to the path ----------------------- */
+/* replaces: calc_wnd_stat (track/env_wind.py:180-228) for one month: wnd[c] = ua250, va250,
+ * ua850, va850 as [n_samples][n_points] planes (points = the flattened lat x lon grid); day_start
+ * (NULL: samples are days) holds n_days + 1 sample offsets of the calendar days of a sub-daily
+ * record (the reference's groupby("time.day").mean).  out = [14][n_points]: 4 means, then the lower
+ * triangle of the covariance row by row, variances with ddof 0 and covariances with ddof 1 exactly as
+ * the reference's .var / xr.cov give them.  _dev: device pointers, asynchronous on `stream`. */
+int tcr_wind_stats_dev(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const double *const wnd[4],
+                       const int32_t *day_start, int32_t n_days, double *out, void *stream);
+int tcr_wind_stats_host(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const double *const wnd[4],
+                        const int32_t *day_start, int32_t n_days, double *out);
+
 /* ---- single-point probes (parity tests of the seam's leaf methods) -------- */
 /* replaces: Coupled_FAST.dydt (coupled_fast.py:196-207), ._env_winds
  * (bam_track.py:116-128) and ._calc_alpha (coupled_fast.py:65-94) at n points

@@ -270,3 +270,36 @@ def test_pad_state_reuse_is_bit_identical(golden_env, built_lib):
         assert np.array_equal(got['flags'], ref['flags'])
         del fresh
     eng.close()
+
+
+def test_wind_stats_kernel_vs_oracle(built_lib):
+    """k_wind_stats against the NumPy restatement — fp64 inputs, sums in day order on both
+    sides, so bit for bit; plus the host mirror of calc_wnd_stat (month mask, levels, grouping rule)."""
+    import datetime
+    from oracle import wind_stats as ws
+    from tropical_cyclone_risk_amd import preprocess as pp
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    rng = np.random.default_rng(11)
+    eng = TCEngine('GL', device=0)
+    planes = [rng.normal(5 * c, 3 + c, size=(31, 91, 180)) for c in range(4)]
+    got = eng.wind_stats(planes)
+    assert np.array_equal(got, ws.wind_stats(planes))
+    # sub-daily record with ragged days
+    ds = np.array([0, 3, 4, 8, 12, 13, 17, 21, 25, 31], dtype=np.int32)
+    assert np.array_equal(eng.wind_stats(planes, ds), ws.wind_stats(planes, ds))
+    # covariance matrix is symmetric positive semi-definite up to the ddof mix: check the diagonal dominates
+    assert (got[4] > 0).all() and (got[6] > 0).all()
+    # calc_wnd_stat: 6-hourly record over two months, 3 levels in Pa
+    times = [datetime.datetime(2001, 1, 25) + datetime.timedelta(hours=6 * k) for k in range(80)]
+    ua = rng.normal(size=(80, 3, 20, 30)).astype(np.float32)
+    va = rng.normal(size=(80, 3, 20, 30)).astype(np.float32)
+    lev = [85000, 50000, 25000]
+    out = pp.calc_wnd_stat(eng, ua, va, lev, 'Pa', times, 2001, 2)
+    keep = pp.month_mask(times, 2001, 2)
+    sel = [ua[keep][:, 2], va[keep][:, 2], ua[keep][:, 0], va[keep][:, 0]]
+    assert np.array_equal(out, ws.wind_stats(sel))                                  # the reference's `< 0` test: no grouping
+    out_d = pp.calc_wnd_stat(eng, ua, va, lev, 'Pa', times, 2001, 2, group_days=True)
+    assert np.array_equal(out_d, ws.wind_stats(sel, pp.day_groups([t for t, k in zip(times, keep) if k])))
+    with pytest.raises(Exception, match='at least two days'):
+        eng.wind_stats([p[:1] for p in planes])
+    eng.close()

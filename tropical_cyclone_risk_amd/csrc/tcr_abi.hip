@@ -14,6 +14,7 @@
 #include "tcr_kernels.hip"
 #include "tcr_seed.hip"
 #include "tcr_compact.hip"
+#include "tcr_prep.hip"
 
 using namespace tcr;
 
@@ -670,6 +671,47 @@ int tcr_fourier_table_host(tcr_ctx *ctx, int64_t n, const double *phases, double
     for (int64_t s = 0; s < n; ++s)
         for (size_t i = 0; i < ns; ++i)
             for (int k = 0; k < 4; ++k) Fs[((size_t)s * 4 + k) * ns + i] = h[((size_t)s * ns + i) * 4 + k];
+    return 0;
+}
+
+int tcr_wind_stats_dev(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const double *const wnd[4],
+                       const int32_t *day_start, int32_t n_days, double *out, void *stream_)
+{
+    if (!ctx) return -1;
+    if (!wnd || !out || n_samples <= 0 || n_points <= 0) return fail(ctx, "tcr_wind_stats_dev: bad argument");
+    if (!day_start) n_days = (int32_t)n_samples;
+    if (n_days < 2) return fail(ctx, "tcr_wind_stats_dev: a covariance needs at least two days");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    WindStatArgs a{};
+    for (int c = 0; c < 4; ++c) a.w[c] = wnd[c];
+    a.day_start = day_start; a.n_days = n_days; a.n_points = n_points; a.out = out;
+    hipEvent_t *ev = nullptr;
+    if (ctx->timing && timing_events(ctx, &ev)) return -1;
+    if (ev) { HIPCHK(ctx, hipEventRecord(ev[0], st)); HIPCHK(ctx, hipEventRecord(ev[1], st)); }
+    hipLaunchKernelGGL(k_wind_stats, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, st, a);
+    if (ev) { HIPCHK(ctx, hipEventRecord(ev[2], st)); HIPCHK(ctx, hipEventRecord(ev[3], st)); }
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+int tcr_wind_stats_host(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const double *const wnd[4],
+                        const int32_t *day_start, int32_t n_days, double *out)
+{
+    if (!ctx) return -1;
+    if (!wnd || !out || n_samples <= 0 || n_points <= 0) return fail(ctx, "tcr_wind_stats_host: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevBuf B;
+    const double *d_w[4];
+    for (int c = 0; c < 4; ++c)
+        if (!(d_w[c] = B.put(wnd[c], (size_t)n_samples * n_points))) return fail(ctx, "tcr_wind_stats_host: device allocation failed");
+    const int32_t *d_ds = nullptr;
+    if (day_start && !(d_ds = B.put(day_start, (size_t)n_days + 1))) return fail(ctx, "tcr_wind_stats_host: device allocation failed");
+    double *d_out = B.get<double>((size_t)14 * n_points);
+    if (!d_out) return fail(ctx, "tcr_wind_stats_host: device allocation failed");
+    if (tcr_wind_stats_dev(ctx, n_samples, n_points, d_w, d_ds, n_days, d_out, ctx->stream)) return -1;
+    HIPCHK(ctx, hipMemcpyAsync(out, d_out, sizeof(double) * 14 * (size_t)n_points, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 

@@ -253,6 +253,11 @@ class TCEngine:
         self._ck(self.L.tcr_timing_sum(self.h, ms, C.byref(n)))
         return dict(fourier_ms=ms[0], integrate_ms=ms[1], post_ms=ms[2], calls=int(n.value))
 
+    def wind_stats(self, planes, day_start=None):
+        """Monthly wind mean / covariance (env_wind.py:180-228) of 4 [n_samples, ...] planes -> [14, ...]."""
+        from . import preprocess
+        return preprocess.wind_stats_host(self, planes, day_start)
+
     def pass_stats(self):
         """Occupancy of the last integrate call's k_integrate passes (device must be idle):
         list of dicts {requests, parked, wave_cycles, lane_cycles, wave_ms, shader_mhz}."""

@@ -1,0 +1,80 @@
+"""Preprocessing next to the hot path: monthly wind mean / covariance on the GPU.
+
+Host mirror of `track/env_wind.calc_wnd_stat(ua, va, dt)` (env_wind.py:180-228) over plain arrays:
+the month mask (:184-190), the pressure-level pick by units (:192-196), the optional per-day
+averaging (:198-206) and the stacking order of the 14 statistics (:226-229) are host logic; the
+reduction itself is `k_wind_stats` (csrc/tcr_prep.hip) behind `tcr_wind_stats_*`.
+
+Two things of the reference are reproduced on purpose and named:
+  * variances use ddof = 0 (`.var`) but covariances ddof = 1 (`xr.cov`);
+  * `dt_step = 1 day - step` is tested with `< 0`, so the per-day averaging only happens for records
+    *coarser* than daily — sub-daily records are reduced sample by sample (group_days='reference').
+    group_days=True gives what the comment in the reference says (daily means first).
+Inputs are converted to float64; the reference inherits float32 from ERA5 files, so its own numbers
+carry ~1e-7 relative rounding that this path does not.
+"""
+import ctypes as C
+import datetime
+
+import numpy as np
+
+from . import _lib
+
+MEAN_NAMES = ['ua250_Mean', 'va250_Mean', 'ua850_Mean', 'va850_Mean']
+
+
+def month_mask(times, year, month):
+    """env_wind.py:184-190: samples in [first of the month, first of the next month)."""
+    t0 = datetime.datetime(year, month, 1)
+    t1 = datetime.datetime(year + 1, 1, 1) if month == 12 else datetime.datetime(year, month + 1, 1)
+    return np.array([(t >= t0) and (t < t1) for t in times], dtype=bool)
+
+
+def pick_levels(levels, units):
+    """env_wind.py:192-196: 250 / 850 in hPa or 25000 / 85000 in Pa; returns (i_upper, i_lower)."""
+    levels = np.asarray(levels)
+    up, lo = (250, 850) if units in ('millibars', 'hPa') else (25000, 85000)
+    iu, il = np.where(levels == up)[0], np.where(levels == lo)[0]
+    if len(iu) != 1 or len(il) != 1:
+        raise KeyError('levels %s do not contain %s and %s' % (levels, up, lo))
+    return int(iu[0]), int(il[0])
+
+
+def day_groups(times):
+    """Sample offsets of the calendar days of a time-sorted month (groupby("time.day"))."""
+    days = np.array([t.day for t in times])
+    start = [0] + [i for i in range(1, len(days)) if days[i] != days[i - 1]] + [len(days)]
+    return np.asarray(start, dtype=np.int32)
+
+
+def calc_wnd_stat(engine, ua, va, levels, level_units, times, year, month, group_days='reference'):
+    """ua, va: [time, level, lat, lon]; times: datetimes (sorted).  Returns wnd_stats [14, lat, lon]."""
+    ua, va = np.asarray(ua), np.asarray(va)
+    keep = month_mask(times, year, month)
+    t_sel = [t for t, k in zip(times, keep) if k]
+    iu, il = pick_levels(levels, level_units)
+    planes = [np.ascontiguousarray(a[keep][:, lev], dtype=np.float64)
+              for a, lev in ((ua, iu), (va, iu), (ua, il), (va, il))]
+    step = (times[1] - times[0]).total_seconds()
+    if group_days == 'reference':
+        group_days = (86400.0 - step) < 0          # env_wind.py:198-199, as written
+    ds = day_groups(t_sel) if group_days else None
+    return engine.wind_stats(planes, ds)
+
+
+def wind_stats_host(engine, planes, day_start=None):
+    """planes: 4 float64 arrays [n_samples, ...] (same trailing shape) -> [14, ...]."""
+    planes = [np.ascontiguousarray(p, dtype=np.float64) for p in planes]
+    n = planes[0].shape[0]
+    shape = planes[0].shape[1:]
+    npts = int(np.prod(shape))
+    for p in planes:
+        if p.shape != planes[0].shape:
+            raise ValueError('the four wind components must have the same shape')
+    out = np.empty((14,) + shape)
+    ptrs = (C.c_void_p * 4)(*[p.ctypes.data for p in planes])
+    ds = None if day_start is None else np.ascontiguousarray(day_start, dtype=np.int32)
+    nd = 0 if ds is None else len(ds) - 1
+    engine._ck(engine.L.tcr_wind_stats_host(engine.h, n, npts, ptrs, None if ds is None else ds.ctypes.data, nd,
+                                            out.ctypes.data))
+    return out
