@@ -207,6 +207,24 @@ int tcr_wind_stats_dev(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const 
 int tcr_wind_stats_host(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const double *const wnd[4],
                         const int32_t *day_start, int32_t n_days, double *out);
 
+/* ---- thermodynamic preprocessing ---------------------------- */
+/* replaces: np.load(thermo/entropy_table.npz) in CAPE_PI_vectorized (thermo/thermo.py:272-277):
+ * T[np][ns] over ascending pressure (Pa) and entropy (J/kg/K) axes. */
+int tcr_entropy_table_upload(tcr_ctx *ctx, int32_t np, int32_t ns, const double *p, const double *s, const double *T);
+/* replaces: thermo.CAPE_PI_vectorized(sst, p_surf, p_env, T_env, r_env) (thermo/thermo.py:266-412;
+ * select_thermo = 1, select_interp = 2) for n_points columns: p_env[n_lev] in Pa from the lowest level up,
+ * T_env / r_env as [n_lev][n_points] planes, ck_over_cd = namelist.Ck / namelist.Cd; pi[n_points] in m/s. */
+int tcr_potential_intensity_host(tcr_ctx *ctx, int64_t n_points, int32_t n_lev, const double *p_env,
+                                 const double *sst, const double *psl, const double *T_env, const double *r_env,
+                                 double ck_over_cd, double *pi);
+int tcr_potential_intensity_dev(tcr_ctx *ctx, int64_t n_points, int32_t n_lev, const double *p_env,
+                                const double *sst, const double *psl, const double *T_env, const double *r_env,
+                                double ck_over_cd, double *pi, void *stream);
+/* replaces: thermo.sat_deficit (thermo/thermo.py:92-104, unclipped) and thermo.conv_q_to_rh (:41-46) at the
+ * mid level p_mid (Pa), as thermo/calc_thermo.py:66-74 calls them. */
+int tcr_chi_rh_host(tcr_ctx *ctx, int64_t n_points, const double *sst, const double *psl, const double *T_mid,
+                    const double *q_mid, double p_mid, double *chi, double *rh_mid);
+
 /* ---- single-point probes (parity tests of the seam's leaf methods) -------- */
 /* replaces: Coupled_FAST.dydt (coupled_fast.py:196-207), ._env_winds
  * (bam_track.py:116-128) and ._calc_alpha (coupled_fast.py:65-94) at n points

@@ -25,7 +25,8 @@ EXPORTS = ('tcr_abi_version', 'tcr_ctx_create', 'tcr_ctx_destroy', 'tcr_last_err
            'tcr_integrate_host', 'tcr_integrate_dev', 'tcr_seed_dev', 'tcr_seed_host',
            'tcr_probe_rhs_host', 'tcr_fourier_table_host', 'tcr_timing_enable',
            'tcr_timing_last', 'tcr_timing_sum', 'tcr_sync', 'tcr_compact_dev',
-           'tcr_gather_seeds_dev', 'tcr_pack_tracks_dev', 'tcr_stats_dev', 'tcr_integrate_pass_stats', 'tcr_wind_stats_dev', 'tcr_wind_stats_host')
+           'tcr_gather_seeds_dev', 'tcr_pack_tracks_dev', 'tcr_stats_dev', 'tcr_integrate_pass_stats', 'tcr_wind_stats_dev', 'tcr_wind_stats_host', 'tcr_entropy_table_upload',
+           'tcr_potential_intensity_host', 'tcr_potential_intensity_dev', 'tcr_chi_rh_host')
 
 
 class Grid(C.Structure):
@@ -140,6 +141,10 @@ def lib():
     L.tcr_integrate_pass_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int]
     L.tcr_wind_stats_dev.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_void_p, C.c_int32,
                                      C.c_void_p, C.c_void_p]
+    L.tcr_entropy_table_upload.argtypes = [C.c_void_p, C.c_int32, C.c_int32, DP, DP, DP]
+    L.tcr_potential_intensity_host.argtypes = [C.c_void_p, C.c_int64, C.c_int32, DP, DP, DP, DP, DP, C.c_double, DP]
+    L.tcr_potential_intensity_dev.argtypes = [C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 5 + [C.c_double, C.c_void_p, C.c_void_p]
+    L.tcr_chi_rh_host.argtypes = [C.c_void_p, C.c_int64, DP, DP, DP, DP, C.c_double, DP, DP]
     L.tcr_wind_stats_host.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_void_p, C.c_int32,
                                       C.c_void_p]
     L.tcr_compact_dev.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64,

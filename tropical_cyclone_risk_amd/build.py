@@ -13,7 +13,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 OUT = os.path.join(PKG, 'libtcrisk_hip.so')
-SOURCES = ['tcr_abi.hip', 'tcr_kernels.hip', 'tcr_seed.hip', 'tcr_compact.hip', 'tcr_prep.hip', 'tcr_device.h',
+SOURCES = ['tcr_abi.hip', 'tcr_kernels.hip', 'tcr_seed.hip', 'tcr_compact.hip', 'tcr_prep.hip', 'tcr_thermo.hip', 'tcr_device.h',
            os.path.join('..', '..', 'include', 'tcrisk_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-DTCR_OPAQUE_K', '-fPIC', '-shared']
 

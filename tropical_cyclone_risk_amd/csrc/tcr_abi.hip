@@ -15,6 +15,7 @@
 #include "tcr_seed.hip"
 #include "tcr_compact.hip"
 #include "tcr_prep.hip"
+#include "tcr_thermo.hip"
 
 using namespace tcr;
 
@@ -76,6 +77,8 @@ struct tcr_ctx {
     double *d_park[2] = {nullptr, nullptr};     // ping-pong lists of parked storms
     size_t park_cap[2] = {0, 0};
     double2 *d_sc_table = nullptr;              // one period of (sin, cos)(2π j / period)
+    double *d_tab = nullptr;                    // entropy table: p[np], s[ns], T[np][ns]
+    int tab_np = 0, tab_ns = 0;
     double2 *d_pf = nullptr;                    // weighted phase factors [n][n_series][4] of the periodic Fourier kernel
     size_t pf_cap = 0;
     int fs_period = 0;                          // 0: direct Fourier kernel
@@ -345,7 +348,7 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_run_mask); (void)hipFree(ctx->d_basin_masks);
     (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_srec);
     for (auto &ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
-    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf);
+    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_tab);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -671,6 +674,83 @@ int tcr_fourier_table_host(tcr_ctx *ctx, int64_t n, const double *phases, double
     for (int64_t s = 0; s < n; ++s)
         for (size_t i = 0; i < ns; ++i)
             for (int k = 0; k < 4; ++k) Fs[((size_t)s * 4 + k) * ns + i] = h[((size_t)s * ns + i) * 4 + k];
+    return 0;
+}
+
+int tcr_entropy_table_upload(tcr_ctx *ctx, int32_t np, int32_t ns, const double *p, const double *s, const double *T)
+{
+    if (!ctx) return -1;
+    if (np < 2 || ns < 2 || !p || !s || !T) return fail(ctx, "tcr_entropy_table_upload: bad argument");
+    for (int i = 1; i < np; ++i) if (!(p[i] > p[i - 1])) return fail(ctx, "tcr_entropy_table_upload: pressure axis must ascend");
+    for (int i = 1; i < ns; ++i) if (!(s[i] > s[i - 1])) return fail(ctx, "tcr_entropy_table_upload: entropy axis must ascend");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->d_tab) HIPCHK(ctx, hipFree(ctx->d_tab));
+    ctx->d_tab = nullptr;
+    const size_t n = (size_t)np + ns + (size_t)np * ns;
+    if (dev_alloc(ctx, &ctx->d_tab, n)) return -1;
+    HIPCHK(ctx, hipMemcpy(ctx->d_tab, p, sizeof(double) * np, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_tab + np, s, sizeof(double) * ns, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_tab + np + ns, T, sizeof(double) * (size_t)np * ns, hipMemcpyHostToDevice));
+    ctx->tab_np = np; ctx->tab_ns = ns;
+    return 0;
+}
+
+int tcr_potential_intensity_dev(tcr_ctx *ctx, int64_t n_points, int32_t n_lev, const double *p_env, const double *sst,
+                                const double *psl, const double *T_env, const double *r_env, double ck_over_cd,
+                                double *pi, void *stream_)
+{
+    if (!ctx) return -1;
+    if (!ctx->d_tab) return fail(ctx, "tcr_potential_intensity: no entropy table (tcr_entropy_table_upload)");
+    if (n_points <= 0 || n_lev < 2 || !p_env || !sst || !psl || !T_env || !r_env || !pi)
+        return fail(ctx, "tcr_potential_intensity: bad argument (at least two levels)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    th::PiArgs a{};
+    a.tab.np = ctx->tab_np; a.tab.ns = ctx->tab_ns;
+    a.tab.p = ctx->d_tab; a.tab.s = ctx->d_tab + ctx->tab_np; a.tab.T = ctx->d_tab + ctx->tab_np + ctx->tab_ns;
+    a.n_points = n_points; a.n_lev = n_lev; a.p_env = p_env; a.sst = sst; a.psl = psl; a.T_env = T_env; a.r_env = r_env;
+    a.cecd = ck_over_cd; a.pi = pi;
+    hipLaunchKernelGGL(th::k_potential_intensity, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, st, a);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+int tcr_potential_intensity_host(tcr_ctx *ctx, int64_t n_points, int32_t n_lev, const double *p_env, const double *sst,
+                                 const double *psl, const double *T_env, const double *r_env, double ck_over_cd, double *pi)
+{
+    if (!ctx) return -1;
+    if (n_points <= 0 || n_lev < 2) return fail(ctx, "tcr_potential_intensity: bad argument (at least two levels)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (int k = 1; k < n_lev; ++k)
+        if (!(p_env[k] < p_env[k - 1])) return fail(ctx, "tcr_potential_intensity: levels must run from the lowest (highest pressure) up");
+    DevBuf B;
+    const double *d_p = B.put(p_env, (size_t)n_lev), *d_sst = B.put(sst, (size_t)n_points), *d_psl = B.put(psl, (size_t)n_points);
+    const double *d_T = B.put(T_env, (size_t)n_lev * n_points), *d_r = B.put(r_env, (size_t)n_lev * n_points);
+    double *d_pi = B.get<double>((size_t)n_points);
+    if (!d_p || !d_sst || !d_psl || !d_T || !d_r || !d_pi) return fail(ctx, "tcr_potential_intensity_host: device allocation failed");
+    if (tcr_potential_intensity_dev(ctx, n_points, n_lev, d_p, d_sst, d_psl, d_T, d_r, ck_over_cd, d_pi, ctx->stream)) return -1;
+    HIPCHK(ctx, hipMemcpyAsync(pi, d_pi, sizeof(double) * (size_t)n_points, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int tcr_chi_rh_host(tcr_ctx *ctx, int64_t n_points, const double *sst, const double *psl, const double *T_mid,
+                    const double *q_mid, double p_mid, double *chi, double *rh_mid)
+{
+    if (!ctx) return -1;
+    if (n_points <= 0 || !sst || !psl || !T_mid || !q_mid || !chi || !rh_mid) return fail(ctx, "tcr_chi_rh_host: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevBuf B;
+    const size_t n = (size_t)n_points;
+    const double *d_sst = B.put(sst, n), *d_psl = B.put(psl, n), *d_T = B.put(T_mid, n), *d_q = B.put(q_mid, n);
+    double *d_chi = B.get<double>(n), *d_rh = B.get<double>(n);
+    if (!d_sst || !d_psl || !d_T || !d_q || !d_chi || !d_rh) return fail(ctx, "tcr_chi_rh_host: device allocation failed");
+    hipLaunchKernelGGL(th::k_chi_rh, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, ctx->stream, n_points,
+                       d_sst, d_psl, d_T, d_q, p_mid, d_chi, d_rh);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(chi, d_chi, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(rh_mid, d_rh, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 

@@ -78,3 +78,71 @@ def wind_stats_host(engine, planes, day_start=None):
     engine._ck(engine.L.tcr_wind_stats_host(engine.h, n, npts, ptrs, None if ds is None else ds.ctypes.data, nd,
                                             out.ctypes.data))
     return out
+
+
+# --------------------------------------------------------------------------------------
+# thermodynamic preprocessing
+def load_entropy_table(fn=None, nl=None):
+    """The reference's `thermo/entropy_table.npz` (thermo.py:272-277): p [Pa], s [J/kg/K], T[p][s].
+    The table was made by a Nelder-Mead inversion (thermo.py:451-469), so results match the reference's
+    only with *its* table; point `fn` (or namelist.src_directory) at it."""
+    import os
+    from . import namelist as default_namelist
+    nl = nl or default_namelist
+    fn = fn or os.path.join(nl.src_directory, 'thermo', 'entropy_table.npz')
+    with np.load(fn) as t:
+        return np.array(t['p'], dtype=np.float64), np.array(t['s'], dtype=np.float64), np.array(t['T'], dtype=np.float64)
+
+
+def stage_entropy_table(engine, p, s, T):
+    p, s, T = (np.ascontiguousarray(x, dtype=np.float64) for x in (p, s, T))
+    if T.shape != (len(p), len(s)):
+        raise ValueError('T must be [len(p), len(s)]')
+    dp = lambda a: a.ctypes.data_as(_lib.DP)
+    engine._ck(engine.L.tcr_entropy_table_upload(engine.h, len(p), len(s), dp(p), dp(s), dp(T)))
+
+
+def potential_intensity(engine, sst, p_surf, p_env, T_env, r_env, nl=None):
+    """thermo.CAPE_PI_vectorized(sst, p_surf, p_env, T_env, r_env): p_env [L] Pa lowest level first,
+    T_env / r_env [L, lat, lon]; returns PI [lat, lon]."""
+    from . import namelist as default_namelist
+    nl = nl or default_namelist
+    sst, p_surf = np.ascontiguousarray(sst, dtype=np.float64), np.ascontiguousarray(p_surf, dtype=np.float64)
+    T_env, r_env = np.ascontiguousarray(T_env, dtype=np.float64), np.ascontiguousarray(r_env, dtype=np.float64)
+    p_env = np.ascontiguousarray(p_env, dtype=np.float64)
+    L = len(p_env)
+    if T_env.shape != (L,) + sst.shape or r_env.shape != T_env.shape or p_surf.shape != sst.shape:
+        raise ValueError('shapes: sst/p_surf [..], T_env/r_env [L, ..]')
+    out = np.empty(sst.shape)
+    dp = lambda a: a.ctypes.data_as(_lib.DP)
+    engine._ck(engine.L.tcr_potential_intensity_host(engine.h, sst.size, L, dp(p_env), dp(sst), dp(p_surf), dp(T_env),
+                                                     dp(r_env), float(nl.Ck / nl.Cd), dp(out)))
+    return out
+
+
+def chi_rh(engine, sst, p_surf, T_mid, q_mid, p_mid):
+    """(thermo.sat_deficit, thermo.conv_q_to_rh) at the mid level; chi is not clipped here."""
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (sst, p_surf, T_mid, q_mid)]
+    chi, rh = np.empty(a[0].shape), np.empty(a[0].shape)
+    dp = lambda x: x.ctypes.data_as(_lib.DP)
+    engine._ck(engine.L.tcr_chi_rh_host(engine.h, a[0].size, dp(a[0]), dp(a[1]), dp(a[2]), dp(a[3]), float(p_mid), dp(chi), dp(rh)))
+    return chi, rh
+
+
+def compute_thermo(engine, sst_K, psl, levels, level_units, ta, hus, nl=None):
+    """One time sample of thermo/calc_thermo.compute_thermo (:36-74) over plain arrays already on the
+    atmospheric grid: orders the levels lowest first (:50-54), converts hPa to Pa (:56-59), picks the
+    level nearest namelist.p_midlevel (:59, 65-68), and returns (vmax, chi clipped to [0, 10], rh_mid).
+    As in the reference, specific humidity is handed to the PI routine as if it were mixing ratio (:63)."""
+    from . import namelist as default_namelist
+    nl = nl or default_namelist
+    lev = np.array(levels, dtype=np.float64)
+    ta, hus = np.asarray(ta, dtype=np.float64), np.asarray(hus, dtype=np.float64)
+    if lev[0] - lev[1] < 0:
+        lev, ta, hus = lev[::-1], ta[::-1], hus[::-1]
+    if level_units in ('millibars', 'hPa'):
+        lev = lev * 100
+    k_mid = int(np.argmin(np.abs(lev - nl.p_midlevel)))
+    vmax = potential_intensity(engine, sst_K, psl, lev, ta, hus, nl)
+    chi, rh = chi_rh(engine, sst_K, psl, ta[k_mid], hus[k_mid], float(lev[k_mid]))
+    return vmax, np.minimum(np.maximum(chi, 0), 10), rh
