@@ -14,11 +14,11 @@ reference's preprocessing leaves behind:
 and returns the same 12-month object `synthetic.make_env` returns, so `engine.stage_env`,
 `compute.run_tracks` and `run.py` work on real fields unchanged.
 
-Files are read through xarray when it is installed (NetCDF-4, as the reference writes them) and
-otherwise through ``scipy.io.netcdf_file`` (NetCDF-3 classic / 64-bit offset; ``nccopy -k classic``
-converts).  Neither the build nor the bench container has xarray, netCDF4 or h5py, so the HDF5
-flavour is untested here; `write_reference_files` writes the same schema as NetCDF-3, which is what
-the round-trip tests read, and which lets the *reference* be run on this project's synthetic fields.
+Files are read through xarray when it is installed; otherwise NetCDF-3 (classic / 64-bit offset) through
+``scipy.io.netcdf_file`` and NetCDF-4 through the built-in minimal HDF5 reader `hdf5lite` (neither the
+build nor the bench container has xarray, netCDF4 or h5py).  `write_reference_files` writes the same
+schema as NetCDF-3, which is what the round-trip tests read and which lets the *reference* be run on
+this project's synthetic fields; the HDF5 path is tested on the reference's own `intensity/data/land.nc`.
 
 Time handling follows the reference: the thermo record is cut to ``[Dec 31 of year-1, Dec 31 of
 year]`` and interpolated linearly to the 15th of every month (NaN outside the record: vpot -> 0,
@@ -68,10 +68,13 @@ class _Dataset:
             return
         with open(fn, 'rb') as f:
             magic = f.read(4)
+        if magic == b'\x89HDF':                                 # NetCDF-4: the built-in minimal HDF5 reader
+            from . import hdf5lite
+            for k, (a, at) in hdf5lite.read_variables(fn).items():
+                self.vars[k], self.attrs[k], self.dims[k] = a, at, ()
+            return
         if magic[:3] != b'CDF':
-            raise RuntimeError(
-                '%s is not NetCDF-3 (magic %r) and xarray is not installed; convert it with '
-                '`nccopy -k classic` or install xarray + netCDF4' % (fn, magic))
+            raise RuntimeError('%s is neither NetCDF-3 nor HDF5 (magic %r)' % (fn, magic))
         from scipy.io import netcdf_file
         with netcdf_file(fn, 'r', mmap=False, maskandscale=True) as f:
             for k, v in f.variables.items():
