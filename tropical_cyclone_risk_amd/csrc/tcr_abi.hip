@@ -605,6 +605,7 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
         a.slot = in->slot; a.n_valid = out->n_valid; a.status = out->status; a.n_accept = out->n_accept;
         a.lon = out->lon; a.lat = out->lat; a.v = out->v; a.m = out->m; a.vmax = out->vmax;
         a.envw = out->envw; a.flags = out->flags; a.pad_state = out->pad_state;
+        make_eval_k(P, a.D, a.K);
         const unsigned chunks = (unsigned)((ns + kPostThreads - 1) / kPostThreads);
         hipLaunchKernelGGL(k_dense, dim3((unsigned)n), dim3(kWave), 0, st, a, ctx->d_sidx);
         if (a.D.all_affine) hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);

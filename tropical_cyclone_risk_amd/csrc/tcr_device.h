@@ -80,7 +80,7 @@ struct EvalK {
     int n_steps, coupled_track;
 };
 
-__device__ inline void make_eval_k(const tcr_params &P, const DevFields &D, EvalK &K)
+__host__ __device__ inline void make_eval_k(const tcr_params &P, const DevFields &D, EvalK &K)
 {
     K.wx = D.wg.ax; K.wy = D.wg.ay; K.tx = D.tg.ax; K.ty = D.tg.ay; K.hx = D.hg.ax; K.hy = D.hg.ay;
     K.stat = D.stat;

@@ -521,7 +521,9 @@ struct EArgs {
     double *lon, *lat, *v, *m, *vmax, *envw;
     int32_t *flags;
     const int32_t *pad_state;    // rows are already NaN from this sample on (NULL / <0: unknown), see tcrisk_hip.h
+    EvalK K;                     // built on the host; k_emit's small workgroups copy it to LDS with one load per lane
 };
+static_assert(sizeof(EvalK) % 8 == 0 && sizeof(EvalK) / 8 <= 128, "EvalK is copied to LDS as <= 128 eight-byte words");
 constexpr int kBitAny15 = 1 << 8, kBitVmax = 1 << 9;     // scratch bits in flags[] between the kernels
 constexpr int kPostThreads = 128;
 constexpr int kEmitSlotCache = 32;      // field-slot wind pointers kept in LDS by k_emit
@@ -660,7 +662,8 @@ __global__ __launch_bounds__(kPostThreads, TCR_EMIT_WPS) void k_emit(EArgs a, co
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     const bool live_block = (int)(blockIdx.y * kPostThreads) < n;
     if (live_block) {
-        if (threadIdx.x == 0) make_eval_k(P, a.D, K);
+        if (threadIdx.x < sizeof(EvalK) / 8)
+            reinterpret_cast<uint64_t *>(&K)[threadIdx.x] = reinterpret_cast<const uint64_t *>(&a.K)[threadIdx.x];
         if (threadIdx.x < kEmitSlotCache && (int)threadIdx.x < a.D.n_slots) s_wind[threadIdx.x] = a.D.slots[threadIdx.x].wind;
         __syncthreads();
     }
