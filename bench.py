@@ -85,45 +85,15 @@ def main():
     acc = torch.zeros(4, dtype=torch.int64, device=dev)       # storm-steps, nfev, samples, accepted (tcr_stats_dev)
     short = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(n_str)]   # rounds with < B passing seeds
     row = 9 * ns
-    # N > 1: all-gather of every batch's final (accepted) tracks.  Nothing in a step waits on the host:
-    # the 8-byte count all-gather of batch k is read back only when batch k + n_str is issued (by then it
-    # has long completed), and only then is the row all-gather of batch k launched, on RCCL's own stream,
-    # while the compute streams are already n_str batches ahead.  Buffers rotate over n_str + 2 slots.
-    depth = n_str + 2
+    # N > 1: all-gather of every batch's final (accepted) tracks through distributed.DeferredRowGather:
+    # nothing in a step waits on the host — batch k's count is read back only when batch k + n_str is
+    # issued, and only then is its row all-gather launched on RCCL's stream, n_str batches behind compute.
     cap = max(1024, int(0.2 * B))               # accepted fraction is ~6 %
-    if world > 1:
-        import collections
-        packed = [torch.empty(cap, row, dtype=torch.float64, device=dev) for _ in range(depth)]
-        cnt_buf = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(depth)]
-        row_work = [None] * depth                # finish() of the row all-gather that last read packed[slot]
-        inflight = collections.deque()
-        comm_stream = torch.cuda.Stream(device=dev)
-    gathered_rows = 0
-    clipped = 0
+    gather = D.DeferredRowGather(cap, row, dev, lag=n_str) if world > 1 else None
 
     def step(k):
         with torch.cuda.stream(streams[k % n_str]):
             _step(k, pipes[k % n_str])
-
-    def finish_oldest():
-        nonlocal gathered_rows, clipped
-        slot, wc = inflight.popleft()
-        with torch.cuda.stream(comm_stream):
-            wc.wait()
-            counts = [int(c) for c in cnt_buf[slot].tolist()]
-            clipped += sum(max(0, c - cap) for c in counts)
-            counts = [min(c, cap) for c in counts]
-            _, fin = D.allgather_rows(packed[slot], None, counts=counts, async_op=True, concat=False)
-        row_work[slot] = (fin, sum(counts))
-
-    def retire(slot):
-        nonlocal gathered_rows
-        if row_work[slot] is not None:
-            fin, n_rows = row_work[slot]
-            parts, _ = fin()                     # stream-side wait, no host sync, no copy
-            assert sum(p.shape[0] for p in parts) == n_rows
-            gathered_rows += n_rows
-            row_work[slot] = None
 
     def _step(k, pipe):
         # warm-up steps run exactly the same code; the accumulators are zeroed after them
@@ -132,22 +102,15 @@ def main():
         pipe.integrate(B)
         pipe.add_stats(acc)
         short[k % n_str].add_((pipe.n_passed < B).long())
-        if world > 1:
-            slot = k % depth
-            retire(slot)                         # the gather that read packed[slot] must be done before repacking
+        if gather is not None:
+            buf = gather.buffer()                # waits (on this stream) for the gather that last read it
             pipe.select_accepted()
-            pipe.pack_accepted(packed[slot], cap)
-            wc = torch.distributed.all_gather_into_tensor(cnt_buf[slot], pipe.n_accepted.reshape(1), async_op=True)
-            inflight.append((slot, wc))
-            if len(inflight) > n_str:
-                finish_oldest()
+            pipe.pack_accepted(buf, cap)
+            gather.submit(pipe.n_accepted)
 
     def drain():
-        if world > 1:
-            while inflight:
-                finish_oldest()
-            for slot in range(depth):
-                retire(slot)
+        if gather is not None:
+            gather.drain()
 
     for e in engs:
         e.timing_enable(True)
@@ -162,7 +125,8 @@ def main():
     D.barrier(); torch.cuda.synchronize()
     for e in engs:
         e.timing_enable(True)        # resets the event record: only the K timed steps count
-    gathered_rows = 0
+    if gather is not None:
+        gather.rows_gathered = gather.rows_clipped = 0
     t0 = time.perf_counter()
     for k in range(w_eff, w_eff + args.steps):
         step(k)
@@ -245,6 +209,10 @@ def main():
             wave_ms=sum(p['wave_ms'] for p in iso_passes), simds=simds,
             simd_time_ms=sum(p['wave_ms'] for p in iso_passes) / simds,
             shader_mhz_pass0=iso_passes[0]['shader_mhz'] if iso_passes else None)
+        # the same algorithmic bytes over the SIMD time the chain actually occupies (what it costs a pipelined run)
+        st_ms = roof['isolated']['integrate_passes']['simd_time_ms']
+        roof['isolated']['integrate_passes']['achieved_over_simd_time'] = ib / (st_ms * 1e-3) / 1e9
+        roof['isolated']['integrate_passes']['frac_over_simd_time'] = ib / (st_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
 
     out = None
     if rank == 0:
@@ -264,8 +232,8 @@ def main():
                        'storm_steps_per_storm': steps_total / (B * args.steps * world),
                        'rhs_per_storm_step': nfev_total / max(steps_total, 1),
                        'accepted_fraction': accepted_total / (B * args.steps * world),
-                       'allgather_rows': gathered_rows if world > 1 else None,
-                       'allgather_rows_clipped': clipped if world > 1 else None},
+                       'allgather_rows': gather.rows_gathered if gather is not None else None,
+                       'allgather_rows_clipped': gather.rows_clipped if gather is not None else None},
             'roofline': roof,
             'cpu_baseline': cpu,
         }

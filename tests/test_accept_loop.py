@@ -132,3 +132,59 @@ def _ragged_worker(rank, world, port, q):
     D.barrier()
     import torch.distributed as dist
     dist.destroy_process_group()
+
+
+def test_deferred_row_gather_gloo():
+    """distributed.DeferredRowGather (bench.py's N > 1 path): counts read `lag` batches late, rotating
+    buffers, capacity clipping, rank order — every batch's rows arrive exactly once and intact."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_deferred_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, msg in got:
+        assert ok, (rank, msg)
+
+
+def _deferred_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch
+    from tropical_cyclone_risk_amd import distributed as D
+    D.init_from_env(backend='gloo')
+    cap, width, lag, n_batches = 5, 4, 3, 11
+    counts_of = lambda k, r: (3 * k + 2 * r) % 8            # 0..7: some batches exceed cap = 5, some are empty
+    seen = []
+
+    def on_rows(parts, counts):
+        seen.append(([p.clone() for p in parts], list(counts)))
+    g = D.DeferredRowGather(cap, width, 'cpu', lag=lag, on_rows=on_rows)
+    for k in range(n_batches):
+        buf = g.buffer()
+        n = counts_of(k, rank)
+        buf.fill_(-1.0)
+        for i in range(min(n, cap)):
+            buf[i] = 1000.0 * k + 10.0 * rank + i
+        g.submit(torch.tensor([n], dtype=torch.int64))
+    g.drain()
+    ok, msg = True, ''
+    exp_total = sum(min(counts_of(k, r), cap) for k in range(n_batches) for r in range(world))
+    exp_clip = sum(max(0, counts_of(k, r) - cap) for k in range(n_batches) for r in range(world))
+    if g.rows_gathered != exp_total or g.rows_clipped != exp_clip or len(seen) != n_batches:
+        ok, msg = False, 'totals %s %s %s' % (g.rows_gathered, g.rows_clipped, len(seen))
+    for k, (parts, counts) in enumerate(seen):              # batches finish in submission order
+        for r in range(world):
+            n = min(counts_of(k, r), cap)
+            exp = torch.tensor([[1000.0 * k + 10.0 * r + i] * width for i in range(n)], dtype=torch.float64).reshape(n, width)
+            if counts[r] != n or not torch.equal(parts[r], exp):
+                ok, msg = False, 'batch %d rank %d: %s vs %s' % (k, r, parts[r], exp)
+    q.put((rank, ok, msg))
+    D.barrier()
+    import torch.distributed as dist
+    dist.destroy_process_group()

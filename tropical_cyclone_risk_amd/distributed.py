@@ -105,6 +105,89 @@ def allgather_rows(rows, count, counts=None, async_op=False, concat=True):
     return (work, finish) if async_op else finish()
 
 
+class DeferredRowGather:
+    """All-gather of a stream of row batches without a host sync in the producer's step.
+
+    Batch k's row count (a device scalar) is all-gathered asynchronously when the batch is submitted;
+    it is read on the host only when batch k + lag is submitted — by then that tiny collective has long
+    finished — and only then is the row all-gather of batch k launched (on the collective backend's own
+    stream).  The producer fills `buffer(k)` (one of lag + 2 rotating [cap, width] buffers); before a
+    buffer is handed out again the gather that read it is waited for on the *caller's stream*, not on
+    the host.  `on_rows(parts, counts)` (optional) receives the per-rank views of each finished gather.
+    """
+
+    def __init__(self, cap, width, device, lag, dtype=torch.float64, on_rows=None):
+        import collections
+        self.cap, self.lag, self.depth = int(cap), int(lag), int(lag) + 2
+        self.w = world()
+        self.packed = [torch.empty(self.cap, width, dtype=dtype, device=device) for _ in range(self.depth)]
+        self.cnt = [torch.zeros(self.w, dtype=torch.int64, device=device) for _ in range(self.depth)]
+        self.row_work = [None] * self.depth
+        self.inflight = collections.deque()
+        self.launched = collections.deque()     # slots with a row gather in flight, oldest first
+        self.side = torch.cuda.Stream(device=device) if torch.device(device).type == 'cuda' else None
+        self.rows_gathered = 0
+        self.rows_clipped = 0
+        self.on_rows = on_rows
+        self.k = 0
+
+    def buffer(self):
+        """The buffer for the next batch; waits (stream-side) for the gather that last read it."""
+        slot = self.k % self.depth
+        self._retire(slot)
+        return self.packed[slot]
+
+    def submit(self, count):
+        """The buffer returned by the last buffer() call holds `count` (device int64 [1]) valid rows."""
+        slot = self.k % self.depth
+        if self.w > 1:
+            wc = dist.all_gather_into_tensor(self.cnt[slot], count.reshape(1), async_op=True)
+        else:
+            self.cnt[slot].copy_(count.reshape(1))
+            wc = None
+        self.inflight.append((slot, wc))
+        self.k += 1
+        if len(self.inflight) > self.lag:
+            self._launch_oldest()
+
+    def _launch_oldest(self):
+        slot, wc = self.inflight.popleft()
+        ctx = torch.cuda.stream(self.side) if self.side is not None else _null()
+        with ctx:
+            if wc is not None:
+                wc.wait()
+            counts = [int(c) for c in self.cnt[slot].tolist()]
+            self.rows_clipped += sum(max(0, c - self.cap) for c in counts)
+            counts = [min(c, self.cap) for c in counts]
+            _, fin = allgather_rows(self.packed[slot], None, counts=counts, async_op=True, concat=False)
+        self.row_work[slot] = (fin, counts)
+        self.launched.append(slot)
+
+    def _retire(self, slot):
+        if self.row_work[slot] is not None:
+            fin, counts = self.row_work[slot]
+            parts, _ = fin()                                   # stream-side wait, no copy
+            self.rows_gathered += sum(counts)
+            if self.on_rows is not None:
+                self.on_rows(parts, counts)
+            self.row_work[slot] = None
+            self.launched.remove(slot)
+
+    def drain(self):
+        while self.inflight:
+            self._launch_oldest()
+        while self.launched:
+            self._retire(self.launched[0])
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 def allreduce_sum_(t):
     if world() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
