@@ -22,6 +22,9 @@ def main():
     ap.add_argument('--fields', default=None, metavar='DIR',
                     help='read thermo_*.nc, env_wnd_*.nc, {mld,strat}_climatology.nc, land.nc, bathymetry.nc and '
                          'land/<B>.nc from DIR (the layout --export-synthetic writes) instead of the namelist paths')
+    ap.add_argument('--preprocess', action='store_true',
+                    help='first write env_wnd_*.nc / thermo_*.nc from the raw daily winds and monthly sst / mslp / t / q '
+                         'files under namelist.base_directory, as the reference\'s compute_downscaling_inputs does')
     ap.add_argument('--export-synthetic', default=None, metavar='DIR',
                     help='write the synthetic fields for the namelist\'s years in the reference\'s file schema and exit')
     a = ap.parse_args()
@@ -46,6 +49,13 @@ def main():
             strat=one('strat_climatology.nc'), land=one('land.nc'), bathy=one('bathymetry.nc'),
             basin_dir=os.path.join(a.fields, 'land')))
     rank, world, local = distributed.init_from_env()
+    if a.preprocess and rank == 0:
+        from tropical_cyclone_risk_amd import preprocess
+        from tropical_cyclone_risk_amd.engine import TCEngine
+        eng = TCEngine(a.basin, device=distributed.local_device(local), nl=namelist)
+        preprocess.run_preprocessing(eng, namelist)
+        eng.close()
+    distributed.barrier()
     f_base = '%s/%s/' % (namelist.output_directory, namelist.exp_name)
     if rank == 0:
         os.makedirs(f_base, exist_ok=True)

@@ -146,3 +146,150 @@ def compute_thermo(engine, sst_K, psl, levels, level_units, ta, hus, nl=None):
     vmax = potential_intensity(engine, sst_K, psl, lev, ta, hus, nl)
     chi, rh = chi_rh(engine, sst_K, psl, ta[k_mid], hus[k_mid], float(lev[k_mid]))
     return vmax, np.minimum(np.maximum(chi, 0), 10), rh
+
+
+# --------------------------------------------------------------------------------------
+# file drivers: the reference's gen_wind_mean_cov / gen_thermo over NetCDF files
+def _datetimes(ta):
+    """Datetimes of a fields.TimeAxis (input.convert_to_datetime)."""
+    out = []
+    for sec in ta.t:
+        if ta.calendar in ('noleap', '365_day'):
+            days, rem = divmod(sec, 86400.0)
+            y, doy = divmod(int(days), 365)
+            mo = int(np.searchsorted(np.cumsum([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31]), doy, side='right'))
+            d = doy - int(([0] + list(np.cumsum([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31])))[mo])
+            out.append(datetime.datetime(y + 1, mo + 1, d + 1) + datetime.timedelta(seconds=rem))
+        else:
+            out.append(datetime.datetime(1, 1, 1) + datetime.timedelta(seconds=float(sec)))
+    return out
+
+
+def _bounding_times(nl):
+    """input.get_bounding_times (:135-139)."""
+    import calendar
+    s = datetime.datetime(nl.start_year, nl.start_month, 1)
+    e = datetime.datetime(nl.end_year, nl.end_month, calendar.monthrange(nl.end_year, nl.end_month)[1])
+    return s, e
+
+
+def _write_nc3(fn, coords, variables, time_days, year0):
+    from scipy.io import netcdf_file
+    with netcdf_file(fn, 'w', version=2) as f:
+        f.createDimension('time', len(time_days)); f.createDimension('lat', len(coords['lat'])); f.createDimension('lon', len(coords['lon']))
+        v = f.createVariable('time', 'd', ('time',)); v[:] = time_days
+        v.units = 'days since %04d-01-01 00:00:00' % year0; v.calendar = 'standard'
+        for k in ('lat', 'lon'):
+            v = f.createVariable(k, 'd', (k,)); v[:] = np.asarray(coords[k], dtype=np.float64)
+        for name, arr in variables.items():
+            v = f.createVariable(name, 'd', ('time', 'lat', 'lon')); v[:] = np.asarray(arr, dtype=np.float64)
+
+
+def gen_wind_mean_cov(engine, fns_ua, fns_va, out_fn, nl=None, group_days='reference'):
+    """track/env_wind.gen_wind_mean_cov + wnd_stat_wrapper (:83-176) for pairs of daily u / v files:
+    every month covered by a file pair between the namelist's bounding times gets its 14 statistics
+    (GPU), and the result is written with the reference's variable names (`<c>_Mean`, `<c>_Var`,
+    `<a>_<b>_cov`) on (time, lat, lon).  As in the reference the first record of a file is stamped with
+    the start of its period and the following ones with the 15th of their month (:139-152)."""
+    from . import fields, namelist as default_namelist
+    nl = nl or default_namelist
+    vk = nl.var_keys[nl.dataset_type]
+    dt_start, dt_end = _bounding_times(nl)
+    stamps, stats, grid = [], [], None
+    for fu, fv in zip(fns_ua, fns_va):
+        du, dv = fields._Dataset(fu), fields._Dataset(fv)
+        times = _datetimes(fields.TimeAxis(du['time'], du.attrs['time']))
+        t0 = max(dt_start, times[0])
+        t_months = [t0]
+        while t_months[-1] <= min(dt_end, times[-1]):
+            y, m = t_months[-1].year, t_months[-1].month
+            t_months.append(datetime.datetime(y + 1, 1, 15) if m == 12 else datetime.datetime(y, m + 1, 15))
+        t_months = t_months[:-1]
+        units = str(du.attrs[vk['lvl']].get('units', 'Pa'))
+        for tm in t_months:
+            stats.append(calc_wnd_stat(engine, du[vk['u']], dv[vk['v']], du[vk['lvl']], units, times, tm.year, tm.month, group_days))
+            stamps.append(tm)
+        grid = dict(lat=du[vk['lat']], lon=du[vk['lon']])
+    if not stats:
+        raise ValueError('no month of the namelist period is covered by the given files')
+    stats = np.stack(stats)                                    # [time, 14, lat, lon]
+    names = MEAN_NAMES + [n for n in _cov_names()]
+    year0 = stamps[0].year
+    days = [(t - datetime.datetime(year0, 1, 1)).total_seconds() / 86400.0 for t in stamps]
+    _write_nc3(out_fn, grid, {n: stats[:, i] for i, n in enumerate(names)}, days, year0)
+    return out_fn
+
+
+def _cov_names():
+    from .fields import cov_name
+    return [cov_name(i, j) for i in range(4) for j in range(i + 1)]
+
+
+def gen_thermo(engine, fn_sst, fn_mslp, fn_temp, fn_sp_hum, out_fn, nl=None, table=None):
+    """thermo/calc_thermo.gen_thermo + compute_thermo (:24-117) for monthly sst / mslp / temperature /
+    specific-humidity files: sst is regridded bilinearly (after nan_to_num) onto the atmospheric grid
+    (:37-41, Celsius -> Kelvin by the units attribute), PI / chi / rh_mid come from the GPU kernels, and
+    records are stamped on the 15th of their month (:101-106).  Axes must ascend in latitude (the
+    reference's RectBivariateSpline regridding needs that too)."""
+    from . import fields, namelist as default_namelist
+    nl = nl or default_namelist
+    vk = nl.var_keys[nl.dataset_type]
+    if table is not None:
+        stage_entropy_table(engine, *table)
+    ds_sst, ds_psl, ds_ta, ds_q = (fields._Dataset(f) for f in (fn_sst, fn_mslp, fn_temp, fn_sp_hum))
+    dt_start, dt_end = _bounding_times(nl)
+    times = _datetimes(fields.TimeAxis(ds_psl['time'], ds_psl.attrs['time']))
+    keep = [i for i, t in enumerate(times) if dt_start <= t <= dt_end]
+    lon_a, lat_a = np.asarray(ds_ta[vk['lon']], dtype=np.float64), np.asarray(ds_ta[vk['lat']], dtype=np.float64)
+    lev = ds_ta[vk['lvl']]
+    lev_units = str(ds_ta.attrs[vk['lvl']].get('units', 'Pa'))
+    celsius = 'C' in str(ds_sst.attrs[vk['sst']].get('units', 'K'))
+    vmax, chi, rh = [], [], []
+    for i in keep:
+        sst = fields.interp_2d_grid(ds_sst[vk['lon']], ds_sst[vk['lat']], np.nan_to_num(np.asarray(ds_sst[vk['sst']][i], dtype=np.float64)),
+                                    lon_a, lat_a)
+        if celsius:
+            sst = sst + 273.15
+        v, c, r = compute_thermo(engine, sst, ds_psl[vk['mslp']][i], lev, lev_units, ds_ta[vk['temp']][i], ds_q[vk['sp_hum']][i], nl)
+        vmax.append(v); chi.append(c); rh.append(r)
+    stamps = [datetime.datetime(times[i].year, times[i].month, 15) for i in keep]
+    year0 = stamps[0].year
+    days = [(t - datetime.datetime(year0, 1, 1)).total_seconds() / 86400.0 for t in stamps]
+    _write_nc3(out_fn, dict(lat=ds_psl[vk['lat']], lon=ds_psl[vk['lon']]),
+               dict(vmax=np.stack(vmax), chi=np.stack(chi), rh_mid=np.stack(rh)), days, year0)
+    return out_fn
+
+
+def glob_prefix(nl, var_key):
+    """input._glob_prefix (:22-27): files under base_directory whose name carries the experiment prefix
+    and `_<var>_` (or `<var>_`)."""
+    import glob
+    fns = glob.glob('%s/**/*%s*.nc' % (nl.base_directory, nl.exp_prefix), recursive=True)
+    out = sorted(x for x in fns if '_%s_' % var_key in x)
+    return out or sorted(x for x in fns if '%s_' % var_key in x)
+
+
+def run_preprocessing(engine, nl=None, table=None):
+    """What the reference's run.py does before the downscaling (run.py:14-15): write env_wnd_*.nc and
+    thermo_*.nc next to the data unless they exist.  Monthly variables must be one file each."""
+    import os
+    from . import fields, namelist as default_namelist
+    nl = nl or default_namelist
+    fl = fields.default_files(nl)
+    vk = nl.var_keys[nl.dataset_type]
+    if not os.path.exists(fl['env_wnd']):
+        fu, fv = glob_prefix(nl, vk['u']), glob_prefix(nl, vk['v'])
+        n = min(len(fu), len(fv))
+        gen_wind_mean_cov(engine, fu[:n], fv[:n], fl['env_wnd'], nl)
+        print('Saved %s' % fl['env_wnd'])
+    if not os.path.exists(fl['thermo']):
+        one = {}
+        for k in ('sst', 'mslp', 'temp', 'sp_hum'):
+            f = glob_prefix(nl, vk[k])
+            if len(f) != 1:
+                raise NotImplementedError('%d files for %s: this driver reads one file per monthly variable' % (len(f), vk[k]))
+            one[k] = f[0]
+        gen_thermo(engine, one['sst'], one['mslp'], one['temp'], one['sp_hum'], fl['thermo'], nl,
+                   table=table or load_entropy_table(nl=nl))
+        print('Saved %s' % fl['thermo'])
+    return fl
