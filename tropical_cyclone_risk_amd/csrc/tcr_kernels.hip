@@ -525,7 +525,10 @@ struct EArgs {
 };
 static_assert(sizeof(EvalK) % 8 == 0 && sizeof(EvalK) / 8 <= 128, "EvalK is copied to LDS as <= 128 eight-byte words");
 constexpr int kBitAny15 = 1 << 8, kBitVmax = 1 << 9;     // scratch bits in flags[] between the kernels
-constexpr int kPostThreads = 128;
+#ifndef TCR_POST_THREADS
+#define TCR_POST_THREADS 128
+#endif
+constexpr int kPostThreads = TCR_POST_THREADS;
 constexpr int kEmitSlotCache = 32;      // field-slot wind pointers kept in LDS by k_emit
 #ifndef TCR_EMIT_WPS
 #define TCR_EMIT_WPS 3     // waves per SIMD k_emit is register-budgeted for (<= 168 VGPRs)
