@@ -122,3 +122,29 @@ def test_run_tracks_from_reference_files(golden_env, built_lib, tmp_path):
              np.allclose(np.nan_to_num(got[2][i]), np.nan_to_num(ref[2][i]), rtol=0, atol=1e-6) for i in range(8)]
     assert sum(close) >= 6, close
     assert np.nanmax(np.abs(got[0] - ref[0])) < 0.5 and np.nanmax(np.abs(got[2] - ref[2])) < 2.0
+
+
+@pytest.mark.gpu
+def test_run_py_is_rank_count_invariant(built_lib, tmp_path):
+    """`run.py GL --synthetic` under torchrun with two ranks (sharing this GPU, gloo as the collective
+    backend) writes the same track file as a single process: candidate-index sharding + ordered accept loop."""
+    import subprocess
+    import sys
+    from tropical_cyclone_risk_amd import io as tio
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tag, world in (('one', 1), ('two', 2)):
+        nlf = tmp_path / ('nl_%s.py' % tag)
+        nlf.write_text("start_year = 2001\nend_year = 2001\ntracks_per_year = 24\noutput_directory = %r\nexp_name = %r\n"
+                       % (str(tmp_path), tag))
+        env = dict(os.environ, TCR_DIST_BACKEND='gloo')
+        cmd = [sys.executable, os.path.join(root, 'run.py'), 'GL', '--synthetic', '--namelist', str(nlf)]
+        if world > 1:
+            cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+                   '--master-addr', '127.0.0.1', '--master-port', '29517'] + cmd[1:]
+        r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = tio.read_tracks(str(tmp_path / tag / 'tracks_GL_era5_200101_200112.nc'))
+    for k in ('lon_trks', 'lat_trks', 'v_trks', 'm_trks', 'vmax_trks', 'u250_trks', 'tc_month', 'tc_basins', 'seeds_per_month'):
+        assert np.array_equal(out['one'][k], out['two'][k], equal_nan=(out['one'][k].dtype.kind == 'f')), k
+    assert out['one']['lon_trks'].shape == (24, 361)

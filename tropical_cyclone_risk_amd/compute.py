@@ -165,7 +165,7 @@ def run_tracks(year, n_tracks, b, engine=None, env=None, nl=None, per_rank=None)
     if own:
         from .engine import TCEngine
         import os
-        engine = TCEngine(basin_id, device=int(os.environ.get('LOCAL_RANK', '0')), nl=nl).stage_env(env)
+        engine = TCEngine(basin_id, device=D.local_device(os.environ.get('LOCAL_RANK', '0')), nl=nl).stage_env(env)
     per_rank = int(per_rank or max(4096, min(nl.gpu_candidate_round, 64 * n_tracks)))
     rf = GpuRound(engine, year, per_rank)
     res = accept_loop(rf, n_tracks, per_rank, engine.n_steps)
@@ -185,7 +185,7 @@ def run_downscaling(basin_id, env=None, nl=None, out_dir=None):
     if env is None:
         env = tio.load_env(nl)
     s = time.time()
-    eng = TCEngine(basin_id, device=int(os.environ.get('LOCAL_RANK', '0')), nl=nl).stage_env(env)
+    eng = TCEngine(basin_id, device=D.local_device(os.environ.get('LOCAL_RANK', '0')), nl=nl).stage_env(env)
     out = []
     years = list(range(nl.start_year, nl.end_year + 1))
     for yr in years:
