@@ -112,8 +112,14 @@ __global__ __launch_bounds__(256) void k_phase_factors(tcr_params P, int64_t n, 
 // the whole workgroup, so they are scalar loads (SGPR operands of the FMAs) and the only LDS
 // traffic is one table entry per (sample, harmonic) — the first version read the factors from
 // LDS as well and was LDS-issue bound.
-constexpr int kFsThreads = 128;
-constexpr int kFsPerThread = 3;
+#ifndef TCR_FS_THREADS
+#define TCR_FS_THREADS 128
+#endif
+constexpr int kFsThreads = TCR_FS_THREADS;
+#ifndef TCR_FS_PER_THREAD
+#define TCR_FS_PER_THREAD 3
+#endif
+constexpr int kFsPerThread = TCR_FS_PER_THREAD;
 
 __global__ __launch_bounds__(kFsThreads) void k_fourier_periodic(tcr_params P, int64_t n, int period,
                                                                   const double2 *__restrict__ sc_table,
