@@ -161,3 +161,36 @@ def test_file_drivers_wind_and_thermo(cases, table, built_lib, tmp_path):
     np.testing.assert_allclose(ds['vmax'][1], ds['vmax'][0], rtol=0, atol=0)
     assert np.nanmin(ds['chi']) >= 0 and np.nanmax(ds['chi']) <= 10
     eng.close()
+
+
+@pytest.mark.gpu
+def test_device_pointer_entry_points(cases, table, built_lib):
+    """tcr_potential_intensity_dev / tcr_wind_stats_dev (device buffers, caller's stream) give what the host
+    entry points give."""
+    import ctypes as C
+    import torch
+    from tropical_cyclone_risk_amd import preprocess as pp
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    eng = TCEngine('GL', device=0)
+    pp.stage_entropy_table(eng, table['p'], table['s'], table['T'])
+    p, sst, psl, T, r = (cases['a_' + k] for k in ('p', 'sst', 'psl', 'T', 'r'))
+    ref = pp.potential_intensity(eng, sst, psl, p, T, r)
+    dev = torch.device('cuda', 0)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
+    dp, dsst, dpsl, dT, dr = t(p), t(sst.ravel()), t(psl.ravel()), t(T.reshape(len(p), -1)), t(r.reshape(len(p), -1))
+    out = torch.empty(sst.size, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    eng._ck(eng.L.tcr_potential_intensity_dev(eng.h, sst.size, len(p), dp.data_ptr(), dsst.data_ptr(), dpsl.data_ptr(),
+                                              dT.data_ptr(), dr.data_ptr(), float(cases['Ck_over_Cd']), out.data_ptr(), C.c_void_p(st)))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().reshape(sst.shape), ref)
+    rng = np.random.default_rng(2)
+    planes = [rng.normal(size=(20, 500)) for _ in range(4)]
+    want = eng.wind_stats(planes)
+    dpl = [t(x) for x in planes]
+    ptrs = (C.c_void_p * 4)(*[x.data_ptr() for x in dpl])
+    o2 = torch.empty(14, 500, dtype=torch.float64, device=dev)
+    eng._ck(eng.L.tcr_wind_stats_dev(eng.h, 20, 500, ptrs, None, 0, o2.data_ptr(), C.c_void_p(st)))
+    torch.cuda.synchronize()
+    assert np.array_equal(o2.cpu().numpy(), want)
+    eng.close()
