@@ -46,6 +46,9 @@ def main():
     ap.add_argument('--cpu-budget', type=float, default=12.0)
     ap.add_argument('--traffic', type=float, default=None,
                     help='HBM bytes per integrate launch from a separate rocprofv3 --pmc pass (see profiles/)')
+    ap.add_argument('--rows', choices=('tc', 'all'), default='tc',
+                    help="tc: env winds / vmax / rows only for storms that pass accept test 1, as the reference does "
+                         "(compute.py:190-204); all: rows for every integrated storm (round 1's workload)")
     args = ap.parse_args()
 
     import numpy as np
@@ -79,10 +82,10 @@ def main():
     p_pass = float(((probe.cand['seed_flags'] & 2) != 0).double().mean().item())
     del probe
     C = int(B / max(p_pass, 1e-3) * 1.15) + 4096
-    pipes = [DevicePipeline(e, C, B, sort_storms=args.sort) for e in engs]
+    pipes = [DevicePipeline(e, C, B, sort_storms=args.sort, tc_rows_only=(args.rows == 'tc')) for e in engs]
     pipe = pipes[0]
 
-    acc = torch.zeros(4, dtype=torch.int64, device=dev)       # storm-steps, nfev, samples, accepted (tcr_stats_dev)
+    acc = torch.zeros(6, dtype=torch.int64, device=dev)       # storm-steps, nfev, samples, accepted, is_tc, is_tc samples (tcr_stats_dev)
     short = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(n_str)]   # rounds with < B passing seeds
     row = 9 * ns
     # N > 1: all-gather of every batch's final (accepted) tracks through distributed.DeferredRowGather:
@@ -150,7 +153,7 @@ def main():
     # part of `value`): with several streams the event-bracketed duration of a launch includes the
     # time it shared the GPU with other batches, so the per-kernel roofline is quoted both ways.
     iso = None
-    if n_str > 1:
+    if True:
         acc_keep = acc.clone()
         for e in engs:
             e.timing_enable(True)
@@ -164,7 +167,8 @@ def main():
         iso_passes = engs[0].pass_stats()
     if world > 1:
         D.allreduce_sum_(acc)
-    steps_total, nfev_total, samples_total, accepted_total = (float(x) for x in acc.tolist())
+    steps_total, nfev_total, samples_total, accepted_total, tc_total, tc_samples_total = (float(x) for x in acc.tolist())
+    emitted_total = tc_samples_total if args.rows == 'tc' else samples_total     # samples k_emit actually produced
     n_short = int(sum(int(t.item()) for t in short))
     value = steps_total / dt
 
@@ -176,43 +180,50 @@ def main():
     k_ms = ms['integrate_ms'] / launches
     e_ms = ms['post_ms'] / launches
     int_bytes = BYTES_PER_RHS * nfev_total / (launches * world)
-    emit_bytes = BYTES_PER_SAMPLE * samples_total / (launches * world)
-    achieved = int_bytes / (k_ms * 1e-3) / 1e9
-    traffic = args.traffic if args.traffic is not None else measured_traffic('tcr::k_integrate<true>', B)
+    emit_bytes = BYTES_PER_SAMPLE * emitted_total / (launches * world)
+    # HIP-event time of every kernel of the timed region, summed over launches and streams (overlapping
+    # streams make this exceed the wall time; it shows the GPU was busy even when SMI sampling misses a 50 ms region)
+    gpu_active_s = (ms['fourier_ms'] + ms['integrate_ms'] + ms['post_ms']) * 1e-3
+    traffic, traffic_src = (args.traffic, 'command line') if args.traffic is not None else measured_traffic('k_integrate', B, args.rows)
+    # Exclusive duration: the same launch, one batch at a time on one stream right after the timed region
+    # (3 batches).  With several streams the event-bracketed duration of a launch in the timed region
+    # includes time it shared the GPU with other batches (it can exceed ms_per_step), so that figure is
+    # kept under `pipelined_events`, not at the top level.
+    ik, ie = iso['integrate_ms'] / iso['calls'], iso['post_ms'] / iso['calls']
+    ib = BYTES_PER_RHS * iso_counts[1] / iso['calls']
+    eb = BYTES_PER_SAMPLE * (iso_counts[5] if args.rows == 'tc' else iso_counts[2]) / iso['calls']
+    achieved = ib / (ik * 1e-3) / 1e9
+    e_traffic, e_src = measured_traffic('k_emit', B, args.rows)
     roof = dict(bound='hbm', kernel='k_integrate', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
-                frac=achieved / HBM_PEAK_GBS, traffic=traffic,
-                # a "launch" of k_integrate is the chain of passes of one batch (tail compaction); with several
-                # streams its event-bracketed duration includes time shared with other batches (see `isolated`)
+                frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+                note='a launch = the chain of k_integrate passes of one batch (tail compaction); achieved = 704 B x RHS '
+                     'evaluations of the batch / exclusive HIP-event duration of the chain (one batch at a time on one '
+                     'stream, after the timed region); profiles/ lists k_integrate once per pass',
+                algorithmic_bytes_per_launch=ib, launch_ms=ik,
+                kernel_ms=dict(fourier=iso['fourier_ms'] / iso['calls'], integrate=ik, post=ie),
+                pipelined_events=dict(note='event-bracketed durations inside the timed region, %d streams overlapping' % n_str,
+                                      launch_ms=k_ms, achieved=int_bytes / (k_ms * 1e-3) / 1e9,
+                                      frac=int_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      kernel_ms=dict(fourier=ms['fourier_ms'] / launches, integrate=k_ms, post=e_ms)),
                 sustained=dict(note='algorithmic bytes of all k_integrate launches / wall time of the timed region',
                                achieved=BYTES_PER_RHS * nfev_total / world / dt / 1e9,
                                frac=BYTES_PER_RHS * nfev_total / world / dt / 1e9 / HBM_PEAK_GBS),
-                algorithmic_bytes_per_launch=int_bytes, launch_ms=k_ms,
-                kernel_ms=dict(fourier=ms['fourier_ms'] / launches, integrate=k_ms, emit=e_ms),
-                emit=dict(kernel='k_emit', achieved=emit_bytes / (e_ms * 1e-3) / 1e9,
-                          frac=emit_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                          algorithmic_bytes_per_launch=emit_bytes, launch_ms=e_ms,
-                          traffic=measured_traffic('tcr::k_emit<true>', B)))
-    if iso and iso['calls']:
-        ik, ie = iso['integrate_ms'] / iso['calls'], iso['post_ms'] / iso['calls']
-        ib = BYTES_PER_RHS * iso_counts[1] / iso['calls']
-        eb = BYTES_PER_SAMPLE * iso_counts[2] / iso['calls']
-        roof['isolated'] = dict(note='same kernels, one batch at a time on one stream, after the timed region',
-                                kernel_ms=dict(fourier=iso['fourier_ms'] / iso['calls'], integrate=ik, emit=ie),
-                                achieved=ib / (ik * 1e-3) / 1e9, frac=ib / (ik * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                emit_achieved=eb / (ie * 1e-3) / 1e9, emit_frac=eb / (ie * 1e-3) / 1e9 / HBM_PEAK_GBS)
-        # k_integrate runs as a chain of passes (tail compaction); occupancy of the last isolated batch:
-        # wave_ms = summed wave residency, i.e. SIMD time (one integrator wave owns a SIMD's registers)
-        wc = sum(p['wave_cycles'] for p in iso_passes)
-        simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
-        roof['isolated']['integrate_passes'] = dict(
-            passes=len(iso_passes), lane_utilisation=sum(p['lane_cycles'] for p in iso_passes) / max(1, 64 * wc),
-            wave_ms=sum(p['wave_ms'] for p in iso_passes), simds=simds,
-            simd_time_ms=sum(p['wave_ms'] for p in iso_passes) / simds,
-            shader_mhz_pass0=iso_passes[0]['shader_mhz'] if iso_passes else None)
-        # the same algorithmic bytes over the SIMD time the chain actually occupies (what it costs a pipelined run)
-        st_ms = roof['isolated']['integrate_passes']['simd_time_ms']
-        roof['isolated']['integrate_passes']['achieved_over_simd_time'] = ib / (st_ms * 1e-3) / 1e9
-        roof['isolated']['integrate_passes']['frac_over_simd_time'] = ib / (st_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                emit=dict(kernel='k_screen + k_dense + k_emit + k_flags' if args.rows == 'tc' else 'k_dense + k_emit + k_flags',
+                          note='520 B x samples actually emitted (%s) / exclusive duration of the post-processing'
+                               % ('storms that pass accept test 1' if args.rows == 'tc' else 'every storm'),
+                          achieved=eb / (ie * 1e-3) / 1e9, frac=eb / (ie * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          algorithmic_bytes_per_launch=eb, launch_ms=ie, traffic=e_traffic, traffic_source=e_src))
+    # k_integrate runs as a chain of passes (tail compaction); occupancy of the last isolated batch:
+    # wave_ms = summed wave residency, i.e. SIMD time (one integrator wave owns a SIMD's registers)
+    wc = sum(p['wave_cycles'] for p in iso_passes)
+    simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+    st_ms = sum(p['wave_ms'] for p in iso_passes) / simds
+    roof['integrate_passes'] = dict(
+        passes=len(iso_passes), lane_utilisation=sum(p['lane_cycles'] for p in iso_passes) / max(1, 64 * wc),
+        wave_ms=sum(p['wave_ms'] for p in iso_passes), simds=simds, simd_time_ms=st_ms,
+        shader_mhz_pass0=iso_passes[0]['shader_mhz'] if iso_passes else None,
+        # the same algorithmic bytes over the SIMD time the chain occupies (what it costs a pipelined run)
+        achieved_over_simd_time=ib / (st_ms * 1e-3) / 1e9, frac_over_simd_time=ib / (st_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
 
     out = None
     if rank == 0:
@@ -223,10 +234,14 @@ def main():
             'metric': 'storm-steps/sec (100k-storm ensemble)', 'value': value, 'unit': 'storm-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic', 'gpu_active_s': gpu_active_s,
             'config': {'workload': '%s basin, %d storms per GPU per step, synthetic ERA5-shaped monthly fields '
                                    '(1 deg thermo/wind, 0.25 deg land/bathymetry), 15-day tracks, hourly output, '
-                                   'device-side seeding, fp64' % (args.basin, B),
+                                   'device-side seeding, fp64; %s' % (args.basin, B, (
+                                       'env winds, vmax and rows only for storms that pass accept test 1, as the reference '
+                                       'does (compute.py:190-204)' if args.rows == 'tc' else 'rows for every integrated storm')),
+                       'rows': args.rows, 'is_tc_fraction': tc_total / (B * args.steps * world),
+                       'emitted_samples_per_step': emitted_total / (args.steps * world),
                        'storms_per_gpu': B, 'candidates_per_round': C, 'seed_pass_rate': p_pass,
                        'n_steps_out': ns, 'rounds_short_of_storms': n_short, 'streams': n_str, 'warmup_effective': w_eff,
                        'storm_steps_per_storm': steps_total / (B * args.steps * world),
@@ -243,17 +258,23 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def measured_traffic(kernel, storms):
-    """HBM bytes per batch (for k_integrate: summed over the passes of its chain) from the committed
-    rocprofv3 --pmc runs (profiles/, tools/collect_profiles.sh; collected separately from timing as
-    MI355X_MICROARCH.md prescribes); only valid for the profiled size."""
-    fn = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm.json')
+def measured_traffic(kernel, storms, rows):
+    """(HBM bytes per batch, source) of a kernel from the committed rocprofv3 --pmc runs of this same workload
+    (tools/collect_profiles.sh; counters are collected in separate passes from timing, as MI355X_MICROARCH.md
+    prescribes, so they cannot be measured inside this process).  Only valid for the profiled size."""
+    fn = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm.json')
     if storms != 100_000 or not os.path.exists(fn):
-        return None
+        return None, None
     try:
-        return json.load(open(fn))['kernels'][kernel]['hbm_bytes_per_batch_raw']
+        d = json.load(open(fn))
+        if d.get('rows') != rows:
+            return None, None
+        for name, v in d['kernels'].items():
+            if kernel in name:
+                return v['hbm_bytes_per_batch'], 'profiles/r02_pmc_hbm.json: rocprofv3 --pmc, separate passes, %s' % d.get('command', '')
     except Exception:
-        return None
+        pass
+    return None, None
 
 
 def cpu_baseline(pipe, args, B):
@@ -269,9 +290,10 @@ def cpu_baseline(pipe, args, B):
         fn = os.path.join(d, 'storms.npz')
         np.savez(fn, **host)
         try:
+            env1 = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
             r = subprocess.run([sys.executable, '-m', 'oracle.cpu_baseline', '--inputs', fn, '--basin', args.basin,
                                 '--budget', str(args.cpu_budget)], cwd=ROOT, capture_output=True, text=True,
-                               timeout=600)
+                               timeout=600, env=env1)
             res = json.loads(r.stdout.strip().splitlines()[-1])
         except Exception as e:                                        # report, never hide
             return {'value': None, 'unit': 'storm-steps/s', 'cores': 0, 'kind': 'port',
@@ -281,7 +303,9 @@ def cpu_baseline(pipe, args, B):
             'sample': 'oracle/scipy_port.py (solve_ivp RK45 + RectBivariateSpline.ev + numpy cholesky, integration + '
                       'env-wind recompute + vmax) on the first %d storms of the last GPU batch, %d worker '
                       'processes, %.1f s' % (best['storms'], best.get('procs', 1), best['seconds']),
-            'value_1core': res['one_core']['value'], 'storms_1core': res['one_core']['storms']}
+            'value_1core': res['one_core']['value'], 'storms_1core': res['one_core']['storms'],
+            'per_core_efficiency': best.get('per_core_efficiency'),
+            'c_port_1core': res.get('c_port_one_core')}
 
 
 if __name__ == '__main__':

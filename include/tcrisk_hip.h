@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TCR_ABI_VERSION 2
+#define TCR_ABI_VERSION 3
 #define TCR_NW 4            /* ua250, va250, ua850, va850  (track/env_wind.py:22-26) */
 #define TCR_NCOV 10         /* packed lower triangle (0,0),(1,0),(1,1),(2,0)..(3,3) (env_wind.py:31-42) */
 #define TCR_MAX_SERIES 32
@@ -113,6 +113,13 @@ typedef struct {
      * re-padding; on return pad_state[r] = n_valid[r].  The planes come out bit-identical to a
      * full padding.  NULL or -1: the whole tail is written. */
     int32_t *pad_state;
+    /* 0: rows are produced for every storm of the batch (what the parity tests compare).
+     * 1: rows are produced only where the reference produces them — for candidates that pass accept test 1
+     *    (`if is_tc:`, compute.py:190-204): env winds, vmax and the row writes are skipped for the others
+     *    (~90 % of a batch); their rows and pad_state entries are left untouched (unspecified contents).
+     *    n_valid, status, flags, nfev, n_accept, n_reject are complete in both modes, and the rows of
+     *    is_tc storms are bit-identical in both.  tcr_integrate_host always produces every row. */
+    int32_t tc_rows_only;
 } tcr_tracks;
 
 /* ---- lifecycle ----------------------------------------------------------- */
@@ -186,8 +193,9 @@ int tcr_gather_seeds_dev(tcr_ctx *ctx, const tcr_seeds *src_dev, const int32_t *
                          const int64_t *count_dev, const tcr_seeds *dst_dev, uint64_t experiment_seed,
                          int32_t year, int64_t cand0, void *stream);
 /* sums over a finished batch, for throughput accounting and round control: out_dev[0] = storm-steps
- * (sum of max(n_valid-1, 0)), [1] = RHS evaluations, [2] = output samples, [3] = accepted tracks;
- * the four uint64 counters are ADDED to (zero them first). */
+ * (sum of max(n_valid-1, 0)), [1] = RHS evaluations, [2] = output samples, [3] = accepted tracks,
+ * [4] = storms that passed accept test 1 (is_tc), [5] = output samples of those storms (the rows
+ * tc_rows_only produces); the six uint64 counters are ADDED to (zero them first). */
 int tcr_stats_dev(tcr_ctx *ctx, int64_t n, const tcr_tracks *tracks_dev, uint64_t *out_dev, void *stream);
 /* survivor records for the all-gather of final tracks (compute.py:233-242 concatenation):
  * packed[r] = { lon[ns], lat[ns], v[ns], m[ns], vmax[ns], envw[ns][4] } of track idx[r],
@@ -233,6 +241,12 @@ int tcr_probe_rhs_host(tcr_ctx *ctx, int slot, double h_bl, const double *Fs, in
                        const double *t, const double *lon, const double *lat,
                        const double *v, const double *m,
                        double *dydt /*[n][4]*/, double *envw /*[n][4]*/, double *alpha /*[n]*/);
+/* Test instrument of Coupled_FAST._get_over_land (coupled_fast.py:35-38): tcr_integrate_host plus, per storm,
+ * one byte per evaluation of dydt in call order — bit0 = `f_land.ev(lon, lat) == 1`, bit1 = the interpolated
+ * PI is non-zero, bit2 = the land value is within 1e-12 of 1; 0xff = not evaluated.  dec is [n][cap] host
+ * memory.  That decision is taken by rounding in the interior of land, so parity tests compare tracks up
+ * to the first evaluation where it lands differently (oracle/parity.py).  Results equal tcr_integrate_host's. */
+int tcr_integrate_probe_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out, uint8_t *dec, int32_t cap);
 /* replaces: gen_f (bam_track.py:23-31): Fs[n][4][n_steps] from phases[n][4][n_series] */
 int tcr_fourier_table_host(tcr_ctx *ctx, int64_t n, const double *phases, double *Fs);
 

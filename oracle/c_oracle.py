@@ -144,30 +144,57 @@ def bilinear(cme, which, plane_name, lon, lat):
     return np.array([lib().orc_bilinear(C.byref(g), plane, float(a), float(b)) for a, b in zip(lon, lat)])
 
 
-def run_ensemble(env, basin, storms, prm=None, post=True, bounds=None):
-    """Same contract as scipy_port.run_ensemble, plus per-storm step counters."""
-    prm = prm or Params()
-    p = c_params(prm)
-    n = len(storms['lon'])
-    ns = p.n_steps
-    months = np.ascontiguousarray(storms['month'], dtype=np.int32)
-    cmes = {}
-    envs = (C.POINTER(_Env) * 12)()
-    for mo in np.unique(months):
-        cmes[int(mo)] = CMonthEnv(env, basin, int(mo) - 1, bounds)
-        envs[int(mo) - 1] = C.pointer(cmes[int(mo)].c)
-    f64 = lambda k: np.ascontiguousarray(storms[k], dtype=np.float64)
-    lon0, lat0, v0, m0, h_bl, ph = f64('lon'), f64('lat'), f64('v0'), f64('m0'), f64('h_bl'), f64('phases')
-    traj = np.empty((n, 4, ns)); envw = np.empty((n, ns, 4)); vmax = np.empty((n, ns))
-    n_valid = np.zeros(n, np.int32); status = np.zeros(n, np.int32)
-    counters = np.zeros((n, 5), np.int32); flags = np.zeros((n, 2), np.int32)
-    lib().orc_run_ensemble(envs, C.byref(p), C.c_int(n), _dp(lon0), _dp(lat0), _dp(v0), _dp(m0),
-                           _dp(h_bl), _ip(months), _dp(ph), _dp(traj), _dp(envw), _dp(vmax),
-                           _ip(n_valid), _ip(status), _ip(counters), _ip(flags), C.c_int(1 if post else 0))
-    if not post:
-        envw[:] = np.nan; vmax[:] = np.nan
-    return dict(traj=traj, envw=envw, vmax=vmax, n_valid=n_valid, status=status,
-                nfev=counters[:, 0].copy(), n_accept=counters[:, 1].copy(),
-                n_reject=counters[:, 2].copy(), anomaly=counters[:, 3].copy(),
-                flicker=counters[:, 4].copy(),
-                is_tc=flags[:, 0].astype(bool), accepted=flags[:, 1].astype(bool))
+PROBE_CAP = 1024          # RHS evaluations recorded per storm by the decision probe (max observed ~400)
+
+
+class Ensemble:
+    """The twelve month field sets of one (environment, basin), cropped once and kept — what the list of
+    `cpl_fast` objects is in run_tracks (util/compute.py:101-121).  `run(storms)` has the contract of
+    scipy_port.run_ensemble plus per-storm step counters."""
+
+    def __init__(self, env, basin, prm=None, bounds=None):
+        self.env, self.basin, self.bounds = env, basin, bounds
+        self.prm = prm or Params()
+        self.p = c_params(self.prm)
+        self.cmes = {}
+        self.envs = (C.POINTER(_Env) * 12)()
+
+    def _need(self, months):
+        for mo in np.unique(months):
+            if int(mo) not in self.cmes:
+                self.cmes[int(mo)] = CMonthEnv(self.env, self.basin, int(mo) - 1, self.bounds)
+                self.envs[int(mo) - 1] = C.pointer(self.cmes[int(mo)].c)
+
+    def run(self, storms, post=True, probe=False):
+        p = self.p
+        n = len(storms['lon'])
+        ns = p.n_steps
+        months = np.ascontiguousarray(storms['month'], dtype=np.int32)
+        self._need(months)
+        f64 = lambda k: np.ascontiguousarray(storms[k], dtype=np.float64)
+        lon0, lat0, v0, m0, h_bl, ph = f64('lon'), f64('lat'), f64('v0'), f64('m0'), f64('h_bl'), f64('phases')
+        traj = np.empty((n, 4, ns)); envw = np.empty((n, ns, 4)); vmax = np.empty((n, ns))
+        n_valid = np.zeros(n, np.int32); status = np.zeros(n, np.int32)
+        counters = np.zeros((n, 5), np.int32); flags = np.zeros((n, 2), np.int32)
+        dec = np.full((n, PROBE_CAP), 0xff, np.uint8) if probe else None
+        dec_t0 = np.full((n, PROBE_CAP), np.nan) if probe else None
+        lib().orc_run_ensemble_probe(self.envs, C.byref(p), C.c_int(n), _dp(lon0), _dp(lat0), _dp(v0), _dp(m0),
+                                     _dp(h_bl), _ip(months), _dp(ph), _dp(traj), _dp(envw), _dp(vmax),
+                                     _ip(n_valid), _ip(status), _ip(counters), _ip(flags), C.c_int(1 if post else 0),
+                                     dec.ctypes.data_as(C.c_void_p) if probe else None,
+                                     dec_t0.ctypes.data_as(C.c_void_p) if probe else None, C.c_int(PROBE_CAP))
+        if not post:
+            envw[:] = np.nan; vmax[:] = np.nan
+        extra = dict(dec=dec, dec_t0=dec_t0) if probe else {}
+        return dict(traj=traj, envw=envw, vmax=vmax, n_valid=n_valid, status=status, **extra,
+                    nfev=counters[:, 0].copy(), n_accept=counters[:, 1].copy(),
+                    n_reject=counters[:, 2].copy(), anomaly=counters[:, 3].copy(),
+                    flicker=counters[:, 4].copy(),
+                    is_tc=flags[:, 0].astype(bool), accepted=flags[:, 1].astype(bool))
+
+
+def run_ensemble(env, basin, storms, prm=None, post=True, bounds=None, probe=False):
+    """Same contract as scipy_port.run_ensemble, plus per-storm step counters.  probe=True adds
+    'dec' [n, PROBE_CAP] uint8 (per RHS evaluation: bit0 `land == 1`, bit1 PI != 0, bit2 land within
+    1e-12 of 1; 0xff = not evaluated) and 'dec_t0' (start time of the step attempt of that evaluation)."""
+    return Ensemble(env, basin, prm, bounds).run(storms, post=post, probe=probe)

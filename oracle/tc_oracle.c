@@ -222,6 +222,14 @@ typedef struct {
     double h_bl;
     long nfev;
     long flicker;   /* diagnostics only: RHS evaluations whose `land == 1` test is decided by rounding */
+    /* decision probe (diagnostics only, may be NULL): per RHS evaluation k (in call order)
+     *   dec[k]    bit0 = `f_land.ev(lon, lat) == 1` (coupled_fast.py:35-38), bit1 = interpolated PI != 0
+     *             (the decision changes the RHS only then), bit2 = the land value is within 1e-12 of 1
+     *   dec_t0[k] start time of the step attempt the evaluation belongs to (0 for f0 / f1)        */
+    unsigned char *dec;
+    double *dec_t0;
+    int dec_cap;
+    double t_attempt;
 } orc_storm;
 
 static void steering(const orc_params *p, double v, double *c)
@@ -282,6 +290,13 @@ void orc_rhs(orc_storm *s, double t, const double *y, double *dy, double *w_out)
     double lon = y[0], lat = y[1], v = y[2], m = y[3];
     double c[2], vb[2], w[NW];
     s->flicker += flicker_exposed(e, lon, lat);
+    if (s->dec && s->nfev - 1 < s->dec_cap) {
+        double l = orc_bilinear(&e->hg, e->land, lon, lat);
+        int d = (l == 1.0 ? 1 : 0) | (orc_bilinear(&e->tg, e->vpot, lon, lat) != 0.0 ? 2 : 0) |
+                (fabs(l - 1.0) <= 1e-12 ? 4 : 0);
+        s->dec[s->nfev - 1] = (unsigned char)d;
+        if (s->dec_t0) s->dec_t0[s->nfev - 1] = s->t_attempt;
+    }
     steering(p, v, c);
     if (fabs(lat) >= 80) {
         vb[0] = vb[1] = 0.0; w[0] = w[1] = w[2] = w[3] = 0.0;
@@ -313,7 +328,7 @@ void orc_rhs_points(const orc_env *e, const orc_params *p, const double *Fs, dou
                     const double *t, const double *lon, const double *lat, const double *v,
                     const double *m, double *dydt, double *envw, double *alpha)
 {
-    orc_storm s = { e, p, Fs, h_bl, 0, 0 };
+    orc_storm s = { e, p, Fs, h_bl, 0, 0, NULL, NULL, 0, 0.0 };
     for (int i = 0; i < n; i++) {
         double y[4] = { lon[i], lat[i], v[i], m[i] };
         orc_rhs(&s, t[i], y, dydt + 4 * i, NULL);
@@ -375,14 +390,14 @@ static double event_fn(const orc_env *e, const double *y)
  *          anomaly (dense output at the step end disagrees with y_new about the event),
  *          [4]=RHS evaluations exposed to the `land == 1` rounding flicker (diagnostic).
  */
-int orc_integrate(const orc_env *e, const orc_params *p, double lon0, double lat0, double v0,
-                  double m0, double h_bl, const double *phases, double *traj, int *n_valid,
-                  int *counters, double *Fs_out)
+int orc_integrate_probe(const orc_env *e, const orc_params *p, double lon0, double lat0, double v0,
+                        double m0, double h_bl, const double *phases, double *traj, int *n_valid,
+                        int *counters, double *Fs_out, unsigned char *dec, double *dec_t0, int dec_cap)
 {
     int ns = p->n_steps;
     double *Fs = Fs_out ? Fs_out : (double *)malloc(sizeof(double) * NW * ns);
     orc_fourier_table(p, phases, Fs);
-    orc_storm s = { e, p, Fs, h_bl, 0, 0 };
+    orc_storm s = { e, p, Fs, h_bl, 0, 0, dec, dec_t0, dec_cap, 0.0 };
     int status;
     long nacc = 0, nrej = 0, anomaly = 0;
     *n_valid = 0;
@@ -396,6 +411,12 @@ int orc_integrate(const orc_env *e, const orc_params *p, double lon0, double lat
         double S = sqrt(du * du + dv * dv);
         double vp = vpot_here(e, lon0, lat0);
         double chi = orc_bilinear(&e->tg, e->chi, lon0, lat0);
+        if (dec && dec_cap > 0) {       /* the gate reads the same `land == 1` decision f0 will read */
+            double l = orc_bilinear(&e->hg, e->land, lon0, lat0);
+            dec[0] = (unsigned char)((l == 1.0 ? 1 : 0) | (orc_bilinear(&e->tg, e->vpot, lon0, lat0) != 0.0 ? 2 : 0) |
+                                     (fabs(l - 1.0) <= 1e-12 ? 4 : 0));
+            if (dec_t0) dec_t0[0] = 0.0;
+        }
         if (vp > 0 && S * chi / vp >= 1) { status = -1; goto done; }
     }
     {
@@ -430,6 +451,7 @@ int orc_integrate(const orc_env *e, const orc_params *p, double lon0, double lat
             double h = 0, t_new = 0, y_new[4], f_new[4];
             while (!accepted) {
                 if (ha < min_step) { failed = 1; break; }
+                s.t_attempt = t;
                 h = ha;
                 t_new = t + h;
                 if (t_new - tb > 0) t_new = tb;
@@ -524,6 +546,14 @@ done:
     return status;
 }
 
+int orc_integrate(const orc_env *e, const orc_params *p, double lon0, double lat0, double v0,
+                  double m0, double h_bl, const double *phases, double *traj, int *n_valid,
+                  int *counters, double *Fs_out)
+{
+    return orc_integrate_probe(e, p, lon0, lat0, v0, m0, h_bl, phases, traj, n_valid, counters, Fs_out,
+                               NULL, NULL, 0);
+}
+
 /* ---------------------------------------------------------------- post-step */
 static double haversine_km(const orc_params *p, double lon1, double lat1, double lon2, double lat2)
 {
@@ -590,23 +620,35 @@ void orc_post(const orc_env *e, const orc_params *p, const double *Fs, int statu
 }
 
 /* Whole ensemble, storm-major outputs.  env_of_month[12] may contain NULLs for unused months. */
-void orc_run_ensemble(const orc_env *const *env_of_month, const orc_params *p, int n,
-                      const double *lon0, const double *lat0, const double *v0, const double *m0,
-                      const double *h_bl, const int *month, const double *phases,
-                      double *traj, double *envw, double *vmax, int *n_valid, int *status,
-                      int *counters, int *flags, int do_post)
+void orc_run_ensemble_probe(const orc_env *const *env_of_month, const orc_params *p, int n,
+                            const double *lon0, const double *lat0, const double *v0, const double *m0,
+                            const double *h_bl, const int *month, const double *phases,
+                            double *traj, double *envw, double *vmax, int *n_valid, int *status,
+                            int *counters, int *flags, int do_post,
+                            unsigned char *dec /* [n][dec_cap] or NULL */, double *dec_t0, int dec_cap)
 {
     int ns = p->n_steps;
     double *Fs = (double *)malloc(sizeof(double) * NW * ns);
     for (int i = 0; i < n; i++) {
         const orc_env *e = env_of_month[month[i] - 1];
         double *tr = traj + (size_t)i * 4 * ns;
-        status[i] = orc_integrate(e, p, lon0[i], lat0[i], v0[i], m0[i], h_bl[i],
-                                  phases + (size_t)i * NW * p->n_series, tr, n_valid + i,
-                                  counters + 5 * i, Fs);
+        status[i] = orc_integrate_probe(e, p, lon0[i], lat0[i], v0[i], m0[i], h_bl[i],
+                                        phases + (size_t)i * NW * p->n_series, tr, n_valid + i,
+                                        counters + 5 * i, Fs, dec ? dec + (size_t)i * dec_cap : NULL,
+                                        dec_t0 ? dec_t0 + (size_t)i * dec_cap : NULL, dec_cap);
         if (do_post)
             orc_post(e, p, Fs, status[i], n_valid[i], tr, envw + (size_t)i * ns * 4,
                      vmax + (size_t)i * ns, flags + 2 * i);
     }
     free(Fs);
+}
+
+void orc_run_ensemble(const orc_env *const *env_of_month, const orc_params *p, int n,
+                      const double *lon0, const double *lat0, const double *v0, const double *m0,
+                      const double *h_bl, const int *month, const double *phases,
+                      double *traj, double *envw, double *vmax, int *n_valid, int *status,
+                      int *counters, int *flags, int do_post)
+{
+    orc_run_ensemble_probe(env_of_month, p, n, lon0, lat0, v0, m0, h_bl, month, phases, traj, envw, vmax,
+                           n_valid, status, counters, flags, do_post, NULL, NULL, 0);
 }

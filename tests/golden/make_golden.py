@@ -110,6 +110,10 @@ def run_set(ref, env, basin, n_scan, seed, per_class, extra=()):
         envw[i, :m] = post['envw']
         vmax[i, :m] = post['vmax'][:m] if m else []
     out.update(traj=traj, envw=envw, vmax=vmax)
+    # decision probe of the reference itself (ref_harness.gen_track), ragged: storm i owns [dec_off[i], dec_off[i+1])
+    out['dec_off'] = np.concatenate([[0], np.cumsum([len(k[1]['dec']) for k in keep])]).astype(np.int64)
+    out['dec'] = np.concatenate([k[1]['dec'] for k in keep]).astype(np.uint8)
+    out['dec_t0'] = np.concatenate([k[1]['dec_t0'] for k in keep]).astype(np.float64)
     print('%s: kept %d of %d scanned; classes %s' % (basin, n, len(cands), counts))
     return out
 

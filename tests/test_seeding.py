@@ -83,6 +83,65 @@ def test_run_tracks_end_to_end(golden_env, built_lib):
         assert np.isnan(lon[i, n_valid[i]:]).all() and np.isnan(vmax[i, n_valid[i]:]).all()
 
 
+def _rows_vs_sequential_oracle(tag, eng, env, basin, year, cand, got, ref):
+    """Rows of compute.run_tracks against the rows of the sequential oracle loop, by the probe method of
+    oracle/parity.py: the kept candidates are re-seeded on both sides (device seeds within 1e-12 of the
+    oracle's), re-integrated with the decision probe on both sides — the device re-run must reproduce
+    run_tracks' rows bit for bit — and compared pointwise / up to the first differing `land == 1` decision."""
+    from oracle import c_oracle, parity, seeding as S
+    seed = int(eng.nl.gpu_experiment_seed)
+    se = S.SeedEnv(env, basin)
+    rows = [S.seed_candidate(se, seed, year, int(c)) for c in cand]
+    o_st = {k: np.array([r[k] for r in rows]) for k in ('lon', 'lat', 'v0', 'm0', 'h_bl', 'month', 'phases')}
+    d_st = {k: [] for k in o_st}
+    for c in cand:
+        d = eng.seed(year, int(c), 1, experiment_seed=seed)
+        for k in d_st:
+            d_st[k].append(d[k][0])
+    d_st = {k: np.array(v) for k, v in d_st.items()}
+    for k in ('lon', 'lat', 'v0', 'm0'):
+        assert np.abs(d_st[k] - o_st[k]).max() < 1e-12, k
+    assert np.array_equal(d_st['h_bl'], o_st['h_bl']) and np.array_equal(d_st['month'], o_st['month'])
+    assert np.array_equal(d_st['phases'], o_st['phases'])
+    dev = eng.integrate(d_st, probe_cap=c_oracle.PROBE_CAP)
+    orc = c_oracle.Ensemble(env, basin).run(o_st, probe=True)
+    lon, lat, v, m, vmax, envw = got[:6]
+    for a, b in ((lon, dev['lon']), (lat, dev['lat']), (v, dev['v']), (m, dev['m']), (vmax, dev['vmax']), (envw, dev['envw'])):
+        assert np.array_equal(a, b, equal_nan=True)              # run_tracks' rows ARE these integrations
+    # and the oracle loop's rows are the oracle's integrations of its own seeds
+    r = ref['tuple9']
+    assert np.array_equal(r[0], orc['traj'][:, 0], equal_nan=True) and np.array_equal(r[4], orc['vmax'], equal_nan=True)
+    assert orc['accepted'].all() and dev['accepted'].all()
+    return parity.check_tracks(tag, dev, orc, dev['dec'], orc['dec'], orc['dec_t0'], eng.t_s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('basin,year,n_tracks,per_rank', [('NA', 2003, 40, 1500), ('GL', 2001, 100, None)])
+def test_run_tracks_vs_sequential_oracle(golden_env, built_lib, basin, year, n_tracks, per_rank):
+    """the batched device run_tracks against the literal sequential loop of
+    util/compute.py:134-210 (oracle/run_tracks.py) for the same Philox key — which candidates end up in the
+    output, in which order, their month / basin, where the n_seeds count stops, and the rows.
+    GL / 100 tracks is BASELINE config 1's size."""
+    from oracle import run_tracks as RT
+    from tropical_cyclone_risk_amd import compute, namelist
+    from tropical_cyclone_risk_amd.basins import TC_Basin
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    eng = TCEngine(basin, device=0).stage_env(golden_env)
+    info = {}
+    got = compute.run_tracks(year, n_tracks, TC_Basin(basin), engine=eng, per_rank=per_rank, info=info)
+    ref = RT.run_tracks(golden_env, basin, year, n_tracks, int(namelist.gpu_experiment_seed))
+    r = ref['tuple9']
+    print('%s/%d: %d candidates, %d integrated, %d is_tc, %d rounds of %d' % (basin, n_tracks, ref['n_candidates'],
+          ref['n_integrated'], ref['n_is_tc'], info['rounds'], info['per_rank']))
+    assert np.array_equal(info['cand'], ref['cand'])             # the same candidates, in the same order
+    assert np.array_equal(got[6], r[6])                          # tc_month
+    assert list(got[7]) == list(r[7])                            # tc_basin
+    assert np.array_equal(got[8], r[8]) and got[8].sum() > n_tracks      # n_seeds: the count stops at the same candidate
+    s = _rows_vs_sequential_oracle('run_tracks-%s' % basin, eng, golden_env, basin, year, info['cand'], got, ref)
+    eng.close()
+    assert s['identical'] + s['diverged'] == n_tracks
+
+
 @pytest.mark.gpu
 def test_run_downscaling_writes_reference_schema(golden_env, built_lib, tmp_path):
     """run_downscaling (compute.py:216-270): years loop + concatenation + track file."""

@@ -33,15 +33,19 @@ for k, e in res.items():
         if c + '_per_dispatch' in e and batches.get(c):
             e[c + '_per_batch'] = e[c + '_per_dispatch'] * e['dispatches_' + c] / batches[c]
     if 'FETCH_SIZE_per_batch' in e and 'WRITE_SIZE_per_batch' in e:
-        # rocprofv3 reports both in KiB
+        # rocprofv3 reports both in KiB.  gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE =
+        # TCC_EA0_RDREQ x 64 B while the L2 fills 128-B lines, i.e. it reports half the bytes read -> doubled.
         e['hbm_bytes_per_batch_raw'] = 1024.0 * (e['FETCH_SIZE_per_batch'] + e['WRITE_SIZE_per_batch'])
+        e['hbm_bytes_per_batch'] = 1024.0 * (2.0 * e['FETCH_SIZE_per_batch'] + e['WRITE_SIZE_per_batch'])
     if e.get('TCC_REQ_sum_per_batch'):
         e['l2_hit_rate'] = e['TCC_HIT_sum_per_batch'] / e['TCC_REQ_sum_per_batch']
-meta = dict(command='rocprofv3 --kernel-trace --output-format csv --pmc <FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum '
-                    'TCC_REQ_sum> -- python bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline (three separate runs)',
-            workload='GL, 100000 storms per batch; the first batch of each run pads whole plane rows (pad_state = -1)',
+rows = sys.argv[2] if len(sys.argv) > 2 else 'tc'
+command = ('rocprofv3 --kernel-trace --output-format csv --pmc <FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum> -- '
+           'python bench.py --steps 3 --warmup 1 --streams 1 --rows %s --no-cpu-baseline (three separate runs)' % rows)
+meta = dict(workload='GL, 100000 storms per batch; the first batch of each run pads whole plane rows (pad_state = -1)',
             units='FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; *_per_batch = summed over the dispatches of a bench step',
-            note='MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x; these kernels '
-                 'issue 16-byte gathers, an uncalibrated pattern, so the raw value is reported (true fetch traffic lies between '
-                 '1x and 2x of it).  WRITE_SIZE matches known byte counts (Fourier table 1.155 GB).')
-print(json.dumps(dict(meta=meta, kernels=res), indent=1))
+            note='hbm_bytes_per_batch = 2 x FETCH_SIZE + WRITE_SIZE: MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B '
+                 'while requests are 128-B line fills, so reads are under-reported 2x; calibrated there on 16-B/lane streaming loads, '
+                 'these kernels issue 16-B/lane gathers (same request size).  WRITE_SIZE matches known byte counts (Fourier table '
+                 '1.155 GB).  *_raw = FETCH_SIZE + WRITE_SIZE uncorrected.  Infinity-Cache hits are counted, so this is fabric-side traffic.')
+print(json.dumps(dict(command=command, rows=rows, meta=meta, kernels=res), indent=1))

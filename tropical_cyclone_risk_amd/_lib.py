@@ -10,7 +10,7 @@ import os
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, 'libtcrisk_hip.so')
 
-TCR_ABI_VERSION = 2
+TCR_ABI_VERSION = 3
 TCR_NW, TCR_NCOV, TCR_MAX_SERIES, TCR_N_BASINS = 4, 10, 32, 7
 STATUS_GATED, STATUS_FINISHED, STATUS_EVENT, STATUS_STEP_FAIL, STATUS_STEP_OVERFLOW = -1, 0, 1, -2, -3
 FLAG_IS_TC, FLAG_ACCEPTED = 1, 2
@@ -26,7 +26,8 @@ EXPORTS = ('tcr_abi_version', 'tcr_ctx_create', 'tcr_ctx_destroy', 'tcr_last_err
            'tcr_probe_rhs_host', 'tcr_fourier_table_host', 'tcr_timing_enable',
            'tcr_timing_last', 'tcr_timing_sum', 'tcr_sync', 'tcr_compact_dev',
            'tcr_gather_seeds_dev', 'tcr_pack_tracks_dev', 'tcr_stats_dev', 'tcr_integrate_pass_stats', 'tcr_wind_stats_dev', 'tcr_wind_stats_host', 'tcr_entropy_table_upload',
-           'tcr_potential_intensity_host', 'tcr_potential_intensity_dev', 'tcr_chi_rh_host')
+           'tcr_potential_intensity_host', 'tcr_potential_intensity_dev', 'tcr_chi_rh_host',
+           'tcr_integrate_probe_host')
 
 
 class Grid(C.Structure):
@@ -62,7 +63,8 @@ class Tracks(C.Structure):
     _fields_ = [('lon', C.c_void_p), ('lat', C.c_void_p), ('v', C.c_void_p), ('m', C.c_void_p),
                 ('vmax', C.c_void_p), ('envw', C.c_void_p), ('n_valid', C.c_void_p),
                 ('status', C.c_void_p), ('flags', C.c_void_p), ('nfev', C.c_void_p),
-                ('n_accept', C.c_void_p), ('n_reject', C.c_void_p), ('pad_state', C.c_void_p)]
+                ('n_accept', C.c_void_p), ('n_reject', C.c_void_p), ('pad_state', C.c_void_p),
+                ('tc_rows_only', C.c_int32)]
 
 
 class Seeds(C.Structure):
@@ -128,6 +130,7 @@ def lib():
     L.tcr_rh_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Grid), DP]
     L.tcr_masks_upload.argtypes = [C.c_void_p, C.POINTER(Grid), U8P, C.POINTER(U8P)]
     L.tcr_integrate_host.argtypes = [C.c_void_p, C.POINTER(Storms), C.POINTER(Tracks)]
+    L.tcr_integrate_probe_host.argtypes = [C.c_void_p, C.POINTER(Storms), C.POINTER(Tracks), C.c_void_p, C.c_int32]
     L.tcr_integrate_dev.argtypes = [C.c_void_p, C.POINTER(Storms), C.POINTER(Tracks), C.c_void_p]
     L.tcr_seed_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_int64, C.POINTER(Seeds), C.c_void_p]
     L.tcr_seed_host.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_int64, C.POINTER(Seeds)]

@@ -102,7 +102,7 @@ class GpuRound:
         self.eng = engine
         self.year = int(year)
         self.seed = experiment_seed
-        self.pipe = DevicePipeline(engine, per_rank, per_rank)
+        self.pipe = DevicePipeline(engine, per_rank, per_rank, tc_rows_only=True)
         self.packed = None
 
     def __call__(self, cand0, count):
@@ -152,12 +152,13 @@ def rows_to_tuple(res, n_steps):
     return (tc_lon, tc_lat, tc_v, tc_m, tc_vmax, tc_env_wnds, tc_month, tc_basin, res['n_seeds'])
 
 
-def run_tracks(year, n_tracks, b, engine=None, env=None, nl=None, per_rank=None):
+def run_tracks(year, n_tracks, b, engine=None, env=None, nl=None, per_rank=None, info=None):
     """Generate n_tracks TC tracks in basin b for one year (reference: compute.py:64-210).
 
     Returns (tc_lon, tc_lat, tc_v, tc_m, tc_vmax, tc_env_wnds, tc_month, tc_basin, n_seeds).
     ``engine`` is a staged TCEngine; if omitted one is built from ``env`` (a field set shaped
-    like ``synthetic.SyntheticEnv``) on this rank's GPU.
+    like ``synthetic.SyntheticEnv``) on this rank's GPU.  ``info`` (a dict, optional) receives what the
+    reference's loop keeps implicit: ``cand`` (global candidate index of every returned track) and ``rounds``.
     """
     nl = nl or default_namelist
     basin_id = b.basin_id if isinstance(b, TC_Basin) else b
@@ -169,6 +170,8 @@ def run_tracks(year, n_tracks, b, engine=None, env=None, nl=None, per_rank=None)
     per_rank = int(per_rank or max(4096, min(nl.gpu_candidate_round, 64 * n_tracks)))
     rf = GpuRound(engine, year, per_rank)
     res = accept_loop(rf, n_tracks, per_rank, engine.n_steps)
+    if info is not None:
+        info.update(cand=res['cand'], rounds=res['rounds'], per_rank=per_rank)
     if own:
         engine.close()
     return rows_to_tuple(res, engine.n_steps)

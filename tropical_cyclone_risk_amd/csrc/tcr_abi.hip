@@ -83,6 +83,11 @@ struct tcr_ctx {
     size_t pf_cap = 0;
     int fs_period = 0;                          // 0: direct Fourier kernel
     int cu_count = 256;
+    int32_t *d_tc_idx = nullptr;                // storms that passed accept test 1 (k_screen -> compaction), tc_rows_only
+    size_t tc_idx_cap = 0;
+    int64_t *d_tc_count = nullptr;
+    uint8_t *d_probe = nullptr;                 // decision probe of the next tcr_integrate_dev (tcr_integrate_probe_host)
+    int probe_cap = 0;
     // timing: four events per timed tcr_integrate_dev call since tcr_timing_enable(ctx, 1)
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -327,7 +332,8 @@ int tcr_ctx_create(int device, tcr_ctx **out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->cu_count = prop.multiProcessorCount;
-    if (hipMalloc(reinterpret_cast<void **>(&ctx->d_queue), kQueueWords * sizeof(unsigned long long)) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void **>(&ctx->d_queue), kQueueWords * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&ctx->d_tc_count), 64) != hipSuccess) {
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return fail(nullptr, "tcr_ctx_create: hipMalloc failed");
@@ -348,7 +354,7 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_run_mask); (void)hipFree(ctx->d_basin_masks);
     (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_srec);
     for (auto &ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
-    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_tab);
+    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_tab);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -592,8 +598,12 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
             a.threshold = last ? 0 : thr;
             a.park_in = ctx->d_park[(pass + 1) & 1];
             a.park_out = ctx->d_park[pass & 1];
-            if (a.D.all_affine) hipLaunchKernelGGL(k_integrate<true>, dim3(waves), dim3(kWave), 0, st, a);
-            else hipLaunchKernelGGL(k_integrate<false>, dim3(waves), dim3(kWave), 0, st, a);
+            if (ctx->d_probe) {
+                a.probe = ctx->d_probe; a.probe_cap = ctx->probe_cap;
+                if (a.D.all_affine) hipLaunchKernelGGL((k_integrate<true, true>), dim3(waves), dim3(kWave), 0, st, a);
+                else hipLaunchKernelGGL((k_integrate<false, true>), dim3(waves), dim3(kWave), 0, st, a);
+            } else if (a.D.all_affine) hipLaunchKernelGGL((k_integrate<true, false>), dim3(waves), dim3(kWave), 0, st, a);
+            else hipLaunchKernelGGL((k_integrate<false, false>), dim3(waves), dim3(kWave), 0, st, a);
             if (last) break;
             waves = (unsigned)(((size_t)waves * (size_t)(thr - 1) + kWave - 1) / kWave);
         }
@@ -607,11 +617,25 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
         a.envw = out->envw; a.flags = out->flags; a.pad_state = out->pad_state;
         make_eval_k(P, a.D, a.K);
         const unsigned chunks = (unsigned)((ns + kPostThreads - 1) / kPostThreads);
+        if (out->tc_rows_only) {
+            // Only what the reference does (compute.py:185-204): accept test 1 from the v series alone, then env
+            // winds, vmax and rows for the storms that passed.  The list stays on the device; the grids are
+            // sized for the whole batch and workgroups beyond *count leave at once.
+            if ((size_t)n > ctx->tc_idx_cap) {
+                if (ctx->d_tc_idx) HIPCHK(ctx, hipFree(ctx->d_tc_idx));
+                ctx->d_tc_idx = nullptr; ctx->tc_idx_cap = 0;
+                if (dev_alloc(ctx, &ctx->d_tc_idx, (size_t)n)) return -1;
+                ctx->tc_idx_cap = (size_t)n;
+            }
+            hipLaunchKernelGGL(k_screen, dim3((unsigned)((n + kScreenStorms - 1) / kScreenStorms)), dim3(kScreenThreads), 0, st, a);
+            if (tcr_compact_dev(ctx, n, out->flags, TCR_FLAG_IS_TC, n, ctx->d_tc_idx, ctx->d_tc_count, st)) return -1;
+            a.list = ctx->d_tc_idx; a.count = ctx->d_tc_count;
+        }
         hipLaunchKernelGGL(k_dense, dim3((unsigned)n), dim3(kWave), 0, st, a, ctx->d_sidx);
         if (a.D.all_affine) hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
         else hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
         hipLaunchKernelGGL(k_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, n, out->n_valid,
-                           out->status, out->v, out->flags, out->pad_state);
+                           out->status, out->v, out->flags, out->pad_state, a.list, a.count);
     }
     if (ev) HIPCHK(ctx, hipEventRecord(ev[3], st));
     HIPCHK(ctx, hipGetLastError());
@@ -644,6 +668,7 @@ int tcr_integrate_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out
         !dout.lat || !dout.v || !dout.m || !dout.vmax || !dout.envw || !dout.n_valid || !dout.status ||
         !dout.flags || !dout.nfev || !dout.n_accept || !dout.n_reject)
         return fail(ctx, "tcr_integrate_host: device allocation / upload failed");
+    dout.tc_rows_only = 0;             // host buffers come back whole: every row is produced
     if (tcr_integrate_dev(ctx, &di, &dout, ctx->stream)) return -1;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 #define D2H(field, count, T) \
@@ -653,6 +678,25 @@ int tcr_integrate_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out
     D2H(n_valid, n, int32_t); D2H(status, n, int32_t); D2H(flags, n, int32_t); D2H(nfev, n, int32_t);
     D2H(n_accept, n, int32_t); D2H(n_reject, n, int32_t);
 #undef D2H
+    return 0;
+}
+
+int tcr_integrate_probe_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out, uint8_t *dec, int32_t cap)
+{
+    if (!ctx) return -1;
+    if (!in || !dec || cap <= 0) return fail(ctx, "tcr_integrate_probe_host: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (in->n <= 0) return 0;
+    DevBuf B;
+    const size_t bytes = (size_t)in->n * (size_t)cap;
+    uint8_t *d = B.get<uint8_t>(bytes);
+    if (!d) return fail(ctx, "tcr_integrate_probe_host: device allocation failed");
+    HIPCHK(ctx, hipMemset(d, 0xff, bytes));
+    ctx->d_probe = d; ctx->probe_cap = cap;
+    const int rc = tcr_integrate_host(ctx, in, out);
+    ctx->d_probe = nullptr; ctx->probe_cap = 0;
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpy(dec, d, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -130,21 +130,27 @@ __global__ __launch_bounds__(256) void k_stats(int64_t n, const int32_t *__restr
                                                const int32_t *__restrict__ nfev, const int32_t *__restrict__ flags,
                                                unsigned long long *__restrict__ out)
 {
-    __shared__ unsigned long long s[4][4];
-    unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    __shared__ unsigned long long s[4][6];
+    unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int nv = n_valid[i];
         a0 += nv > 1 ? nv - 1 : 0;
         a1 += nfev[i];
         a2 += nv;
         a3 += (flags[i] & TCR_FLAG_ACCEPTED) ? 1 : 0;
+        a4 += (flags[i] & TCR_FLAG_IS_TC) ? 1 : 0;
+        a5 += (flags[i] & TCR_FLAG_IS_TC) ? nv : 0;
     }
     for (int off = 32; off > 0; off >>= 1) {
         a0 += __shfl_down(a0, off); a1 += __shfl_down(a1, off); a2 += __shfl_down(a2, off); a3 += __shfl_down(a3, off);
+        a4 += __shfl_down(a4, off); a5 += __shfl_down(a5, off);
     }
-    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; s[w][0] = a0; s[w][1] = a1; s[w][2] = a2; s[w][3] = a3; }
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        s[w][0] = a0; s[w][1] = a1; s[w][2] = a2; s[w][3] = a3; s[w][4] = a4; s[w][5] = a5;
+    }
     __syncthreads();
-    if (threadIdx.x < 4) atomicAdd(out + threadIdx.x, s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x]);
+    if (threadIdx.x < 6) atomicAdd(out + threadIdx.x, s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x]);
 }
 
 // Pack selected tracks into fixed-size survivor records for the all-gather:

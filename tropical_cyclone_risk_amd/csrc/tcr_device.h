@@ -326,6 +326,7 @@ struct Rhs {
     double w[4];     // raw env winds at the point (what _env_winds returns)
     double alpha;    // ocean feedback (probe only)
     double shear, vpot, chi;   // what the ventilation gate needs (coupled_fast.py:238-244)
+    int dec;         // decision probe (tests only; dead code elsewhere): bit0 `land == 1`, bit1 PI != 0, bit2 |land - 1| <= 1e-12
 };
 
 // Everything of dydt after the lookups: steering, beta-advection, _dvdt, ocean feedback, _dmdt.
@@ -362,6 +363,7 @@ __device__ __forceinline__ void rhs_tail(const EvalK &K, double h_bl, double lat
     r.d[1] = vb1 / RD(K.earth_R) * 180. / kPi;
     // intensity
     const double vp = (lb[0] == 1.0) ? 0.0 : th[0];                        // coupled_fast.py:35-58
+    r.dec = (lb[0] == 1.0 ? 1 : 0) | (th[0] != 0.0 ? 2 : 0) | (fabs(lb[0] - 1.0) <= 1e-12 ? 4 : 0);
     const double h_m = th[2], gam = th[3], bathy = lb[1];
     const bool no_mix = (bathy >= 0) || (-h_m <= bathy) || (gam == 0);
     const double uT = sqrt(vb0 * vb0 + vb1 * vb1);

@@ -47,6 +47,11 @@ struct KArgs {
     int threshold;               // park the wave's storms and exit once fewer lanes than this are live (0: run to the end)
     const double *park_in;       // [.. ][kParkRec] list written by the previous pass
     double *park_out;            // list this pass writes
+    // decision probe (PROBE instantiation only, tcr_integrate_probe_host): probe[storm][probe_cap], one byte
+    // per evaluation of fun in call order (Rhs::dec), so tests can find the first `land == 1` decision
+    // that lands differently from the oracle's (oracle/parity.py)
+    uint8_t *probe;
+    int probe_cap;
 };
 constexpr int kMaxPasses = 16;
 constexpr int kParkRec = 16;     // doubles per parked storm: t, h, t_new, ha, g, y[4], f[4], 6 x int32
@@ -229,7 +234,7 @@ constexpr int kRunning = 99;
 // the two evaluations of RungeKutta.__init__ (f0 and select_initial_step's f1) and idles
 // for the other four.  Every accepted step leaves one kStepRec-double record
 // (t_old, h, t_new, y_old, K[7][4]) from which k_emit evaluates the hourly samples.
-template <bool AFFINE>
+template <bool AFFINE, bool PROBE>
 __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
 {
     // Kl[(stage*4 + component)*64 + lane]
@@ -382,6 +387,10 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
             const EvalK &Kq = K;
 #endif
             if (live) r = rhs_eval_cached<AFFINE>(CC, Kq, S, fs, h_bl, e[0], e[1], e[2], e[3], e[4]);
+            if (PROBE && live) {
+                const int ev = fresh ? slot : nfev;          // index of this evaluation in the storm's call order
+                if (ev < a.probe_cap) a.probe[(size_t)sid * a.probe_cap + ev] = (uint8_t)r.dec;
+            }
             if (live && !fresh) {
                 // rk_step (rk.py:62-70): K[s] = fun(...); next stage input dy = dot(K[:s].T, a[:s]) * h
                 ++nfev;
@@ -527,9 +536,13 @@ struct EArgs {
     double *lon, *lat, *v, *m, *vmax, *envw;
     int32_t *flags;
     const int32_t *pad_state;    // rows are already NaN from this sample on (NULL / <0: unknown), see tcrisk_hip.h
+    // TC-rows-only mode (tcr_tracks.tc_rows_only): the kernels run over list[0 .. *count) — the storms k_screen
+    // found to pass accept test 1 — instead of over every storm of the batch (list == NULL)
+    const int32_t *list;
+    const int64_t *count;
     EvalK K;                     // built on the host; k_emit's small workgroups copy it to LDS with one load per lane
 };
-static_assert(sizeof(EvalK) % 8 == 0 && sizeof(EvalK) / 8 <= 128, "EvalK is copied to LDS as <= 128 eight-byte words");
+static_assert(sizeof(EvalK) % 8 == 0, "EvalK is copied to LDS in eight-byte words");
 constexpr int kBitAny15 = 1 << 8, kBitVmax = 1 << 9;     // scratch bits in flags[] between the kernels
 #ifndef TCR_POST_THREADS
 #define TCR_POST_THREADS 128
@@ -547,7 +560,8 @@ constexpr int kEmitSlotCache = 32;      // field-slot wind pointers kept in LDS 
 __global__ __launch_bounds__(kWave) void k_dense(EArgs a, uint16_t *__restrict__ sidx)
 {
     const tcr_params &P = a.P;
-    const int64_t sid = blockIdx.x;
+    if (a.list && (int64_t)blockIdx.x >= *a.count) return;
+    const int64_t sid = a.list ? (int64_t)a.list[blockIdx.x] : (int64_t)blockIdx.x;
     const int ns = P.n_steps;
     const int n = a.n_valid[sid];
     int nst = a.n_accept[sid];
@@ -659,7 +673,8 @@ __global__ __launch_bounds__(kPostThreads, TCR_EMIT_WPS) void k_emit(EArgs a, co
     __shared__ EvalK K;
     __shared__ const double *s_wind[kEmitSlotCache];
     const tcr_params &P = a.P;
-    const int64_t sid = blockIdx.x;
+    if (a.list && (int64_t)blockIdx.x >= *a.count) return;            // uniform per workgroup
+    const int64_t sid = a.list ? (int64_t)a.list[blockIdx.x] : (int64_t)blockIdx.x;
     const int ns = P.n_steps;
     const int i = blockIdx.y * kPostThreads + threadIdx.x;
     // the three per-storm / per-sample indices are independent loads: one round trip, not three
@@ -671,8 +686,8 @@ __global__ __launch_bounds__(kPostThreads, TCR_EMIT_WPS) void k_emit(EArgs a, co
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     const bool live_block = (int)(blockIdx.y * kPostThreads) < n;
     if (live_block) {
-        if (threadIdx.x < sizeof(EvalK) / 8)
-            reinterpret_cast<uint64_t *>(&K)[threadIdx.x] = reinterpret_cast<const uint64_t *>(&a.K)[threadIdx.x];
+        for (unsigned w = threadIdx.x; w < sizeof(EvalK) / 8; w += kPostThreads)       // any workgroup size (69 words)
+            reinterpret_cast<uint64_t *>(&K)[w] = reinterpret_cast<const uint64_t *>(&a.K)[w];
         if (threadIdx.x < kEmitSlotCache && (int)threadIdx.x < a.D.n_slots) s_wind[threadIdx.x] = a.D.slots[threadIdx.x].wind;
         __syncthreads();
     }
@@ -731,12 +746,87 @@ __global__ __launch_bounds__(kPostThreads, TCR_EMIT_WPS) void k_emit(EArgs a, co
     }
 }
 
+// k_screen: accept test 1 (util/compute.py:185-189) without producing a single row.  The reference
+// recomputes env winds, computes vmax and writes rows only for candidates that pass this test
+// (compute.py:190-204) — ~10 % of the integrated storms — and it needs only the hourly v series:
+// `any(v >= 15)` and `np.interp(2 d, res.t, v) >= 6.5`.  So: 16 lanes per storm, lane = accepted step;
+// a lane forms row 2 (v) of its step's dense-output matrix Q = K^T P (rk.py:179-181) and walks the
+// hourly samples of its step (ivp.py:706-723).  The arithmetic is k_dense's and dense_at's, operation
+// for operation, so the v values — and therefore the decision — are bit-identical to what k_emit
+// writes for the same storm and what k_flags would decide from those rows.  Writes flags[] only.
+constexpr int kScreenThreads = 256;
+constexpr int kScreenGroup = 16;                                   // lanes per storm
+constexpr int kScreenStorms = kScreenThreads / kScreenGroup;       // storms per workgroup
+
+__global__ __launch_bounds__(kScreenThreads) void k_screen(EArgs a)
+{
+    __shared__ double cap[kScreenStorms][3];      // v at sample j2d, j2d + 1, n - 1
+    const tcr_params &P = a.P;
+    const int g = threadIdx.x / kScreenGroup, l = threadIdx.x % kScreenGroup;
+    const int64_t sid = (int64_t)blockIdx.x * kScreenStorms + g;
+    const bool on = sid < a.n;
+    const int ns = P.n_steps;
+    int n = 0, nst = 0, st = TCR_STATUS_GATED;
+    if (on) {
+        n = a.n_valid[sid]; nst = a.n_accept[sid]; st = a.status[sid];
+        nst = nst < a.max_rk_steps ? nst : a.max_rk_steps;
+    }
+    // np.interp(2 d, res.t, v): which samples it reads (compute.py:186-188; same as k_flags)
+    const double step_out = P.total_time / (double)(ns - 1);
+    const double t2d = 2 * 86400.0;
+    const bool clamp2d = n > 0 && t2d >= ts_at(P, n - 1);
+    const int j2d = clamp2d ? n - 1 : (int)floor(t2d / step_out);
+    bool any15 = false;
+    const double *srec_storm = a.srec + sid * (int64_t)a.max_rk_steps * kStepRec;
+    for (int j = l; j < nst && n > 0; j += kScreenGroup) {
+        const double *rj = srec_storm + (size_t)j * kStepRec;
+        const double t_old = rj[0], hh = rj[1], t_new = rj[2], y0 = rj[6];
+        double kq[7];
+        for (int q = 0; q < 7; ++q) kq[q] = rj[8 + q * 4 + 2];
+        double Q[4];
+        for (int k = 0; k < 4; ++k) {
+            double acc = 0.0;
+            for (int q = 0; q < 7; ++q) acc += kq[q] * RK_P[q][k];
+            Q[k] = acc;
+        }
+        const int i_lo = (j == 0) ? 0 : samples_upto(P, t_old);
+        int i_hi = samples_upto(P, t_new);
+        i_hi = i_hi < n ? i_hi : n;
+        for (int i = i_lo; i < i_hi; ++i) {
+            const double te = ts_at(P, i);
+            const double x = (te - t_old) / hh;
+            const double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
+            double acc = 0.0;
+            acc += Q[0] * p1; acc += Q[1] * p2; acc += Q[2] * p3; acc += Q[3] * p4;
+            const double v = hh * acc + y0;
+            any15 = any15 || (v >= P.v_thresh);
+            if (i == j2d) cap[g][0] = v;
+            if (i == j2d + 1) cap[g][1] = v;
+            if (i == n - 1) cap[g][2] = v;
+        }
+    }
+    for (int off = kScreenGroup / 2; off > 0; off >>= 1) any15 = any15 || (__shfl_xor((int)any15, off) != 0);
+    __syncthreads();
+    if (on && l == 0) {
+        int fl = 0;
+        if (n > 0 && st != TCR_STATUS_GATED) {
+            double v2d;
+            if (clamp2d) v2d = cap[g][2];
+            else v2d = (cap[g][1] - cap[g][0]) / (ts_at(P, j2d + 1) - ts_at(P, j2d)) * (t2d - ts_at(P, j2d)) + cap[g][0];
+            if (any15 && v2d >= P.v_2d_thresh) fl = TCR_FLAG_IS_TC;
+        }
+        a.flags[sid] = fl;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_flags(tcr_params P, int64_t n_storms, const int32_t *__restrict__ n_valid,
                                                const int32_t *__restrict__ status, const double *__restrict__ pv,
-                                               int32_t *__restrict__ flags, int32_t *__restrict__ pad_state)
+                                               int32_t *__restrict__ flags, int32_t *__restrict__ pad_state,
+                                               const int32_t *__restrict__ list, const int64_t *__restrict__ count)
 {
-    const int64_t sid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (sid >= n_storms) return;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (list ? *count : n_storms)) return;
+    const int64_t sid = list ? (int64_t)list[gid] : gid;
     const int ns = P.n_steps;
     const int n = n_valid[sid];
     if (pad_state) pad_state[sid] = n;         // every k_emit block of the row has read the old value

@@ -162,9 +162,10 @@ class TCEngine:
         return self
 
     # -------------------------------------------------------------- hot path
-    def integrate(self, storms):
+    def integrate(self, storms, probe_cap=0):
         """Integrate + post-process a batch given as host arrays (dict with lon, lat, v0,
-        m0, h_bl, month (1..12), phases [n,4,N]); returns a dict of NumPy arrays."""
+        m0, h_bl, month (1..12), phases [n,4,N]); returns a dict of NumPy arrays.  probe_cap > 0 adds
+        'dec' [n, probe_cap] uint8, the per-evaluation `land == 1` decisions (tcr_integrate_probe_host)."""
         n = len(storms['lon'])
         ns = self.n_steps
         lon0, lat0, v0, m0, h_bl = (_f64(storms[k]) for k in ('lon', 'lat', 'v0', 'm0', 'h_bl'))
@@ -174,12 +175,18 @@ class TCEngine:
         out['envw'] = np.empty((n, ns, 4))
         out.update({k: np.zeros(n, np.int32) for k in TRACK_I32})
         if n == 0:
+            if probe_cap:
+                out['dec'] = np.full((0, int(probe_cap)), 0xff, np.uint8)
             return self._finish(out)
         si = _lib.Storms(n, *[a.ctypes.data for a in (lon0, lat0, v0, m0, h_bl, slot, ph)])
         so = _lib.Tracks(*[out[k].ctypes.data for k in ('lon', 'lat', 'v', 'm', 'vmax', 'envw',
                                                          'n_valid', 'status', 'flags', 'nfev',
                                                          'n_accept', 'n_reject')])
-        self._ck(self.L.tcr_integrate_host(self.h, C.byref(si), C.byref(so)))
+        if probe_cap:
+            out['dec'] = np.full((n, int(probe_cap)), 0xff, np.uint8)
+            self._ck(self.L.tcr_integrate_probe_host(self.h, C.byref(si), C.byref(so), out['dec'].ctypes.data, int(probe_cap)))
+        else:
+            self._ck(self.L.tcr_integrate_host(self.h, C.byref(si), C.byref(so)))
         return self._finish(out)
 
     @staticmethod

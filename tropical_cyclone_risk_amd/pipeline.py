@@ -20,7 +20,10 @@ I32 = torch.int32
 
 
 class DevicePipeline:
-    def __init__(self, engine, max_candidates, max_storms, device=None, sort_storms=False):
+    def __init__(self, engine, max_candidates, max_storms, device=None, sort_storms=False, tc_rows_only=False):
+        # tc_rows_only: produce rows only for storms that pass accept test 1, as the reference does
+        # (compute.py:190-204, tcr_tracks.tc_rows_only); False = every row (what parity tests compare)
+        self.tc_rows_only = bool(tc_rows_only)
         self.eng = engine
         self.dev = torch.device('cuda', engine.device) if device is None else device
         self.C, self.B = int(max_candidates), int(max_storms)
@@ -59,7 +62,8 @@ class DevicePipeline:
     def _tracks_struct(self):
         t = self.tracks
         return _lib.Tracks(*[t[k].data_ptr() for k in ('lon', 'lat', 'v', 'm', 'vmax', 'envw', 'n_valid',
-                                                        'status', 'flags', 'nfev', 'n_accept', 'n_reject', 'pad_state')])
+                                                        'status', 'flags', 'nfev', 'n_accept', 'n_reject', 'pad_state')],
+                           1 if self.tc_rows_only else 0)
 
     def _stream(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
@@ -123,7 +127,8 @@ class DevicePipeline:
         self.n_done = n
 
     def add_stats(self, counters):
-        """counters (uint64/int64 tensor [4]) += storm-steps, RHS evaluations, samples, accepted."""
+        """counters (uint64/int64 tensor [6]) += storm-steps, RHS evaluations, samples, accepted, is_tc storms,
+        samples of is_tc storms."""
         so = self._tracks_struct()
         self.eng._ck(self.eng.L.tcr_stats_dev(self.eng.h, self.n_done, C.byref(so), counters.data_ptr(),
                                               C.c_void_p(self._stream())))
