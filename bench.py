@@ -304,7 +304,8 @@ def cpu_baseline(pipe, args, B):
                       'env-wind recompute + vmax) on the first %d storms of the last GPU batch, %d worker '
                       'processes, %.1f s' % (best['storms'], best.get('procs', 1), best['seconds']),
             'value_1core': res['one_core']['value'], 'storms_1core': res['one_core']['storms'],
-            'per_core_efficiency': best.get('per_core_efficiency'),
+            'per_core_efficiency': best.get('per_core_efficiency'), 'cgroup_cpu_quota': best.get('cgroup_cpu_quota'),
+            'physical_cores_visible': best.get('physical_cores_visible'),
             'c_port_1core': res.get('c_port_one_core')}
 
 

@@ -95,6 +95,10 @@ typedef struct {
     const double *h_bl;                     /* fast.h_bl = atm_bl_depth[basin] (compute.py:175) */
     const int32_t *slot;                    /* field slot = genesis month - 1 (compute.py:151-152) */
     const double *phases;                   /* [n][4][n_series] uniforms of gen_f (bam_track.py:27) */
+    /* Optional device scalar (tcr_integrate_dev only; NULL otherwise): only the first min(n, *n_dev) storms
+     * exist — the count tcr_compact_dev left on the device — so a round of the accept loop needs no host
+     * synchronisation between seeding and integration.  Grids are sized for n; flags of the rows beyond are 0. */
+    const int64_t *n_dev;
 } tcr_storms;
 
 /* Outputs: the per-storm part of run_tracks' 9-tuple (compute.py:124-133, 210) */
@@ -196,12 +200,13 @@ int tcr_gather_seeds_dev(tcr_ctx *ctx, const tcr_seeds *src_dev, const int32_t *
  * (sum of max(n_valid-1, 0)), [1] = RHS evaluations, [2] = output samples, [3] = accepted tracks,
  * [4] = storms that passed accept test 1 (is_tc), [5] = output samples of those storms (the rows
  * tc_rows_only produces); the six uint64 counters are ADDED to (zero them first). */
-int tcr_stats_dev(tcr_ctx *ctx, int64_t n, const tcr_tracks *tracks_dev, uint64_t *out_dev, void *stream);
+int tcr_stats_dev(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const tcr_tracks *tracks_dev, uint64_t *out_dev, void *stream);
 /* survivor records for the all-gather of final tracks (compute.py:233-242 concatenation):
  * packed[r] = { lon[ns], lat[ns], v[ns], m[ns], vmax[ns], envw[ns][4] } of track idx[r],
- * r < min(*count_dev, cap). */
+ * r < min(*count_dev, cap); rows are row_stride doubles apart (0 = 9 * ns; larger leaves room for the
+ * caller's own columns, e.g. candidate index / month / basin). */
 int tcr_pack_tracks_dev(tcr_ctx *ctx, const tcr_tracks *src_dev, const int32_t *idx_dev,
-                        const int64_t *count_dev, int64_t cap, double *packed_dev, void *stream);
+                        const int64_t *count_dev, int64_t cap, double *packed_dev, int64_t row_stride, void *stream);
 
 /* ---- preprocessing next to the path ----------------------- */
 /* replaces: calc_wnd_stat (track/env_wind.py:180-228) for one month: wnd[c] = ua250, va250,

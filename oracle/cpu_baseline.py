@@ -38,6 +38,33 @@ def _work(idx):
     return int(np.clip(o['n_valid'] - 1, 0, None).sum()), int(o['nfev'].sum()), len(idx)
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota); None if unlimited.
+    The GPU boxes of this pool show 256 logical CPUs but run under `cpu.max = 1600000 100000`, i.e. 16 cores:
+    forking one worker per visible core (round 1) measured the quota, not the cores."""
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            return float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if q > 0:
+            return q / per
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def usable_cores():
+    """Worker processes to fork: physical cores of the affinity mask, capped by the cgroup CPU quota."""
+    n = physical_cores()
+    q = cgroup_cpu_quota()
+    return max(1, min(n, int(q))) if q else n
+
+
 def physical_cores():
     """Cores in this process's affinity mask, counting SMT siblings once."""
     cpus = sorted(os.sched_getaffinity(0))
@@ -69,7 +96,7 @@ def main():
     z = np.load(a.inputs)
     _STORMS = {k: z[k] for k in z.files}
     n_avail = len(_STORMS['lon'])
-    procs = a.procs or physical_cores()
+    procs = a.procs or usable_cores()
 
     # calibrate on a handful of storms, then size both legs to the time budget
     t0 = time.perf_counter(); s0, _, _ = _work(list(range(min(8, n_avail)))); per = (time.perf_counter() - t0) / min(8, n_avail)
@@ -85,6 +112,7 @@ def main():
             t0 = time.perf_counter(); res = pool.map(_work, chunks); dtP = time.perf_counter() - t0
         stepsP = sum(r[0] for r in res)
         out['all_cores'] = dict(storm_steps=stepsP, seconds=dtP, storms=nP, value=stepsP / dtP, procs=procs,
+                                physical_cores_visible=physical_cores(), cgroup_cpu_quota=cgroup_cpu_quota(),
                                 per_core_efficiency=(stepsP / dtP) / (procs * steps1 / dt1))
     # the plain-C restatement (oracle/tc_oracle.c) on one core, for scale: same algorithm without the
     # interpreter / SciPy call overhead that dominates the reference's own CPU path

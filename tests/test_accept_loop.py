@@ -91,6 +91,43 @@ def test_gloo_ranks_match_sequential(world, per_rank):
         assert np.array_equal(r_seeds, n_seeds), rank
 
 
+def _overflow_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from tropical_cyclone_risk_amd import compute, distributed as D
+    D.init_from_env(backend='gloo')
+
+    def round_fn(cand0, count):
+        out = fake_round(cand0, count)
+        out['bad'] = 3 if rank == 1 else 0          # only rank 1 has storms that overflowed their step record
+        return out
+    try:
+        compute.accept_loop(round_fn, 25, 64, NS)
+        q.put((rank, 'no error'))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    D.barrier()                                    # both ranks get here: nobody is left waiting in a collective
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_step_record_overflow_raises_on_every_rank():
+    """A storm that overflows its step record on ONE rank must abort the round on EVERY rank (the count is part of
+    the round's one all-gather), not leave the others hanging in the row all-gather."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overflow_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all('gpu_max_rk_steps' in got[r] and got[r].startswith('3 storms') for r in (0, 1)), got
+
+
 def test_allgather_rows_ragged_gloo():
     """Ragged all-gather incl. an empty contribution and the rank-order guarantee."""
     ctx = mp.get_context('spawn')

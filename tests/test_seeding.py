@@ -143,6 +143,42 @@ def test_run_tracks_vs_sequential_oracle(golden_env, built_lib, basin, year, n_t
 
 
 @pytest.mark.gpu
+def test_product_round_is_device_resident(golden_env, built_lib):
+    """compute.GpuRound — the round function run.py's accept loop calls — keeps everything on the device: a whole
+    round (seed, select, integrate, TC-rows-only post-processing, pack, meta columns, n_seeds histogram) runs
+    without a single host synchronisation (torch's sync debug mode raises on one), and hands the accept loop
+    device tensors; the loop itself syncs once per round, for the (count, overflow) pairs."""
+    import torch
+    from tropical_cyclone_risk_amd import compute
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    eng = TCEngine('NA', device=0).stage_env(golden_env)
+    rf = compute.GpuRound(eng, 2003, 4096)
+    rf(0, 4096)                                   # first call sizes the library's workspaces
+    cut = torch.tensor(5000.0, device=rf.pipe.dev, dtype=torch.float64)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        out = rf(4096, 4096)
+        h = out['hist']()
+        h2 = out['hist'](cut)
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    assert out['rows'].is_cuda and out['count'].is_cuda and out['bad'].is_cuda and h.is_cuda
+    n_acc = int(out['count'].item())
+    width = 9 * eng.n_steps
+    rows = out['rows'][:n_acc].cpu().numpy()
+    assert n_acc > 0 and (np.diff(rows[:, width]) > 0).all() and rows[:, width].min() >= 4096 and rows[:, width].max() < 8192
+    assert int(out['bad'].item()) == 0 and h.sum().item() > h2.sum().item() > 0
+    # the same round through the host-visible pieces: seeds, flags
+    flags = rf.pipe.tracks['flags'][:4096].cpu().numpy()
+    n_pass = int(rf.pipe.n_passed.item())
+    assert (flags[n_pass:] == 0).all() and ((flags[:n_pass] & 2) != 0).sum() == n_acc
+    month = rows[:, width + 1]
+    assert ((month >= 1) & (month <= 12)).all()
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_run_downscaling_writes_reference_schema(golden_env, built_lib, tmp_path):
     """run_downscaling (compute.py:216-270): years loop + concatenation + track file."""
     import types

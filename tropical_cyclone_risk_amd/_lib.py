@@ -56,7 +56,8 @@ class Params(C.Structure):
 
 class Storms(C.Structure):
     _fields_ = [('n', C.c_int64), ('lon0', C.c_void_p), ('lat0', C.c_void_p), ('v0', C.c_void_p),
-                ('m0', C.c_void_p), ('h_bl', C.c_void_p), ('slot', C.c_void_p), ('phases', C.c_void_p)]
+                ('m0', C.c_void_p), ('h_bl', C.c_void_p), ('slot', C.c_void_p), ('phases', C.c_void_p),
+                ('n_dev', C.c_void_p)]
 
 
 class Tracks(C.Structure):
@@ -154,9 +155,9 @@ def lib():
                                   C.c_void_p, C.c_void_p, C.c_void_p]
     L.tcr_gather_seeds_dev.argtypes = [C.c_void_p, C.POINTER(Seeds), C.c_void_p, C.c_int64, C.c_void_p,
                                        C.POINTER(Seeds), C.c_uint64, C.c_int32, C.c_int64, C.c_void_p]
-    L.tcr_stats_dev.argtypes = [C.c_void_p, C.c_int64, C.POINTER(Tracks), C.c_void_p, C.c_void_p]
+    L.tcr_stats_dev.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(Tracks), C.c_void_p, C.c_void_p]
     L.tcr_pack_tracks_dev.argtypes = [C.c_void_p, C.POINTER(Tracks), C.c_void_p, C.c_void_p,
-                                      C.c_int64, C.c_void_p, C.c_void_p]
+                                      C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
     if L.tcr_abi_version() != TCR_ABI_VERSION:
         raise TcrError('libtcrisk_hip.so ABI version %d != binding version %d'
                        % (L.tcr_abi_version(), TCR_ABI_VERSION))

@@ -11,8 +11,13 @@ from . import namelist
 
 _EPS = 1e-5
 
-# order used for per-basin tables (sorted ids without 'GL', compute.py:87)
-BASIN_IDS = tuple(sorted(k for k in namelist.basin_bounds if k != 'GL'))
+def basin_ids(nl=None):
+    """Order used for per-basin tables: sorted ids without 'GL' (compute.py:87), of `nl` (default: the package namelist,
+    read now — a later `namelist.load()` is seen)."""
+    return tuple(sorted(k for k in (nl or namelist).basin_bounds if k != 'GL'))
+
+
+BASIN_IDS = basin_ids()      # the seven reference basins; the device tables (TCR_N_BASINS) are laid out in this order
 
 
 def _parse_bound(token):
@@ -22,11 +27,13 @@ def _parse_bound(token):
 
 
 class TC_Basin:
-    def __init__(self, basin_id):
-        if basin_id.upper() not in namelist.basin_bounds:
+    def __init__(self, basin_id, nl=None):
+        """`nl`: the namelist whose `basin_bounds` define the box (default: the package namelist)."""
+        bounds = (nl or namelist).basin_bounds
+        if basin_id.upper() not in bounds:
             raise ValueError('Basin ID is not valid. See list of valid basins.')
         self.basin_id = basin_id
-        self.basin_bounds = namelist.basin_bounds[basin_id]
+        self.basin_bounds = bounds[basin_id]
 
     def get_bounds(self):
         """(lon_min, lat_min, lon_max, lat_max) in degrees."""

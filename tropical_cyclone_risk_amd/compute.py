@@ -32,68 +32,94 @@ from .basins import BASIN_IDS, TC_Basin
 ROW_VARS = 9          # lon, lat, v, m, vmax, u250, v250, u850, v850 per output sample
 
 
-def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000):
-    """Order-preserving accept loop over rounds of candidates (CPU logic, backend-agnostic).
+N_META = 3          # columns appended to a survivor record: global candidate index, month (1..12), basin index
 
-    round_fn(cand0, count) -> dict with, for the candidates [cand0, cand0+count) of THIS rank:
-        counted   bool[count]   counts toward n_seeds (compute.py:165-167)
-        basin_idx int[count], month int[count] (1..12)
-        acc_cand  int64[a]      global candidate index of each accepted track, ascending
-        acc_rows  float64[a, 9*n_steps]  survivor records (lon, lat, v, m, vmax, envw[ns][4])
-        acc_month int[a], acc_basin int[a]
-    Returns dict(rows [n_tracks, 9*n_steps], month, basin_idx, cand, n_seeds [7, 12], rounds).
-    Every rank returns the same result.
+
+def _legacy_round(out, cand0, n_steps, torch):
+    """Adapter for round functions that return host arrays (the CPU tests' fake rounds):
+    counted / basin_idx / month per candidate, acc_cand / acc_rows / acc_month / acc_basin per accepted track."""
+    a = len(out['acc_cand'])
+    width = ROW_VARS * n_steps
+    rows = np.zeros((a, width + N_META))
+    if a:
+        rows[:, :width] = np.asarray(out['acc_rows'], dtype=np.float64).reshape(a, width)
+        rows[:, width] = np.asarray(out['acc_cand'], dtype=np.float64)
+        rows[:, width + 1] = np.asarray(out['acc_month'], dtype=np.float64)
+        rows[:, width + 2] = np.asarray(out['acc_basin'], dtype=np.float64)
+    dev = out.get('device', 'cpu')
+    counted = np.asarray(out['counted'], bool)
+    key = np.asarray(out['basin_idx']).astype(np.int64) * 12 + (np.asarray(out['month']).astype(np.int64) - 1)
+    idx = cand0 + np.arange(len(counted))
+
+    def hist(cutoff=None):
+        keep = counted if cutoff is None else counted & (idx <= int(cutoff))
+        return torch.from_numpy(np.bincount(key[keep], minlength=len(BASIN_IDS) * 12).astype(np.float64)).to(dev)
+    return dict(rows=torch.from_numpy(rows).to(dev), count=torch.tensor([a], dtype=torch.int64, device=dev),
+                bad=torch.tensor([int(out.get('bad', 0))], dtype=torch.int64, device=dev), hist=hist)
+
+
+def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000):
+    """Order-preserving accept loop over rounds of candidates (backend-agnostic: RCCL on the GPUs, gloo in the
+    CPU tests).
+
+    round_fn(cand0, count) handles the candidates [cand0, cand0+count) of THIS rank and returns, on its device,
+        rows   float64 [cap, 9*n_steps + 3]: survivor records (lon, lat, v, m, vmax, envw[ns][4]) of the accepted
+               tracks in candidate order, then the columns global candidate index, month, basin index
+        count  int64 [1]: how many rows are valid;  bad int64 [1]: storms that overflowed their step record
+        hist(cutoff=None) -> float64 [7*12]: candidates counting toward n_seeds (compute.py:165-167) per
+               (basin, month), optionally only those with global index <= cutoff
+    (or the host-array dict of `_legacy_round`).  Survivor rows never leave the device between the kernels
+    and the collective; the loop synchronises with the host ONCE per round — to read the per-rank (count,
+    overflow) pairs that size the all-gather — and the result is copied to the host once, at the end.
+    Returns dict(rows [n_tracks, 9*n_steps], month, basin_idx, cand, n_seeds [7, 12], rounds); every rank
+    returns the same result.
     """
     import torch
     W, rk = D.world(), D.rank()
-    got_rows, got_cand, got_month, got_basin = [], [], [], []
-    n_seeds = np.zeros((len(BASIN_IDS), 12))
-    total = 0
-    pending_counts = []          # per-round (cand index, counted, basin, month) of this rank, for the cutoff
+    width = ROW_VARS * n_steps
+    got, total, hist_full, last = [], 0, None, None
     for r in range(max_rounds):
         cand0 = D.round_block(r, per_rank, rk, W)
         out = round_fn(cand0, per_rank)
-        a = len(out['acc_cand'])
-        dev = out.get('device', 'cpu')
-        # ---- the data-path collective: all-gather of this round's survivor records
-        meta = np.stack([np.asarray(out['acc_cand'], dtype=np.float64), np.asarray(out['acc_month'], dtype=np.float64),
-                         np.asarray(out['acc_basin'], dtype=np.float64)], axis=1) if a else np.zeros((0, 3))
-        rows = np.concatenate([np.asarray(out['acc_rows'], dtype=np.float64).reshape(a, 9 * n_steps), meta], axis=1)
-        t_rows = torch.from_numpy(np.ascontiguousarray(rows)).to(dev)
-        cnt = torch.tensor([a], dtype=torch.int64, device=dev)
-        gathered, counts = D.allgather_rows(t_rows, cnt)
-        g = gathered.cpu().numpy()
-        # rank blocks are contiguous and ascending, so rank order == candidate order
-        assert (np.diff(g[:, -3]) > 0).all() if len(g) > 1 else True
-        got_rows.append(g[:, :-3]); got_cand.append(g[:, -3].astype(np.int64))
-        got_month.append(g[:, -2].astype(np.int64)); got_basin.append(g[:, -1].astype(np.int64))
-        pending_counts.append((cand0, np.asarray(out['counted'], bool), np.asarray(out['basin_idx']),
-                               np.asarray(out['month'])))
-        total += len(g)
+        if 'rows' not in out:
+            out = _legacy_round(out, cand0, n_steps, torch)
+        # ---- the one host synchronisation of the round: (accepted, overflowed) of every rank
+        pairs = D.allgather_ints(torch.cat([out['count'].reshape(1), out['bad'].reshape(1)]))
+        counts, bads = [p[0] for p in pairs], [p[1] for p in pairs]
+        if sum(bads):           # decided collectively: every rank raises, none is left waiting in a collective
+            raise RuntimeError('%d storms needed more accepted RK steps than the step record holds; raise '
+                               'namelist.gpu_max_rk_steps (tcr_params.max_rk_steps)' % sum(bads))
+        if counts[rk] > out['rows'].shape[0]:
+            raise RuntimeError('accept_loop: accepted %d tracks but the round packs only %d' % (counts[rk], out['rows'].shape[0]))
+        # ---- the data-path collective: all-gather of this round's survivor records, device to device
+        gathered, _ = D.allgather_rows(out['rows'], None, counts=counts)
+        got.append(gathered.clone() if W == 1 else gathered)     # one rank: a view of the round's own (reused) buffer
+        total += sum(counts)
+        last = out
         if total >= n_tracks:
             break
+        h = out['hist']()       # rounds before the last one count in full: every candidate in them precedes the cutoff
+        hist_full = h if hist_full is None else hist_full + h
     else:
         raise RuntimeError('accept_loop: quota not reached after %d rounds' % max_rounds)
-    rows = np.concatenate(got_rows)[:n_tracks]
-    cand = np.concatenate(got_cand)[:n_tracks]
-    month = np.concatenate(got_month)[:n_tracks]
-    basin = np.concatenate(got_basin)[:n_tracks]
-    cutoff = cand[-1]            # the candidate that completed the quota
+    rows = torch.cat(got)[:n_tracks]
+    # rank blocks are contiguous and ascending, so rank order == candidate order
+    cutoff = rows[-1, width]                     # the candidate that completed the quota (device scalar)
     # ---- n_seeds: counted candidates with index <= cutoff (compute.py:167), summed over ranks
-    for cand0, counted, bidx, mo in pending_counts:
-        idx = cand0 + np.arange(len(counted))
-        keep = counted & (idx <= cutoff)
-        np.add.at(n_seeds, (bidx[keep], mo[keep] - 1), 1)
-    t_seeds = torch.from_numpy(n_seeds)
-    if D.world() > 1:
-        t_seeds = t_seeds.to(dev)
-        D.allreduce_sum_(t_seeds)
-        n_seeds = t_seeds.cpu().numpy()
-    return dict(rows=rows, month=month, basin_idx=basin, cand=cand, n_seeds=n_seeds, rounds=r + 1)
+    h = last['hist'](cutoff)
+    t_seeds = h if hist_full is None else hist_full + h
+    D.allreduce_sum_(t_seeds)
+    host = rows.cpu().numpy()                    # the result leaves the device here, once
+    cand = host[:, width].astype(np.int64)
+    assert (np.diff(cand) > 0).all() if len(cand) > 1 else True
+    return dict(rows=host[:, :width], month=host[:, width + 1].astype(np.int64), basin_idx=host[:, width + 2].astype(np.int64),
+                cand=cand, n_seeds=t_seeds.cpu().numpy().reshape(len(BASIN_IDS), 12), rounds=r + 1)
 
 
 class GpuRound:
-    """round_fn backed by the device pipeline: seed → select → integrate → pack."""
+    """round_fn backed by the device pipeline: seed → select → integrate → pack, all on the current stream with
+    no host synchronisation: the number of passing seeds and of accepted tracks stay device scalars
+    (tcr_storms.n_dev, tcr_pack_tracks_dev's count)."""
 
     def __init__(self, engine, year, per_rank, experiment_seed=None):
         import torch
@@ -103,41 +129,36 @@ class GpuRound:
         self.year = int(year)
         self.seed = experiment_seed
         self.pipe = DevicePipeline(engine, per_rank, per_rank, tc_rows_only=True)
-        self.packed = None
+        # every candidate of a round could be accepted: 26 kB per row
+        self.packed = torch.zeros(per_rank, ROW_VARS * engine.n_steps + N_META, dtype=torch.float64, device=self.pipe.dev)
+        self.ar = torch.arange(per_rank, device=self.pipe.dev)
 
     def __call__(self, cand0, count):
         torch, p = self.torch, self.pipe
         ns = self.eng.n_steps
+        width = ROW_VARS * ns
         p.seed_round(self.year, cand0, count, self.seed)
         p.select_passed(count)
-        n_pass = min(int(p.n_passed.item()), count)
-        res = dict(device=p.dev)
-        flags = p.cand['seed_flags'][:count].cpu().numpy()
-        res['counted'] = (flags & 1) != 0
-        res['basin_idx'] = p.cand['basin_idx'][:count].cpu().numpy()
-        res['month'] = p.cand['slot'][:count].cpu().numpy() + 1
-        if n_pass == 0:
-            res.update(acc_cand=np.zeros(0, np.int64), acc_rows=np.zeros((0, ROW_VARS * ns)),
-                       acc_month=np.zeros(0, np.int64), acc_basin=np.zeros(0, np.int64))
-            return res
-        p.integrate(n_pass)
-        bad = int((p.tracks['status'][:n_pass] == -3).sum().item())
-        if bad:
-            raise RuntimeError('%d storms needed more than max_rk_steps accepted RK steps; raise '
-                               'tcr_params.max_rk_steps' % bad)
+        p.integrate(count, n_dev=p.n_passed)
+        exists = self.ar[:count] < p.n_passed
+        bad = ((p.tracks['status'][:count] == -3) & exists).sum().reshape(1)
         p.select_accepted()
-        n_acc = int(p.n_accepted.item())
-        if self.packed is None or self.packed.shape[0] < max(n_acc, 1):
-            self.packed = torch.empty(max(n_acc, 1024), ROW_VARS * ns, dtype=torch.float64, device=p.dev)
-        p.pack_accepted(self.packed, n_acc)
-        dense = p.acc_idx[:n_acc].long()                     # position in the dense batch
-        cand_local = p.cand_idx[:n_pass].long()[dense]       # position in this rank's candidate block
-        res['acc_cand'] = (cand_local + int(cand0)).cpu().numpy()
-        res['acc_rows'] = self.packed[:n_acc]
-        res['acc_rows'] = res['acc_rows'].cpu().numpy()
-        res['acc_month'] = (p.storms['slot'][:n_pass][dense] + 1).cpu().numpy()
-        res['acc_basin'] = p.storms['basin_idx'][:n_pass][dense].cpu().numpy()
-        return res
+        p.pack_accepted(self.packed, count)
+        # meta columns, fixed shapes (rows beyond the accepted count are never read)
+        dense = p.acc_idx[:count].long().clamp_(0, count - 1)          # position in the dense batch
+        cand_local = p.cand_idx[:count].long().clamp_(0, count - 1)[dense]   # position in this rank's candidate block
+        self.packed[:count, width] = (cand_local + int(cand0)).double()
+        self.packed[:count, width + 1] = (p.storms['slot'][:count][dense] + 1).double()
+        self.packed[:count, width + 2] = p.storms['basin_idx'][:count][dense].double()
+        flags = p.cand['seed_flags'][:count]
+        key = p.cand['basin_idx'][:count].long() * 12 + p.cand['slot'][:count].long()
+        counted = (flags & 1) != 0
+        idx = self.ar[:count] + int(cand0)
+
+        def hist(cutoff=None):
+            keep = counted if cutoff is None else counted & (idx.double() <= cutoff)
+            return torch.zeros(len(BASIN_IDS) * 12, dtype=torch.float64, device=p.dev).index_add_(0, key, keep.double())
+        return dict(rows=self.packed[:count], count=p.n_accepted, bad=bad, hist=hist)
 
 
 def rows_to_tuple(res, n_steps):
@@ -184,7 +205,7 @@ def run_downscaling(basin_id, env=None, nl=None, out_dir=None):
     nl = nl or default_namelist
     import os
     from .engine import TCEngine
-    b = TC_Basin(basin_id)
+    b = TC_Basin(basin_id, nl)
     if env is None:
         env = tio.load_env(nl)
     s = time.time()

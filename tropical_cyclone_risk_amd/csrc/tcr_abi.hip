@@ -229,7 +229,7 @@ int grow(tcr_ctx *ctx, double **p, size_t *cap, size_t need)
 
 namespace {
 
-int launch_fourier(tcr_ctx *ctx, int64_t n, const double *phases, double *fs, hipStream_t st)
+int launch_fourier(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const double *phases, double *fs, hipStream_t st)
 {
     const tcr_params &P = ctx->prm;
     if (ctx->fs_period > 0) {
@@ -240,12 +240,12 @@ int launch_fourier(tcr_ctx *ctx, int64_t n, const double *phases, double *fs, hi
             if (grow(ctx, &p, &ctx->pf_cap, (size_t)nf * 2)) { ctx->d_pf = nullptr; return -1; }
             ctx->d_pf = reinterpret_cast<double2 *>(p);
         }
-        hipLaunchKernelGGL(k_phase_factors, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, P, n, phases, ctx->d_pf);
-        hipLaunchKernelGGL(k_fourier_periodic, dim3((unsigned)n), dim3(kFsThreads), lds, st, P, n,
+        hipLaunchKernelGGL(k_phase_factors, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, P, n, n_dev, phases, ctx->d_pf);
+        hipLaunchKernelGGL(k_fourier_periodic, dim3((unsigned)n), dim3(kFsThreads), lds, st, P, n, n_dev,
                            ctx->fs_period, ctx->d_sc_table, ctx->d_pf, fs);
     } else {
         const int64_t total = n * (int64_t)P.n_steps;
-        hipLaunchKernelGGL(k_fourier_direct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, n, phases, fs);
+        hipLaunchKernelGGL(k_fourier_direct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, n, n_dev, phases, fs);
     }
     HIPCHK(ctx, hipGetLastError());
     return 0;
@@ -574,11 +574,11 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
     hipEvent_t *ev = nullptr;
     if (ctx->timing && timing_events(ctx, &ev)) return -1;
     if (ev) HIPCHK(ctx, hipEventRecord(ev[0], st));
-    if (launch_fourier(ctx, n, in->phases, ctx->d_fs, st)) return -1;
+    if (launch_fourier(ctx, n, in->n_dev, in->phases, ctx->d_fs, st)) return -1;
     if (ev) HIPCHK(ctx, hipEventRecord(ev[1], st));
     {
         KArgs a{};
-        a.P = P; a.D = dev_fields(ctx); a.n = n;
+        a.P = P; a.D = dev_fields(ctx); a.n = n; a.n_dev = in->n_dev;
         a.lon0 = in->lon0; a.lat0 = in->lat0; a.v0 = in->v0; a.m0 = in->m0; a.h_bl = in->h_bl;
         a.slot = in->slot; a.phases = in->phases; a.fs = ctx->d_fs; a.srec = ctx->d_srec; a.max_rk_steps = max_rk;
         a.n_valid = out->n_valid; a.status = out->status; a.nfev = out->nfev;
@@ -611,7 +611,7 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
     if (ev) HIPCHK(ctx, hipEventRecord(ev[2], st));
     {
         EArgs a{};
-        a.P = P; a.D = dev_fields(ctx); a.n = n; a.max_rk_steps = max_rk; a.srec = ctx->d_srec; a.fs = ctx->d_fs;
+        a.P = P; a.D = dev_fields(ctx); a.n = n; a.n_dev = in->n_dev; a.max_rk_steps = max_rk; a.srec = ctx->d_srec; a.fs = ctx->d_fs;
         a.slot = in->slot; a.n_valid = out->n_valid; a.status = out->status; a.n_accept = out->n_accept;
         a.lon = out->lon; a.lat = out->lat; a.v = out->v; a.m = out->m; a.vmax = out->vmax;
         a.envw = out->envw; a.flags = out->flags; a.pad_state = out->pad_state;
@@ -635,7 +635,7 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
         if (a.D.all_affine) hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
         else hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
         hipLaunchKernelGGL(k_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, n, out->n_valid,
-                           out->status, out->v, out->flags, out->pad_state, a.list, a.count);
+                           out->status, out->v, out->flags, out->pad_state, a.list, a.count, a.n_dev);
     }
     if (ev) HIPCHK(ctx, hipEventRecord(ev[3], st));
     HIPCHK(ctx, hipGetLastError());
@@ -659,6 +659,7 @@ int tcr_integrate_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out
     di.lon0 = B.put(in->lon0, n); di.lat0 = B.put(in->lat0, n); di.v0 = B.put(in->v0, n);
     di.m0 = B.put(in->m0, n); di.h_bl = B.put(in->h_bl, n); di.slot = B.put(in->slot, n);
     di.phases = B.put(in->phases, n * 4 * N);
+    di.n_dev = nullptr;
     tcr_tracks dout{};
     dout.lon = B.get<double>(n * ns); dout.lat = B.get<double>(n * ns); dout.v = B.get<double>(n * ns);
     dout.m = B.get<double>(n * ns); dout.vmax = B.get<double>(n * ns); dout.envw = B.get<double>(n * ns * 4);
@@ -711,7 +712,7 @@ int tcr_fourier_table_host(tcr_ctx *ctx, int64_t n, const double *phases, double
     const double *d_ph = B.put(phases, (size_t)n * 4 * N);
     double *d_fs = B.get<double>((size_t)n * ns * 4);
     if (!d_ph || !d_fs) return fail(ctx, "tcr_fourier_table_host: device allocation failed");
-    if (launch_fourier(ctx, n, d_ph, d_fs, ctx->stream)) return -1;
+    if (launch_fourier(ctx, n, nullptr, d_ph, d_fs, ctx->stream)) return -1;
     std::vector<double> h((size_t)n * ns * 4);
     HIPCHK(ctx, hipMemcpyAsync(h.data(), d_fs, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -960,7 +961,7 @@ int tcr_gather_seeds_dev(tcr_ctx *ctx, const tcr_seeds *src, const int32_t *idx,
     return 0;
 }
 
-int tcr_stats_dev(tcr_ctx *ctx, int64_t n, const tcr_tracks *t, uint64_t *out, void *stream_)
+int tcr_stats_dev(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const tcr_tracks *t, uint64_t *out, void *stream_)
 {
     if (!ctx) return -1;
     if (!t || !out) return fail(ctx, "tcr_stats_dev: NULL argument");
@@ -969,14 +970,14 @@ int tcr_stats_dev(tcr_ctx *ctx, int64_t n, const tcr_tracks *t, uint64_t *out, v
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
     int64_t blocks = (n + 255) / 256;
     if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(k_stats, dim3((unsigned)blocks), dim3(256), 0, st, n, t->n_valid, t->nfev, t->flags,
+    hipLaunchKernelGGL(k_stats, dim3((unsigned)blocks), dim3(256), 0, st, n, n_dev, t->n_valid, t->nfev, t->flags,
                        reinterpret_cast<unsigned long long *>(out));
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
 
 int tcr_pack_tracks_dev(tcr_ctx *ctx, const tcr_tracks *src, const int32_t *idx, const int64_t *count,
-                        int64_t cap, double *packed, void *stream_)
+                        int64_t cap, double *packed, int64_t row_stride, void *stream_)
 {
     if (!ctx) return -1;
     if (!ctx->have_prm) return fail(ctx, "tcr_params_set has not been called");
@@ -986,6 +987,8 @@ int tcr_pack_tracks_dev(tcr_ctx *ctx, const tcr_tracks *src, const int32_t *idx,
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
     PackArgs a{};
     a.src = *src; a.idx = idx; a.count = count; a.cap = cap; a.ns = ctx->prm.n_steps; a.packed = packed;
+    a.row_stride = row_stride > 0 ? row_stride : 9 * (int64_t)ctx->prm.n_steps;
+    if (a.row_stride < 9 * (int64_t)ctx->prm.n_steps) return fail(ctx, "tcr_pack_tracks_dev: row_stride < 9 * n_steps");
     hipLaunchKernelGGL(k_pack_tracks, dim3((unsigned)cap), dim3(256), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
     return 0;

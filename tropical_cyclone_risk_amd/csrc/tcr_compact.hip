@@ -126,10 +126,11 @@ __global__ __launch_bounds__(256) void k_gather_seeds(GatherSeedArgs a)
 }
 
 // Sums over a finished batch (throughput accounting / round control): one atomic per workgroup.
-__global__ __launch_bounds__(256) void k_stats(int64_t n, const int32_t *__restrict__ n_valid,
+__global__ __launch_bounds__(256) void k_stats(int64_t n, const int64_t *__restrict__ n_dev, const int32_t *__restrict__ n_valid,
                                                const int32_t *__restrict__ nfev, const int32_t *__restrict__ flags,
                                                unsigned long long *__restrict__ out)
 {
+    if (n_dev && *n_dev < n) n = *n_dev;
     __shared__ unsigned long long s[4][6];
     unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -161,6 +162,7 @@ struct PackArgs {
     const int64_t *count;       // device scalar written by k_compact_scan
     int64_t cap;
     int ns;
+    int64_t row_stride;         // doubles between packed rows (>= 9 * ns)
     double *packed;
 };
 
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void k_pack_tracks(PackArgs a)
     if (row >= cnt) return;
     const size_t j = (size_t)a.idx[row];
     const int ns = a.ns;
-    double *dst = a.packed + (size_t)row * 9 * ns;
+    double *dst = a.packed + (size_t)row * (size_t)a.row_stride;
     const double *planes[5] = {a.src.lon, a.src.lat, a.src.v, a.src.m, a.src.vmax};
     for (int p = 0; p < 5; ++p)
         for (int i = threadIdx.x; i < ns; i += blockDim.x) dst[(size_t)p * ns + i] = planes[p][j * ns + i];

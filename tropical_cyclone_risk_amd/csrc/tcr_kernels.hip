@@ -33,6 +33,7 @@ struct KArgs {
     tcr_params P;
     DevFields D;
     int64_t n;
+    const int64_t *n_dev;    // optional device scalar (tcr_storms.n_dev): only the first min(n, *n_dev) storms exist
     const double *lon0, *lat0, *v0, *m0, *h_bl;
     const int32_t *slot;
     const double *phases;    // [n][4][n_series]
@@ -60,13 +61,20 @@ constexpr int kParkRec = 16;     // doubles per parked storm: t, h, t_new, ha, g
 // gen_f (track/bam_track.py:23-31), direct form: one thread per (storm, sample),
 // 4 series x n_series sines, NumPy's evaluation order 2π·((n·t)/T + x).
 // Used when the Fourier period is not a whole number of output intervals.
-__global__ __launch_bounds__(256) void k_fourier_direct(tcr_params P, int64_t n,
+__device__ __forceinline__ int64_t n_eff(int64_t n, const int64_t *n_dev)
+{
+    if (!n_dev) return n;
+    const int64_t m = *n_dev;
+    return m < n ? m : n;
+}
+
+__global__ __launch_bounds__(256) void k_fourier_direct(tcr_params P, int64_t n, const int64_t *__restrict__ n_dev,
                                                          const double *__restrict__ phases,
                                                          double *__restrict__ fs)
 {
     const int ns = P.n_steps, N = P.n_series;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n * ns) return;
+    if (gid >= n_eff(n, n_dev) * ns) return;
     const int64_t storm = gid / ns;
     const int i = (int)(gid - storm * ns);
     const double t = ts_at(P, i);
@@ -99,12 +107,12 @@ __global__ __launch_bounds__(256) void k_fourier_direct(tcr_params P, int64_t n,
 //
 // k_phase_factors: amplitude-weighted phase factors n^-1.5 * (sin, cos)(2π x), laid out
 // [storm][harmonic][series] so that one harmonic of a storm is one 64-byte scalar load.
-__global__ __launch_bounds__(256) void k_phase_factors(tcr_params P, int64_t n, const double *__restrict__ phases,
-                                                       double2 *__restrict__ pf)
+__global__ __launch_bounds__(256) void k_phase_factors(tcr_params P, int64_t n, const int64_t *__restrict__ n_dev,
+                                                       const double *__restrict__ phases, double2 *__restrict__ pf)
 {
     const int N = P.n_series;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n * 4 * N) return;
+    if (gid >= n_eff(n, n_dev) * 4 * N) return;
     const int64_t storm = gid / (4 * N);
     const int r = (int)(gid - storm * 4 * N), s = r / N, h = r - s * N;      // phases are [storm][series][harmonic]
     const double x = phases[gid];
@@ -126,12 +134,14 @@ constexpr int kFsThreads = TCR_FS_THREADS;
 #endif
 constexpr int kFsPerThread = TCR_FS_PER_THREAD;
 
-__global__ __launch_bounds__(kFsThreads) void k_fourier_periodic(tcr_params P, int64_t n, int period,
+__global__ __launch_bounds__(kFsThreads) void k_fourier_periodic(tcr_params P, int64_t n, const int64_t *__restrict__ n_dev,
+                                                                  int period,
                                                                   const double2 *__restrict__ sc_table,
                                                                   const double2 *__restrict__ pf,
                                                                   double *__restrict__ fs)
 {
     extern __shared__ double2 lds[];            // [period] one period of (sin, cos)
+    if ((int64_t)blockIdx.x >= n_eff(n, n_dev)) return;
     const int N = P.n_series, ns = P.n_steps;
     double2 *tab = lds;
     const int64_t storm = blockIdx.x;
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
     const tcr_params &P = a.P;
     const DevFields &D = a.D;
     const int lane = threadIdx.x;
-    const long long n_items = a.pass == 0 ? (long long)a.n : (long long)a.queue[kMaxPasses + a.pass - 1];
+    const long long n_items = a.pass == 0 ? (long long)n_eff(a.n, a.n_dev) : (long long)a.queue[kMaxPasses + a.pass - 1];
     if (a.pass > 0 && (long long)blockIdx.x * kWave >= n_items) return;     // the list fits the first waves
     unsigned long long *const q_head = a.queue + a.pass;
     if (lane == 0) make_eval_k(P, D, K);
@@ -528,6 +538,7 @@ struct EArgs {
     tcr_params P;
     DevFields D;
     int64_t n;
+    const int64_t *n_dev;        // optional device scalar: only the first min(n, *n_dev) storms exist; flags of the rest are set to 0
     int max_rk_steps;
     const double *srec;          // [n][max_rk_steps][kStepRec]
     const double *fs;            // [n][n_steps][4]
@@ -561,6 +572,10 @@ __global__ __launch_bounds__(kWave) void k_dense(EArgs a, uint16_t *__restrict__
 {
     const tcr_params &P = a.P;
     if (a.list && (int64_t)blockIdx.x >= *a.count) return;
+    if (!a.list && (int64_t)blockIdx.x >= n_eff(a.n, a.n_dev)) {
+        if (threadIdx.x == 0) a.flags[blockIdx.x] = 0;
+        return;
+    }
     const int64_t sid = a.list ? (int64_t)a.list[blockIdx.x] : (int64_t)blockIdx.x;
     const int ns = P.n_steps;
     const int n = a.n_valid[sid];
@@ -674,6 +689,7 @@ __global__ __launch_bounds__(kPostThreads, TCR_EMIT_WPS) void k_emit(EArgs a, co
     __shared__ const double *s_wind[kEmitSlotCache];
     const tcr_params &P = a.P;
     if (a.list && (int64_t)blockIdx.x >= *a.count) return;            // uniform per workgroup
+    if (!a.list && (int64_t)blockIdx.x >= n_eff(a.n, a.n_dev)) return;
     const int64_t sid = a.list ? (int64_t)a.list[blockIdx.x] : (int64_t)blockIdx.x;
     const int ns = P.n_steps;
     const int i = blockIdx.y * kPostThreads + threadIdx.x;
@@ -764,10 +780,11 @@ __global__ __launch_bounds__(kScreenThreads) void k_screen(EArgs a)
     const tcr_params &P = a.P;
     const int g = threadIdx.x / kScreenGroup, l = threadIdx.x % kScreenGroup;
     const int64_t sid = (int64_t)blockIdx.x * kScreenStorms + g;
-    const bool on = sid < a.n;
+    const bool on = sid < a.n;                       // writes a flag
+    const bool exists = sid < n_eff(a.n, a.n_dev);   // has a storm behind it
     const int ns = P.n_steps;
     int n = 0, nst = 0, st = TCR_STATUS_GATED;
-    if (on) {
+    if (exists) {
         n = a.n_valid[sid]; nst = a.n_accept[sid]; st = a.status[sid];
         nst = nst < a.max_rk_steps ? nst : a.max_rk_steps;
     }
@@ -805,7 +822,9 @@ __global__ __launch_bounds__(kScreenThreads) void k_screen(EArgs a)
             if (i == n - 1) cap[g][2] = v;
         }
     }
-    for (int off = kScreenGroup / 2; off > 0; off >>= 1) any15 = any15 || (__shfl_xor((int)any15, off) != 0);
+    int hit = any15 ? 1 : 0;
+    for (int off = kScreenGroup / 2; off > 0; off >>= 1) hit |= __shfl_xor(hit, off);       // every lane takes part
+    any15 = hit != 0;
     __syncthreads();
     if (on && l == 0) {
         int fl = 0;
@@ -822,10 +841,12 @@ __global__ __launch_bounds__(kScreenThreads) void k_screen(EArgs a)
 __global__ __launch_bounds__(256) void k_flags(tcr_params P, int64_t n_storms, const int32_t *__restrict__ n_valid,
                                                const int32_t *__restrict__ status, const double *__restrict__ pv,
                                                int32_t *__restrict__ flags, int32_t *__restrict__ pad_state,
-                                               const int32_t *__restrict__ list, const int64_t *__restrict__ count)
+                                               const int32_t *__restrict__ list, const int64_t *__restrict__ count,
+                                               const int64_t *__restrict__ n_dev)
 {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (list ? *count : n_storms)) return;
+    if (!list && gid >= n_eff(n_storms, n_dev)) { flags[gid] = 0; return; }
     const int64_t sid = list ? (int64_t)list[gid] : gid;
     const int ns = P.n_steps;
     const int n = n_valid[sid];

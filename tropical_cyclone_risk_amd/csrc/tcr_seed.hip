@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a)
     a.out.lon0[i] = lon;
     a.out.lat0[i] = lat;
     a.out.v0[i] = P.seed_v_init + z;
-    a.out.m0[i] = m_init > 0 ? m_init : 0.0;
+    a.out.m0[i] = np_max(0.0, m_init);        // np.maximum(0, f_mInit(rh)): a NaN rh_mid stays NaN (compute.py:174)
     a.out.h_bl[i] = P.atm_bl_depth[bidx];
     a.out.slot[i] = month - 1;
     a.out.basin_idx[i] = bidx;

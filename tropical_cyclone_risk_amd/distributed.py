@@ -72,6 +72,18 @@ def allgather_counts(count):
     return [int(x) for x in buf.tolist()]
 
 
+def allgather_ints(vec):
+    """vec: int64 tensor [k] on the compute device -> list (per rank) of lists of k python ints.  This is the
+    accept loop's one host synchronisation per round."""
+    if world() == 1:
+        return [[int(x) for x in vec.tolist()]]
+    buf = torch.empty(world() * vec.numel(), dtype=vec.dtype, device=vec.device)
+    dist.all_gather_into_tensor(buf, vec.contiguous())
+    flat = buf.tolist()
+    k = vec.numel()
+    return [[int(x) for x in flat[r * k:(r + 1) * k]] for r in range(world())]
+
+
 def allgather_rows(rows, count, counts=None, async_op=False, concat=True):
     """All-gather variable-length row blocks.
 
@@ -145,15 +157,23 @@ class DeferredRowGather:
         else:
             self.cnt[slot].copy_(count.reshape(1))
             wc = None
-        self.inflight.append((slot, wc))
+        # the producer's stream has written the rows and the count up to here: the side stream that later reads
+        # them must wait for exactly this point (with world == 1 there is no collective to order them)
+        ev = None
+        if self.side is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.packed[slot].device))
+        self.inflight.append((slot, wc, ev))
         self.k += 1
         if len(self.inflight) > self.lag:
             self._launch_oldest()
 
     def _launch_oldest(self):
-        slot, wc = self.inflight.popleft()
+        slot, wc, ev = self.inflight.popleft()
         ctx = torch.cuda.stream(self.side) if self.side is not None else _null()
         with ctx:
+            if ev is not None:
+                self.side.wait_event(ev)
             if wc is not None:
                 wc.wait()
             counts = [int(c) for c in self.cnt[slot].tolist()]

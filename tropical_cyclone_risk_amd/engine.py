@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib, constants
 from . import namelist as default_namelist
-from .basins import BASIN_IDS, TC_Basin
+from .basins import BASIN_IDS, TC_Basin, basin_ids
 
 TRACK_F64 = ('lon', 'lat', 'v', 'm', 'vmax')
 TRACK_I32 = ('n_valid', 'status', 'flags', 'nfev', 'n_accept', 'n_reject')
@@ -44,7 +44,10 @@ def params_from_namelist(nl, basin, n_series=None):
     p.vmax_thresh = nl.seed_vmax_threshold_ms
     p.v_dissipate = 4.0                                           # coupled_fast.py:255
     p.earth_R = constants.earth_R
-    p.box = (C.c_double * 4)(*TC_Basin(basin).get_bounds())
+    if basin_ids(nl) != BASIN_IDS:
+        raise ValueError('namelist.basin_bounds must define exactly the basins %s (+ GL): the device tables hold one entry '
+                         'per reference basin in that order; got %s' % (BASIN_IDS, basin_ids(nl)))
+    p.box = (C.c_double * 4)(*TC_Basin(basin, nl).get_bounds())
     N = int(n_series or getattr(nl, 'gpu_N_series', 15))          # bam_track.py:112
     n = np.linspace(1, N, N)
     p.fs_amp = float(np.sqrt(2 / np.sum(np.power(n, -3))))        # bam_track.py:28
@@ -54,6 +57,7 @@ def params_from_namelist(nl, basin, n_series=None):
     p.n_series = N
     p.n_steps = int(p.total_time / p.dt_out) + 1                  # bam_track.py:54
     p.coupled_track = 1 if nl.coupled_track else 0
+    p.max_rk_steps = int(getattr(nl, 'gpu_max_rk_steps', 64))
     p.seed_v_init = nl.seed_v_init_ms
     p.pi_gate = 35.0                                              # compute.py:168
     p.lat_vort_fac = nl.lat_vort_fac
@@ -74,7 +78,7 @@ class TCEngine:
 
     def __init__(self, basin, device=0, nl=None):
         self.nl = nl or default_namelist
-        self.basin = TC_Basin(basin)
+        self.basin = TC_Basin(basin, self.nl)
         self.L = _lib.lib()
         h = C.c_void_p()
         if self.L.tcr_ctx_create(int(device), C.byref(h)) != 0:

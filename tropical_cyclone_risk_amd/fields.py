@@ -151,8 +151,22 @@ def interp_time(t_axis, values, t_new):
 
 
 def _interp2_fx(lon, lat, X):
-    """util/mat.py `interp2_fx`: RectBivariateSpline(lon, lat, X.T, kx=1, ky=1)."""
-    return RectBivariateSpline(lon, lat, np.asarray(X).T, kx=1, ky=1)
+    """util/mat.py:142-154 `interp2_fx`: RectBivariateSpline(lon, lat, X.T, kx=1, ky=1), with a descending
+    latitude axis (and the field with it) reversed first, since the spline needs increasing axes."""
+    lat, X = np.asarray(lat), np.asarray(X)
+    if lat[1] - lat[0] < 0:
+        lat, X = np.flip(lat, 0), np.flip(X, 0)
+    return RectBivariateSpline(lon, lat, X.T, kx=1, ky=1)
+
+
+def _ascending_lat(lat, *fields):
+    """North-to-south files: flip to the ascending latitude the staging (and FITPACK) requires.  The reference
+    does this for every field it reads through `interp2_fx` (mld / strat, land/<B>.nc, rh_mid) and for the thermo
+    record (compute.py:80-84); flipping is exact, so it is applied to every [.., lat, lon] input here."""
+    lat = np.asarray(lat, dtype=np.float64)
+    if lat[0] - lat[1] > 0:
+        return (lat[::-1].copy(),) + tuple(np.asarray(f)[..., ::-1, :].copy() for f in fields)
+    return (lat,) + tuple(fields)
 
 
 def interp_2d_grid(lon, lat, X, lon_grid, lat_grid):
@@ -238,9 +252,11 @@ def load_year_env(year, nl=None, files=None):
     dl = _Dataset(fl['land'])
     hlon, hlat = np.asarray(dl['lon'], dtype=np.float64), np.asarray(dl['lat'], dtype=np.float64)
     land = np.asarray(dl['land'], dtype=np.float64)
+    hlat, land = _ascending_lat(hlat, land)
     db = _Dataset(fl['bathy'])
     bathy = np.asarray(db['bathymetry'], dtype=np.float64)
     blon, blat = np.asarray(db['lon'], dtype=np.float64), np.asarray(db['lat'], dtype=np.float64)
+    blat, bathy = _ascending_lat(blat, bathy)
     if bathy.shape != land.shape or not (np.array_equal(blon, hlon) and np.array_equal(blat, hlat)):
         raise NotImplementedError('land.nc and bathymetry.nc are on different grids; tcr_static_upload takes one grid '
                                   '(the reference ships both at 0.25 degrees)')
@@ -251,12 +267,13 @@ def load_year_env(year, nl=None, files=None):
         if not os.path.exists(fn):
             continue
         dm = _Dataset(fn)
-        g = (np.asarray(dm['lon'], dtype=np.float64), np.asarray(dm['lat'], dtype=np.float64))
+        mlat_b, mask_b = _ascending_lat(np.asarray(dm['lat'], dtype=np.float64), np.asarray(dm['basin'], dtype=np.float64))
+        g = (np.asarray(dm['lon'], dtype=np.float64), mlat_b)
         if mgrid is None:
             mgrid = g
         elif not (np.array_equal(g[0], mgrid[0]) and np.array_equal(g[1], mgrid[1])):
             raise NotImplementedError('basin masks on different grids')
-        masks[b] = np.asarray(dm['basin'], dtype=np.float64)
+        masks[b] = mask_b
     env = SyntheticEnv(lon=lon, lat=lat, wlon=wlon, wlat=wlat, wnd_mean=np.stack(mean), wnd_cov=np.stack(cov),
                        vpot=np.stack(vpot), chi=np.stack(chi), mld=mld, strat=strat, rh_mid=np.stack(rh_mid),
                        hlon=hlon, hlat=hlat, land=land, bathy=bathy, basin_masks=masks, seed=0, shape='files')

@@ -116,11 +116,14 @@ class DevicePipeline:
         s['phases'][:n].copy_(torch.from_numpy(np.ascontiguousarray(storms['phases'], dtype=np.float64).reshape(n, -1)))
         self.n_storms = n
 
-    def integrate(self, n=None):
-        """gen_track + accept tests + env-wind recompute + vmax for the dense batch."""
+    def integrate(self, n=None, n_dev=None):
+        """gen_track + accept tests + env-wind recompute + vmax for the dense batch.  n_dev (device int64
+        tensor, e.g. ``self.n_passed``): only the first min(n, n_dev) rows hold storms (tcr_storms.n_dev)."""
         n = self.n_storms if n is None else int(n)
         s = self.storms
-        si = _lib.Storms(n, *[s[k].data_ptr() for k in ('lon0', 'lat0', 'v0', 'm0', 'h_bl', 'slot', 'phases')])
+        self._n_dev = n_dev
+        si = _lib.Storms(n, *[s[k].data_ptr() for k in ('lon0', 'lat0', 'v0', 'm0', 'h_bl', 'slot', 'phases')],
+                         n_dev.data_ptr() if n_dev is not None else None)
         so = self._tracks_struct()
         self.eng._ck(self.eng.L.tcr_integrate_dev(self.eng.h, C.byref(si), C.byref(so),
                                                   C.c_void_p(self._stream())))
@@ -130,8 +133,9 @@ class DevicePipeline:
         """counters (uint64/int64 tensor [6]) += storm-steps, RHS evaluations, samples, accepted, is_tc storms,
         samples of is_tc storms."""
         so = self._tracks_struct()
-        self.eng._ck(self.eng.L.tcr_stats_dev(self.eng.h, self.n_done, C.byref(so), counters.data_ptr(),
-                                              C.c_void_p(self._stream())))
+        nd = getattr(self, '_n_dev', None)
+        self.eng._ck(self.eng.L.tcr_stats_dev(self.eng.h, self.n_done, nd.data_ptr() if nd is not None else None,
+                                              C.byref(so), counters.data_ptr(), C.c_void_p(self._stream())))
 
     def select_accepted(self):
         """Indices (dense-batch order == candidate order) of accepted tracks → self.acc_idx."""
@@ -140,11 +144,12 @@ class DevicePipeline:
                                                 self.n_accepted.data_ptr(), C.c_void_p(self._stream())))
 
     def pack_accepted(self, packed, cap):
-        """Survivor records of the first ``cap`` accepted tracks into ``packed`` [cap, 9*ns]."""
+        """Survivor records of the first ``cap`` accepted tracks into ``packed`` [cap, >= 9*ns] (extra
+        columns of a wider buffer are left to the caller)."""
         so = self._tracks_struct()
         self.eng._ck(self.eng.L.tcr_pack_tracks_dev(self.eng.h, C.byref(so), self.acc_idx.data_ptr(),
                                                     self.n_accepted.data_ptr(), int(cap), packed.data_ptr(),
-                                                    C.c_void_p(self._stream())))
+                                                    int(packed.stride(0)), C.c_void_p(self._stream())))
 
     def host_tracks(self, n=None):
         """Copy the per-storm outputs of the last integrate() back as NumPy arrays."""
