@@ -46,6 +46,8 @@ def main():
     ap.add_argument('--cpu-budget', type=float, default=12.0)
     ap.add_argument('--traffic', type=float, default=None,
                     help='HBM bytes per integrate launch from a separate rocprofv3 --pmc pass (see profiles/)')
+    ap.add_argument('--dtype', choices=('f64', 'f32'), default='f64',
+                    help='f32: the fp32 variant of the path (BASELINE config 5): fp32 fields / state / RHS / rows, fp64 time and controller')
     ap.add_argument('--rows', choices=('tc', 'all'), default='tc',
                     help="tc: env winds / vmax / rows only for storms that pass accept test 1, as the reference does "
                          "(compute.py:190-204); all: rows for every integrated storm (round 1's workload)")
@@ -76,13 +78,16 @@ def main():
 
     # ---- calibrate the seed pass rate once (untimed) so that a round of C candidates
     # contains at least B passing seeds with a wide margin
-    probe = DevicePipeline(eng, 1 << 18, 1024)
+    probe = DevicePipeline(eng, 1 << 18, 1024)     # (seeding is fp64 in both modes)
     probe.seed_round(year, 10**12)
     torch.cuda.synchronize()
     p_pass = float(((probe.cand['seed_flags'] & 2) != 0).double().mean().item())
     del probe
     C = int(B / max(p_pass, 1e-3) * 1.15) + 4096
-    pipes = [DevicePipeline(e, C, B, sort_storms=args.sort, tc_rows_only=(args.rows == 'tc')) for e in engs]
+    pipes = [DevicePipeline(e, C, B, sort_storms=args.sort, tc_rows_only=(args.rows == 'tc'), dtype=args.dtype) for e in engs]
+    global BYTES_PER_RHS, BYTES_PER_SAMPLE
+    if args.dtype == 'f32':
+        BYTES_PER_RHS, BYTES_PER_SAMPLE = 352.0, 260.0          # SURVEY.md §8d, fp32 mode
     pipe = pipes[0]
 
     acc = torch.zeros(6, dtype=torch.int64, device=dev)       # storm-steps, nfev, samples, accepted, is_tc, is_tc samples (tcr_stats_dev)
@@ -184,7 +189,7 @@ def main():
     # HIP-event time of every kernel of the timed region, summed over launches and streams (overlapping
     # streams make this exceed the wall time; it shows the GPU was busy even when SMI sampling misses a 50 ms region)
     gpu_active_s = (ms['fourier_ms'] + ms['integrate_ms'] + ms['post_ms']) * 1e-3
-    traffic, traffic_src = (args.traffic, 'command line') if args.traffic is not None else measured_traffic('k_integrate', B, args.rows)
+    traffic, traffic_src = (args.traffic, 'command line') if args.traffic is not None else measured_traffic('k_integrate', B, args.rows, args.dtype)
     # Exclusive duration: the same launch, one batch at a time on one stream right after the timed region
     # (3 batches).  With several streams the event-bracketed duration of a launch in the timed region
     # includes time it shared the GPU with other batches (it can exceed ms_per_step), so that figure is
@@ -193,10 +198,10 @@ def main():
     ib = BYTES_PER_RHS * iso_counts[1] / iso['calls']
     eb = BYTES_PER_SAMPLE * (iso_counts[5] if args.rows == 'tc' else iso_counts[2]) / iso['calls']
     achieved = ib / (ik * 1e-3) / 1e9
-    e_traffic, e_src = measured_traffic('k_emit', B, args.rows)
+    e_traffic, e_src = measured_traffic('k_emit', B, args.rows, args.dtype)
     roof = dict(bound='hbm', kernel='k_integrate', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
                 frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
-                note='a launch = the chain of k_integrate passes of one batch (tail compaction); achieved = 704 B x RHS '
+                note='a launch = the chain of k_integrate passes of one batch (tail compaction); achieved = %d B x RHS ' % BYTES_PER_RHS +
                      'evaluations of the batch / exclusive HIP-event duration of the chain (one batch at a time on one '
                      'stream, after the timed region); profiles/ lists k_integrate once per pass',
                 algorithmic_bytes_per_launch=ib, launch_ms=ik,
@@ -209,8 +214,8 @@ def main():
                                achieved=BYTES_PER_RHS * nfev_total / world / dt / 1e9,
                                frac=BYTES_PER_RHS * nfev_total / world / dt / 1e9 / HBM_PEAK_GBS),
                 emit=dict(kernel='k_screen + k_dense + k_emit + k_flags' if args.rows == 'tc' else 'k_dense + k_emit + k_flags',
-                          note='520 B x samples actually emitted (%s) / exclusive duration of the post-processing'
-                               % ('storms that pass accept test 1' if args.rows == 'tc' else 'every storm'),
+                          note='%d B x samples actually emitted (%s) / exclusive duration of the post-processing'
+                               % (BYTES_PER_SAMPLE, 'storms that pass accept test 1' if args.rows == 'tc' else 'every storm'),
                           achieved=eb / (ie * 1e-3) / 1e9, frac=eb / (ie * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           algorithmic_bytes_per_launch=eb, launch_ms=ie, traffic=e_traffic, traffic_source=e_src))
     # k_integrate runs as a chain of passes (tail compaction); occupancy of the last isolated batch:
@@ -234,10 +239,10 @@ def main():
             'metric': 'storm-steps/sec (100k-storm ensemble)', 'value': value, 'unit': 'storm-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic', 'gpu_active_s': gpu_active_s,
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'gpu_active_s': gpu_active_s,
             'config': {'workload': '%s basin, %d storms per GPU per step, synthetic ERA5-shaped monthly fields '
                                    '(1 deg thermo/wind, 0.25 deg land/bathymetry), 15-day tracks, hourly output, '
-                                   'device-side seeding, fp64; %s' % (args.basin, B, (
+                                   'device-side seeding, %s; %s' % (args.basin, B, 'fp64' if args.dtype == 'f64' else 'fp32 fields/state/RHS/rows with fp64 time and step controller', (
                                        'env winds, vmax and rows only for storms that pass accept test 1, as the reference '
                                        'does (compute.py:190-204)' if args.rows == 'tc' else 'rows for every integrated storm')),
                        'rows': args.rows, 'is_tc_fraction': tc_total / (B * args.steps * world),
@@ -258,12 +263,12 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def measured_traffic(kernel, storms, rows):
+def measured_traffic(kernel, storms, rows, dtype='f64'):
     """(HBM bytes per batch, source) of a kernel from the committed rocprofv3 --pmc runs of this same workload
     (tools/collect_profiles.sh; counters are collected in separate passes from timing, as MI355X_MICROARCH.md
     prescribes, so they cannot be measured inside this process).  Only valid for the profiled size."""
     fn = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm.json')
-    if storms != 100_000 or not os.path.exists(fn):
+    if storms != 100_000 or dtype != 'f64' or not os.path.exists(fn):
         return None, None
     try:
         d = json.load(open(fn))

@@ -126,6 +126,15 @@ typedef struct {
     int32_t tc_rows_only;
 } tcr_tracks;
 
+/* The same outputs in fp32 (BASELINE config 5, "fp32 intensity ODE"): float planes, same layout and meaning. */
+typedef struct {
+    float *lon, *lat, *v, *m, *vmax;        /* [n][n_steps], NaN after the track end */
+    float *envw;                            /* [n][n_steps][4] */
+    int32_t *n_valid, *status, *flags, *nfev, *n_accept, *n_reject;
+    int32_t *pad_state;
+    int32_t tc_rows_only;
+} tcr_tracks_f32;
+
 /* ---- lifecycle ----------------------------------------------------------- */
 int tcr_abi_version(void);
 /* replaces: constructing the 12 Coupled_FAST objects of a year (compute.py:119) */
@@ -163,6 +172,14 @@ int tcr_masks_upload(tcr_ctx *ctx, const tcr_grid *mg, const uint8_t *run_mask,
 int tcr_integrate_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out);
 /* same with device buffers, asynchronous on `stream` */
 int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in_dev, const tcr_tracks *out_dev, void *stream);
+
+/* The fp32 variant of the same path (BASELINE config 5; the reference itself is fp64 throughout, so this is a
+ * documented departure with a stated tolerance, see DESIGN.md and profiles/r02_fp32_study.json): fields are
+ * converted to fp32 on the device on first use, state / stage derivatives / right-hand side / dense output are
+ * fp32, rows come out as fp32; time, the output grid and the step-size controller (error norm, accept test,
+ * step factor) stay fp64.  Storm inputs are the same fp64 tcr_storms.  Device buffers, asynchronous on `stream`. */
+int tcr_integrate_f32_dev(tcr_ctx *ctx, const tcr_storms *in_dev, const tcr_tracks_f32 *out_dev, void *stream);
+int tcr_integrate_f32_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks_f32 *out);
 
 /* replaces: the rejection-sampling seed loop (compute.py:134-175) for candidates
  * [cand0, cand0+n) of `year`, drawn from Philox4x32-10 keyed by
@@ -207,6 +224,9 @@ int tcr_stats_dev(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const tcr_track
  * caller's own columns, e.g. candidate index / month / basin). */
 int tcr_pack_tracks_dev(tcr_ctx *ctx, const tcr_tracks *src_dev, const int32_t *idx_dev,
                         const int64_t *count_dev, int64_t cap, double *packed_dev, int64_t row_stride, void *stream);
+/* the same from fp32 rows; the packed records are fp64 (the 9-tuple is float64 like the reference's) */
+int tcr_pack_tracks_f32_dev(tcr_ctx *ctx, const tcr_tracks_f32 *src_dev, const int32_t *idx_dev,
+                            const int64_t *count_dev, int64_t cap, double *packed_dev, int64_t row_stride, void *stream);
 
 /* ---- preprocessing next to the path ----------------------- */
 /* replaces: calc_wnd_stat (track/env_wind.py:180-228) for one month: wnd[c] = ua250, va250,

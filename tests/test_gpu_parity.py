@@ -300,6 +300,56 @@ def test_tc_rows_only_matches_all_rows(golden_env, built_lib):
     eng.close()
 
 
+def test_fp32_variant_within_stated_tolerance(golden_env, built_lib):
+    """BASELINE config 5: the fp32 variant (tcr_integrate_f32_*: fp32 fields / state / RHS / rows, fp64 time and step
+    controller) against the fp64 path on identical storms.  Stated tolerance (profiles/r02_fp32_study.json has the
+    full distributions at 100 000 storms; the bounds below leave a 3-10x margin over them):
+      * status identical for >= 99.9 % of the storms, track length for >= 97 %, within 6 h for >= 99.5 %;
+      * where the lengths agree: |dv| median <= 1e-4 m/s, p99 <= 0.1 m/s; |dlon|, |dlat| median <= 1e-4 deg,
+        p99 <= 5e-3 deg; |dm| p99 <= 1e-3 (per-storm maxima over the whole track);
+      * the first 24 h (before the adaptive integrator has amplified anything): |dv| p99.9 <= 0.03 m/s;
+      * accept decisions: is_tc flips <= 0.05 % of the storms, accepted flips <= 1 % of the accepted tracks;
+      * the TC-rows-only mode of the fp32 path gives the same flags as its all-rows mode and bit-identical rows."""
+    import torch
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    from tropical_cyclone_risk_amd.pipeline import DevicePipeline
+    B = 40_000
+    eng = TCEngine('GL', device=0).stage_env(golden_env)
+    res = {}
+    for tag, kw in (('f64', dict()), ('f32', dict(dtype='f32')), ('f32tc', dict(dtype='f32', tc_rows_only=True))):
+        p = DevicePipeline(eng, 260_000, B, **kw)
+        p.seed_round(2007, 0); p.select_passed(B)
+        assert int(p.n_passed.item()) >= B
+        p.integrate(B); torch.cuda.synchronize()
+        res[tag] = p.host_tracks()
+        assert res[tag]['lon'].dtype == (np.float64 if tag == 'f64' else np.float32)
+        del p
+    eng.close()
+    a, b, c = res['f64'], res['f32'], res['f32tc']
+    assert (a['status'] == b['status']).mean() >= 0.999
+    dn = np.abs(b['n_valid'].astype(np.int64) - a['n_valid'])
+    assert (dn == 0).mean() >= 0.97 and (dn <= 6).mean() >= 0.995
+    same = dn == 0
+    idx = np.arange(a['lon'].shape[1])[None, :]
+    for k, med, p99 in (('v', 1e-4, 0.1), ('lon', 1e-4, 5e-3), ('lat', 1e-4, 5e-3), ('m', 1e-5, 1e-3)):
+        d = np.abs(np.nan_to_num(a[k][same]) - np.nan_to_num(b[k][same]).astype(np.float64)).max(axis=1)
+        print('fp32 %-3s per-storm max |d|: median %.3g  p99 %.3g  max %.3g' % (k, np.median(d), np.percentile(d, 99), d.max()))
+        assert np.median(d) <= med and np.percentile(d, 99) <= p99, k
+    m24 = (idx <= 24) & (idx < np.minimum(a['n_valid'], b['n_valid'])[:, None])
+    d24 = np.abs(a['v'] - b['v'].astype(np.float64))[m24]
+    assert np.percentile(d24, 99.9) <= 0.03
+    assert (a['is_tc'] != b['is_tc']).mean() <= 5e-4
+    flips = (a['accepted'] != b['accepted']).sum()
+    print('fp32: %d accepted (fp64 %d), %d flips' % (b['accepted'].sum(), a['accepted'].sum(), flips))
+    assert flips <= 0.01 * a['accepted'].sum()
+    # fp32 TC-rows-only vs fp32 all rows
+    for k in ('n_valid', 'status', 'flags', 'nfev'):
+        assert np.array_equal(b[k], c[k]), k
+    tc = b['is_tc']
+    for k in ('lon', 'lat', 'v', 'm', 'vmax', 'envw'):
+        assert np.array_equal(b[k][tc], c[k][tc], equal_nan=True), k
+
+
 def test_wind_stats_kernel_vs_oracle(built_lib):
     """k_wind_stats against the NumPy restatement — fp64 inputs, sums in day order on both
     sides, so bit for bit; plus the host mirror of calc_wnd_stat (month mask, levels, grouping rule)."""

@@ -27,7 +27,7 @@ EXPORTS = ('tcr_abi_version', 'tcr_ctx_create', 'tcr_ctx_destroy', 'tcr_last_err
            'tcr_timing_last', 'tcr_timing_sum', 'tcr_sync', 'tcr_compact_dev',
            'tcr_gather_seeds_dev', 'tcr_pack_tracks_dev', 'tcr_stats_dev', 'tcr_integrate_pass_stats', 'tcr_wind_stats_dev', 'tcr_wind_stats_host', 'tcr_entropy_table_upload',
            'tcr_potential_intensity_host', 'tcr_potential_intensity_dev', 'tcr_chi_rh_host',
-           'tcr_integrate_probe_host')
+           'tcr_integrate_probe_host', 'tcr_integrate_f32_dev', 'tcr_integrate_f32_host', 'tcr_pack_tracks_f32_dev')
 
 
 class Grid(C.Structure):
@@ -132,6 +132,8 @@ def lib():
     L.tcr_masks_upload.argtypes = [C.c_void_p, C.POINTER(Grid), U8P, C.POINTER(U8P)]
     L.tcr_integrate_host.argtypes = [C.c_void_p, C.POINTER(Storms), C.POINTER(Tracks)]
     L.tcr_integrate_probe_host.argtypes = [C.c_void_p, C.POINTER(Storms), C.POINTER(Tracks), C.c_void_p, C.c_int32]
+    L.tcr_integrate_f32_dev.argtypes = [C.c_void_p, C.POINTER(Storms), C.POINTER(Tracks), C.c_void_p]    # tcr_tracks_f32 has tcr_tracks' layout
+    L.tcr_integrate_f32_host.argtypes = [C.c_void_p, C.POINTER(Storms), C.POINTER(Tracks)]
     L.tcr_integrate_dev.argtypes = [C.c_void_p, C.POINTER(Storms), C.POINTER(Tracks), C.c_void_p]
     L.tcr_seed_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_int64, C.POINTER(Seeds), C.c_void_p]
     L.tcr_seed_host.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_int64, C.POINTER(Seeds)]
@@ -158,6 +160,7 @@ def lib():
     L.tcr_stats_dev.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(Tracks), C.c_void_p, C.c_void_p]
     L.tcr_pack_tracks_dev.argtypes = [C.c_void_p, C.POINTER(Tracks), C.c_void_p, C.c_void_p,
                                       C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    L.tcr_pack_tracks_f32_dev.argtypes = L.tcr_pack_tracks_dev.argtypes
     if L.tcr_abi_version() != TCR_ABI_VERSION:
         raise TcrError('libtcrisk_hip.so ABI version %d != binding version %d'
                        % (L.tcr_abi_version(), TCR_ABI_VERSION))

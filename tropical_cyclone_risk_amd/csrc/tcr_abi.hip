@@ -28,27 +28,36 @@ struct GridStore {
     double *d_lon = nullptr, *d_lat = nullptr, *d_rlon = nullptr, *d_rlat = nullptr;
     bool affine_lon = false, affine_lat = false;
     bool set = false;
+    // fp32 view of the same grid (built on first use of an fp32 entry point): knots rounded to float,
+    // reciprocal widths and the affine test redone in float arithmetic
+    std::vector<float> lon32, lat32;
+    float *d_lon32 = nullptr, *d_lat32 = nullptr, *d_rlon32 = nullptr, *d_rlat32 = nullptr;
+    bool affine_lon32 = false, affine_lat32 = false;
+    bool set32 = false;
 };
 
 // An axis is "affine" when x0 + i*dx reproduces every knot bit for bit and every cell's
 // reciprocal width 1.0/(x[i+1]-x[i]) is the same double; the kernels then never load knots.
-bool axis_is_affine(const std::vector<double> &x)
+template <typename R>
+bool axis_is_affine(const std::vector<R> &x)
 {
     const int n = (int)x.size();
-    const double x0 = x[0], dx = x[1] - x[0];
-    const double rdx = 1.0 / dx;
+    const R x0 = x[0], dx = x[1] - x[0];
+    const R rdx = R(1.0) / dx;
     for (int i = 0; i < n; ++i) {
-        volatile double prod = (double)i * dx;      // no FMA contraction: mirror the device expression
-        volatile double xi = x0 + prod;
+        volatile R prod = (R)i * dx;      // no FMA contraction: mirror the device expression
+        volatile R xi = x0 + prod;
         if (xi != x[i]) return false;
     }
     for (int i = 0; i + 1 < n; ++i)
-        if (1.0 / (x[i + 1] - x[i]) != rdx) return false;
+        if (R(1.0) / (x[i + 1] - x[i]) != rdx) return false;
     return true;
 }
 
 struct SlotStore {
     double *wind = nullptr, *thermo = nullptr, *rh = nullptr;
+    float *wind32 = nullptr, *thermo32 = nullptr;       // fp32 copies (tcr_integrate_f32_*), converted on the device
+    bool f32_stale = true;
 };
 
 }  // namespace
@@ -83,6 +92,8 @@ struct tcr_ctx {
     size_t pf_cap = 0;
     int fs_period = 0;                          // 0: direct Fourier kernel
     int cu_count = 256;
+    float *d_stat32 = nullptr;                  // fp32 copy of the land / bathymetry planes
+    bool stat32_stale = true;
     int32_t *d_tc_idx = nullptr;                // storms that passed accept test 1 (k_screen -> compaction), tc_rows_only
     size_t tc_idx_cap = 0;
     int64_t *d_tc_count = nullptr;
@@ -187,7 +198,10 @@ int sync_slots(tcr_ctx *ctx)
         ctx->d_slots_cap = n;
     }
     std::vector<DevSlot> h(n);
-    for (size_t i = 0; i < n; ++i) { h[i].wind = ctx->slots[i].wind; h[i].thermo = ctx->slots[i].thermo; h[i].rh = ctx->slots[i].rh; }
+    for (size_t i = 0; i < n; ++i) {
+        h[i].wind = ctx->slots[i].wind; h[i].thermo = ctx->slots[i].thermo; h[i].rh = ctx->slots[i].rh;
+        h[i].wind32 = ctx->slots[i].wind32; h[i].thermo32 = ctx->slots[i].thermo32;
+    }
     if (n) HIPCHK(ctx, hipMemcpy(ctx->d_slots, h.data(), sizeof(DevSlot) * n, hipMemcpyHostToDevice));
     ctx->slots_dirty = false;
     return 0;
@@ -229,33 +243,15 @@ int grow(tcr_ctx *ctx, double **p, size_t *cap, size_t need)
 
 namespace {
 
-int launch_fourier(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const double *phases, double *fs, hipStream_t st)
-{
-    const tcr_params &P = ctx->prm;
-    if (ctx->fs_period > 0) {
-        const size_t lds = sizeof(double2) * (size_t)ctx->fs_period;
-        const int64_t nf = n * 4 * (int64_t)P.n_series;
-        {
-            double *p = reinterpret_cast<double *>(ctx->d_pf);
-            if (grow(ctx, &p, &ctx->pf_cap, (size_t)nf * 2)) { ctx->d_pf = nullptr; return -1; }
-            ctx->d_pf = reinterpret_cast<double2 *>(p);
-        }
-        hipLaunchKernelGGL(k_phase_factors, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, P, n, n_dev, phases, ctx->d_pf);
-        hipLaunchKernelGGL(k_fourier_periodic, dim3((unsigned)n), dim3(kFsThreads), lds, st, P, n, n_dev,
-                           ctx->fs_period, ctx->d_sc_table, ctx->d_pf, fs);
-    } else {
-        const int64_t total = n * (int64_t)P.n_steps;
-        hipLaunchKernelGGL(k_fourier_direct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, n, n_dev, phases, fs);
-    }
-    HIPCHK(ctx, hipGetLastError());
-    return 0;
-}
-
 // Number of persistent waves of k_integrate.  Lanes pull storms from a queue, so fewer
 // lanes than storms is fine (and balances storm lifetimes); up to one wave per SIMD while
 // the batch is small, two per SIMD once every lane would still get several storms.
-unsigned integrate_waves(const tcr_ctx *ctx, int64_t n)
+unsigned integrate_waves(const tcr_ctx *ctx, int64_t n, int wps)
 {
+    // one wave per SIMD per launch also when the register budget allows wps > 1 resident waves (fp32): the second
+    // slot is for the waves of the batches other streams have in flight, and a launch of more waves than storms / 64
+    // would leave lanes without work from the start
+    (void)wps;
     const int64_t simds = (int64_t)ctx->cu_count * 4;
     int64_t waves = (n + kWave - 1) / kWave;
     if (const char *e = getenv("TCR_WAVES")) {
@@ -270,12 +266,13 @@ unsigned integrate_waves(const tcr_ctx *ctx, int64_t n)
 // live and the queue is empty.  Only worth it when the launch fills the chip (one wave per SIMD):
 // it trades latency of the chain (pass barriers) for SIMD time, and SIMD time is only scarce then.
 // TCR_PARK=0 disables the chain (one launch runs every storm to its end), TCR_PARK=k forces k.
-int park_threshold(const tcr_ctx *ctx, unsigned waves)
+int park_threshold(const tcr_ctx *ctx, unsigned waves, int wps)
 {
     if (const char *e = getenv("TCR_PARK")) {
         const long v = atol(e);
         return v <= 0 ? 0 : (v > 63 ? 63 : (int)v);
     }
+    (void)wps;
     return waves >= (unsigned)ctx->cu_count * 4u ? 32 : 0;
 }
 
@@ -305,6 +302,251 @@ struct DevBuf {
         return d;
     }
 };
+
+int timing_events(tcr_ctx *ctx, hipEvent_t **quad)
+{
+    if (ctx->ev_used + 4 > ctx->ev_pool.size()) {
+        const size_t old = ctx->ev_pool.size();
+        ctx->ev_pool.resize(old + 64, nullptr);
+        for (size_t i = old; i < ctx->ev_pool.size(); ++i) HIPCHK(ctx, hipEventCreate(&ctx->ev_pool[i]));
+    }
+    *quad = &ctx->ev_pool[ctx->ev_used];
+    ctx->ev_used += 4;
+    return 0;
+}
+
+
+void launch_integrate_probe(const KArgsT<double> &a, bool affine, unsigned waves, hipStream_t st)
+{
+    if (affine) hipLaunchKernelGGL((k_integrate<double, true, true>), dim3(waves), dim3(kWave), 0, st, a);
+    else hipLaunchKernelGGL((k_integrate<double, false, true>), dim3(waves), dim3(kWave), 0, st, a);
+}
+void launch_integrate_probe(const KArgsT<float> &, bool, unsigned, hipStream_t) {}      // fp64 instrument only
+
+// ---- fp32 staging: float knots (+ reciprocal widths and the affine test in float arithmetic) and float
+// copies of the interleaved field layouts, converted on the device from the fp64 arrays already staged
+__global__ __launch_bounds__(256) void k_to_f32(const double *__restrict__ src, float *__restrict__ dst, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+
+int grid_f32(tcr_ctx *ctx, GridStore &g, const char *what)
+{
+    if (g.set32) return 0;
+    auto one = [&](const std::vector<double> &x, std::vector<float> &x32, float **d_x, float **d_rx, bool *affine) -> int {
+        const int n = (int)x.size();
+        x32.resize(n);
+        for (int i = 0; i < n; ++i) x32[i] = (float)x[i];
+        for (int i = 1; i < n; ++i)
+            if (!(x32[i] > x32[i - 1])) return fail(ctx, "%s grid: knots are not strictly increasing once rounded to fp32", what);
+        std::vector<float> r(n - 1);
+        for (int i = 0; i + 1 < n; ++i) r[i] = 1.0f / (x32[i + 1] - x32[i]);
+        if (dev_alloc(ctx, d_x, (size_t)n) || dev_alloc(ctx, d_rx, (size_t)n)) return -1;
+        HIPCHK(ctx, hipMemcpy(*d_x, x32.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(*d_rx, r.data(), sizeof(float) * (n - 1), hipMemcpyHostToDevice));
+        *affine = axis_is_affine(x32);
+        return 0;
+    };
+    if (one(g.lon, g.lon32, &g.d_lon32, &g.d_rlon32, &g.affine_lon32)) return -1;
+    if (one(g.lat, g.lat32, &g.d_lat32, &g.d_rlat32, &g.affine_lat32)) return -1;
+    g.set32 = true;
+    return 0;
+}
+
+int ensure_f32(tcr_ctx *ctx, hipStream_t st)
+{
+    if (grid_f32(ctx, ctx->wg, "wind") || grid_f32(ctx, ctx->tg, "thermo") || grid_f32(ctx, ctx->hg, "static")) return -1;
+    const size_t nw = ctx->wg.lon.size() * ctx->wg.lat.size() * kWindStride;
+    const size_t nt = ctx->tg.lon.size() * ctx->tg.lat.size() * kThermoStride;
+    const size_t nh = ctx->hg.lon.size() * ctx->hg.lat.size() * kStaticStride;
+    auto conv = [&](const double *src, float **dst, size_t n) -> int {
+        if (!*dst && dev_alloc(ctx, dst, n)) return -1;
+        hipLaunchKernelGGL(k_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, *dst, n);
+        return 0;
+    };
+    for (auto &s : ctx->slots) {
+        if (!s.wind || !s.f32_stale) continue;
+        if (conv(s.wind, &s.wind32, nw) || conv(s.thermo, &s.thermo32, nt)) return -1;
+        s.f32_stale = false;
+        ctx->slots_dirty = true;
+    }
+    if (ctx->stat32_stale) {
+        if (conv(ctx->d_stat, &ctx->d_stat32, nh)) return -1;
+        ctx->stat32_stale = false;
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return sync_slots(ctx);
+}
+
+template <typename R> AxisT<R> axis_of(const GridStore &g, bool lon);
+template <> AxisT<double> axis_of<double>(const GridStore &g, bool lon)
+{
+    return lon ? dev_axis(g.lon, g.d_lon, g.d_rlon, g.affine_lon) : dev_axis(g.lat, g.d_lat, g.d_rlat, g.affine_lat);
+}
+template <> AxisT<float> axis_of<float>(const GridStore &g, bool lon)
+{
+    const std::vector<float> &x = lon ? g.lon32 : g.lat32;
+    AxisT<float> a{};
+    a.n = (int)x.size();
+    a.affine = (lon ? g.affine_lon32 : g.affine_lat32) ? 1 : 0;
+    a.x = lon ? g.d_lon32 : g.d_lat32; a.rx = lon ? g.d_rlon32 : g.d_rlat32;
+    a.x0 = x.front(); a.xn = x.back();
+    a.dx = x[1] - x[0];
+    a.rdx = 1.0f / a.dx;
+    a.inv_step = (float)(a.n - 1) / (x.back() - x.front());
+    return a;
+}
+
+// evaluation constants of one precision (copied to LDS by the kernels)
+template <typename R>
+void host_eval_k(const tcr_ctx *ctx, EvalKT<R> &K, bool *all_affine)
+{
+    K.wx = axis_of<R>(ctx->wg, true); K.wy = axis_of<R>(ctx->wg, false);
+    K.tx = axis_of<R>(ctx->tg, true); K.ty = axis_of<R>(ctx->tg, false);
+    K.hx = axis_of<R>(ctx->hg, true); K.hy = axis_of<R>(ctx->hg, false);
+    K.stat = std::is_same<R, double>::value ? reinterpret_cast<const R *>(ctx->d_stat) : reinterpret_cast<const R *>(ctx->d_stat32);
+    eval_k_scalars<R>(ctx->prm, K);
+    *all_affine = K.wx.affine && K.wy.affine && K.tx.affine && K.ty.affine && K.hx.affine && K.hy.affine;
+}
+
+// Outputs of one precision: tcr_tracks (double planes) or tcr_tracks_f32 (float planes), same layout
+template <typename R>
+struct TracksT {
+    R *lon, *lat, *v, *m, *vmax, *envw;
+    int32_t *n_valid, *status, *flags, *nfev, *n_accept, *n_reject, *pad_state;
+    int32_t tc_rows_only;
+};
+template <typename R, typename T>
+TracksT<R> tracks_of(const T *o)
+{
+    TracksT<R> t{};
+    t.lon = o->lon; t.lat = o->lat; t.v = o->v; t.m = o->m; t.vmax = o->vmax; t.envw = o->envw;
+    t.n_valid = o->n_valid; t.status = o->status; t.flags = o->flags; t.nfev = o->nfev;
+    t.n_accept = o->n_accept; t.n_reject = o->n_reject; t.pad_state = o->pad_state; t.tc_rows_only = o->tc_rows_only;
+    return t;
+}
+
+template <typename R>
+int launch_fourier(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const double *phases, R *fs, hipStream_t st)
+{
+    const tcr_params &P = ctx->prm;
+    if (ctx->fs_period > 0) {
+        const size_t lds = sizeof(double2) * (size_t)ctx->fs_period;
+        const int64_t nf = n * 4 * (int64_t)P.n_series;
+        {
+            double *p = reinterpret_cast<double *>(ctx->d_pf);
+            if (grow(ctx, &p, &ctx->pf_cap, (size_t)nf * 2)) { ctx->d_pf = nullptr; return -1; }
+            ctx->d_pf = reinterpret_cast<double2 *>(p);
+        }
+        hipLaunchKernelGGL(k_phase_factors, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, P, n, n_dev, phases, ctx->d_pf);
+        hipLaunchKernelGGL(k_fourier_periodic<R>, dim3((unsigned)n), dim3(kFsThreads), lds, st, P, n, n_dev,
+                           ctx->fs_period, ctx->d_sc_table, ctx->d_pf, fs);
+    } else {
+        const int64_t total = n * (int64_t)P.n_steps;
+        hipLaunchKernelGGL(k_fourier_direct<R>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, n, n_dev, phases, fs);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+// The per-candidate body of run_tracks for a batch (see tcr_integrate_dev in the header), in precision R.
+template <typename R>
+int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, void *stream_)
+{
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int64_t n = in->n;
+    if (n < 0) return fail(ctx, "tcr_integrate: negative n");
+    if (n == 0) return 0;
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    const tcr_params &P = ctx->prm;
+    const size_t ns = (size_t)P.n_steps;
+    constexpr size_t REC = (size_t)step_rec_doubles<R>();
+    if (grow(ctx, &ctx->d_fs, &ctx->fs_cap, ((size_t)n * ns * 4 * sizeof(R) + 7) / 8)) return -1;
+    const int max_rk = P.max_rk_steps > 0 ? P.max_rk_steps : 64;
+    if (grow(ctx, &ctx->d_srec, &ctx->srec_cap, (size_t)n * max_rk * REC)) return -1;
+    if (max_rk > 65535) return fail(ctx, "tcr_params.max_rk_steps must be <= 65535");
+    {
+        double *p = reinterpret_cast<double *>(ctx->d_sidx);        // [n][n_steps] uint16: step of each sample
+        if (grow(ctx, &p, &ctx->sidx_cap, ((size_t)n * ns * sizeof(uint16_t) + 7) / 8)) { ctx->d_sidx = nullptr; return -1; }
+        ctx->d_sidx = reinterpret_cast<uint16_t *>(p);
+    }
+    R *fs = reinterpret_cast<R *>(ctx->d_fs);
+    EvalKT<R> EK{};
+    bool affine = false;
+    host_eval_k<R>(ctx, EK, &affine);
+
+    hipEvent_t *ev = nullptr;
+    if (ctx->timing && timing_events(ctx, &ev)) return -1;
+    if (ev) HIPCHK(ctx, hipEventRecord(ev[0], st));
+    if (launch_fourier<R>(ctx, n, in->n_dev, in->phases, fs, st)) return -1;
+    if (ev) HIPCHK(ctx, hipEventRecord(ev[1], st));
+    {
+        KArgsT<R> a{};
+        a.P = P; a.D = dev_fields(ctx); a.K = EK; a.n = n; a.n_dev = in->n_dev;
+        a.lon0 = in->lon0; a.lat0 = in->lat0; a.v0 = in->v0; a.m0 = in->m0; a.h_bl = in->h_bl;
+        a.slot = in->slot; a.phases = in->phases; a.fs = fs; a.srec = ctx->d_srec; a.max_rk_steps = max_rk;
+        a.n_valid = out.n_valid; a.status = out.status; a.nfev = out.nfev;
+        a.n_accept = out.n_accept; a.n_reject = out.n_reject;
+        a.queue = ctx->d_queue;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, kQueueWords * sizeof(unsigned long long), st));
+        // Chain of launches with tail compaction (k_integrate): a pass parks the storms of waves that
+        // fall under `thr` live lanes, the next pass needs at most waves*(thr-1)/64 waves for them.
+        const int wps = std::is_same<R, double>::value ? TCR_INT_WPS : TCR_INT_WPS_F32;
+        unsigned waves = integrate_waves(ctx, n, wps);
+        const int thr = park_threshold(ctx, waves, wps);
+        const unsigned final_waves = park_final_waves();
+        if (thr > 0 && grow(ctx, &ctx->d_park[0], &ctx->park_cap[0], (size_t)waves * kWave * kParkRec)) return -1;
+        if (thr > 0 && grow(ctx, &ctx->d_park[1], &ctx->park_cap[1], (size_t)waves * kWave * kParkRec)) return -1;
+        for (int pass = 0; pass < kMaxPasses; ++pass) {
+            const bool last = thr <= 0 || waves <= final_waves || pass == kMaxPasses - 1;
+            a.pass = pass;
+            a.threshold = last ? 0 : thr;
+            a.park_in = ctx->d_park[(pass + 1) & 1];
+            a.park_out = ctx->d_park[pass & 1];
+            if (std::is_same<R, double>::value && ctx->d_probe) {
+                a.probe = ctx->d_probe; a.probe_cap = ctx->probe_cap;
+                launch_integrate_probe(a, affine, waves, st);
+            } else if (affine) hipLaunchKernelGGL((k_integrate<R, true, false>), dim3(waves), dim3(kWave), 0, st, a);
+            else hipLaunchKernelGGL((k_integrate<R, false, false>), dim3(waves), dim3(kWave), 0, st, a);
+            if (last) break;
+            waves = (unsigned)(((size_t)waves * (size_t)(thr - 1) + kWave - 1) / kWave);
+        }
+    }
+    if (ev) HIPCHK(ctx, hipEventRecord(ev[2], st));
+    {
+        EArgsT<R> a{};
+        a.P = P; a.D = dev_fields(ctx); a.n = n; a.n_dev = in->n_dev; a.max_rk_steps = max_rk; a.srec = ctx->d_srec; a.fs = fs;
+        a.slot = in->slot; a.n_valid = out.n_valid; a.status = out.status; a.n_accept = out.n_accept;
+        a.lon = out.lon; a.lat = out.lat; a.v = out.v; a.m = out.m; a.vmax = out.vmax;
+        a.envw = out.envw; a.flags = out.flags; a.pad_state = out.pad_state;
+        a.K = EK;
+        const unsigned chunks = (unsigned)((ns + kPostThreads - 1) / kPostThreads);
+        if (out.tc_rows_only) {
+            // Only what the reference does (compute.py:185-204): accept test 1 from the v series alone, then env
+            // winds, vmax and rows for the storms that passed.  The list stays on the device; the grids are
+            // sized for the whole batch and workgroups beyond *count leave at once.
+            if ((size_t)n > ctx->tc_idx_cap) {
+                if (ctx->d_tc_idx) HIPCHK(ctx, hipFree(ctx->d_tc_idx));
+                ctx->d_tc_idx = nullptr; ctx->tc_idx_cap = 0;
+                if (dev_alloc(ctx, &ctx->d_tc_idx, (size_t)n)) return -1;
+                ctx->tc_idx_cap = (size_t)n;
+            }
+            hipLaunchKernelGGL(k_screen<R>, dim3((unsigned)((n + kScreenStorms - 1) / kScreenStorms)), dim3(kScreenThreads), 0, st, a);
+            if (tcr_compact_dev(ctx, n, out.flags, TCR_FLAG_IS_TC, n, ctx->d_tc_idx, ctx->d_tc_count, st)) return -1;
+            a.list = ctx->d_tc_idx; a.count = ctx->d_tc_count;
+        }
+        hipLaunchKernelGGL(k_dense<R>, dim3((unsigned)n), dim3(kWave), 0, st, a, ctx->d_sidx);
+        if (affine) hipLaunchKernelGGL((k_emit<R, true>), dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
+        else hipLaunchKernelGGL((k_emit<R, false>), dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
+        hipLaunchKernelGGL(k_flags<R>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, n, out.n_valid,
+                           out.status, out.v, out.flags, out.pad_state, a.list, a.count, a.n_dev);
+    }
+    if (ev) HIPCHK(ctx, hipEventRecord(ev[3], st));
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -349,8 +591,10 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (GridStore *g : {&ctx->wg, &ctx->tg, &ctx->hg, &ctx->mg, &ctx->rg}) {
         (void)hipFree(g->d_lon); (void)hipFree(g->d_lat); (void)hipFree(g->d_rlon); (void)hipFree(g->d_rlat);
+        (void)hipFree(g->d_lon32); (void)hipFree(g->d_lat32); (void)hipFree(g->d_rlon32); (void)hipFree(g->d_rlat32);
     }
-    for (auto &s : ctx->slots) { (void)hipFree(s.wind); (void)hipFree(s.thermo); (void)hipFree(s.rh); }
+    for (auto &s : ctx->slots) { (void)hipFree(s.wind); (void)hipFree(s.thermo); (void)hipFree(s.rh); (void)hipFree(s.wind32); (void)hipFree(s.thermo32); }
+    (void)hipFree(ctx->d_stat32);
     (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_run_mask); (void)hipFree(ctx->d_basin_masks);
     (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_srec);
     for (auto &ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
@@ -403,6 +647,7 @@ int tcr_static_upload(tcr_ctx *ctx, const tcr_grid *hg, const double *land, cons
     for (size_t i = 0; i < np; ++i) { h[i * 2] = land[i]; h[i * 2 + 1] = bathy[i]; }
     if (!ctx->d_stat && dev_alloc(ctx, &ctx->d_stat, h.size())) return -1;
     HIPCHK(ctx, hipMemcpy(ctx->d_stat, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    ctx->stat32_stale = true;
     return 0;
 }
 
@@ -434,6 +679,7 @@ int tcr_fields_upload(tcr_ctx *ctx, int slot, const tcr_grid *wg, const double *
         if (!s.thermo && dev_alloc(ctx, &s.thermo, h.size())) return -1;
         HIPCHK(ctx, hipMemcpy(s.thermo, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
     }
+    s.f32_stale = true;
     ctx->slots_dirty = true;
     return 0;
 }
@@ -477,18 +723,6 @@ int tcr_timing_enable(tcr_ctx *ctx, int on)
     if (!ctx) return -1;
     ctx->timing = on != 0;
     ctx->ev_used = 0;
-    return 0;
-}
-
-static int timing_events(tcr_ctx *ctx, hipEvent_t **quad)
-{
-    if (ctx->ev_used + 4 > ctx->ev_pool.size()) {
-        const size_t old = ctx->ev_pool.size();
-        ctx->ev_pool.resize(old + 64, nullptr);
-        for (size_t i = old; i < ctx->ev_pool.size(); ++i) HIPCHK(ctx, hipEventCreate(&ctx->ev_pool[i]));
-    }
-    *quad = &ctx->ev_pool[ctx->ev_used];
-    ctx->ev_used += 4;
     return 0;
 }
 
@@ -554,96 +788,24 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out,
 {
     if (ready(ctx, false)) return -1;
     if (!in || !out) return fail(ctx, "tcr_integrate_dev: NULL argument");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    const int64_t n = in->n;
-    if (n < 0) return fail(ctx, "tcr_integrate_dev: negative n");
-    if (n == 0) return 0;
-    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
-    const tcr_params &P = ctx->prm;
-    const size_t ns = (size_t)P.n_steps;
-    if (grow(ctx, &ctx->d_fs, &ctx->fs_cap, (size_t)n * ns * 4)) return -1;
-    const int max_rk = P.max_rk_steps > 0 ? P.max_rk_steps : 64;
-    if (grow(ctx, &ctx->d_srec, &ctx->srec_cap, (size_t)n * max_rk * kStepRec)) return -1;
-    if (max_rk > 65535) return fail(ctx, "tcr_params.max_rk_steps must be <= 65535");
-    {
-        double *p = reinterpret_cast<double *>(ctx->d_sidx);        // [n][n_steps] uint16: step of each sample
-        if (grow(ctx, &p, &ctx->sidx_cap, ((size_t)n * ns * sizeof(uint16_t) + 7) / 8)) { ctx->d_sidx = nullptr; return -1; }
-        ctx->d_sidx = reinterpret_cast<uint16_t *>(p);
-    }
+    return integrate_impl<double>(ctx, in, tracks_of<double>(out), stream_);
+}
 
-    hipEvent_t *ev = nullptr;
-    if (ctx->timing && timing_events(ctx, &ev)) return -1;
-    if (ev) HIPCHK(ctx, hipEventRecord(ev[0], st));
-    if (launch_fourier(ctx, n, in->n_dev, in->phases, ctx->d_fs, st)) return -1;
-    if (ev) HIPCHK(ctx, hipEventRecord(ev[1], st));
-    {
-        KArgs a{};
-        a.P = P; a.D = dev_fields(ctx); a.n = n; a.n_dev = in->n_dev;
-        a.lon0 = in->lon0; a.lat0 = in->lat0; a.v0 = in->v0; a.m0 = in->m0; a.h_bl = in->h_bl;
-        a.slot = in->slot; a.phases = in->phases; a.fs = ctx->d_fs; a.srec = ctx->d_srec; a.max_rk_steps = max_rk;
-        a.n_valid = out->n_valid; a.status = out->status; a.nfev = out->nfev;
-        a.n_accept = out->n_accept; a.n_reject = out->n_reject;
-        a.queue = ctx->d_queue;
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, kQueueWords * sizeof(unsigned long long), st));
-        // Chain of launches with tail compaction (k_integrate): a pass parks the storms of waves that
-        // fall under `thr` live lanes, the next pass needs at most waves*(thr-1)/64 waves for them.
-        unsigned waves = integrate_waves(ctx, n);
-        const int thr = park_threshold(ctx, waves);
-        const unsigned final_waves = park_final_waves();
-        if (thr > 0 && grow(ctx, &ctx->d_park[0], &ctx->park_cap[0], (size_t)waves * kWave * kParkRec)) return -1;
-        if (thr > 0 && grow(ctx, &ctx->d_park[1], &ctx->park_cap[1], (size_t)waves * kWave * kParkRec)) return -1;
-        for (int pass = 0; pass < kMaxPasses; ++pass) {
-            const bool last = thr <= 0 || waves <= final_waves || pass == kMaxPasses - 1;
-            a.pass = pass;
-            a.threshold = last ? 0 : thr;
-            a.park_in = ctx->d_park[(pass + 1) & 1];
-            a.park_out = ctx->d_park[pass & 1];
-            if (ctx->d_probe) {
-                a.probe = ctx->d_probe; a.probe_cap = ctx->probe_cap;
-                if (a.D.all_affine) hipLaunchKernelGGL((k_integrate<true, true>), dim3(waves), dim3(kWave), 0, st, a);
-                else hipLaunchKernelGGL((k_integrate<false, true>), dim3(waves), dim3(kWave), 0, st, a);
-            } else if (a.D.all_affine) hipLaunchKernelGGL((k_integrate<true, false>), dim3(waves), dim3(kWave), 0, st, a);
-            else hipLaunchKernelGGL((k_integrate<false, false>), dim3(waves), dim3(kWave), 0, st, a);
-            if (last) break;
-            waves = (unsigned)(((size_t)waves * (size_t)(thr - 1) + kWave - 1) / kWave);
-        }
-    }
-    if (ev) HIPCHK(ctx, hipEventRecord(ev[2], st));
-    {
-        EArgs a{};
-        a.P = P; a.D = dev_fields(ctx); a.n = n; a.n_dev = in->n_dev; a.max_rk_steps = max_rk; a.srec = ctx->d_srec; a.fs = ctx->d_fs;
-        a.slot = in->slot; a.n_valid = out->n_valid; a.status = out->status; a.n_accept = out->n_accept;
-        a.lon = out->lon; a.lat = out->lat; a.v = out->v; a.m = out->m; a.vmax = out->vmax;
-        a.envw = out->envw; a.flags = out->flags; a.pad_state = out->pad_state;
-        make_eval_k(P, a.D, a.K);
-        const unsigned chunks = (unsigned)((ns + kPostThreads - 1) / kPostThreads);
-        if (out->tc_rows_only) {
-            // Only what the reference does (compute.py:185-204): accept test 1 from the v series alone, then env
-            // winds, vmax and rows for the storms that passed.  The list stays on the device; the grids are
-            // sized for the whole batch and workgroups beyond *count leave at once.
-            if ((size_t)n > ctx->tc_idx_cap) {
-                if (ctx->d_tc_idx) HIPCHK(ctx, hipFree(ctx->d_tc_idx));
-                ctx->d_tc_idx = nullptr; ctx->tc_idx_cap = 0;
-                if (dev_alloc(ctx, &ctx->d_tc_idx, (size_t)n)) return -1;
-                ctx->tc_idx_cap = (size_t)n;
-            }
-            hipLaunchKernelGGL(k_screen, dim3((unsigned)((n + kScreenStorms - 1) / kScreenStorms)), dim3(kScreenThreads), 0, st, a);
-            if (tcr_compact_dev(ctx, n, out->flags, TCR_FLAG_IS_TC, n, ctx->d_tc_idx, ctx->d_tc_count, st)) return -1;
-            a.list = ctx->d_tc_idx; a.count = ctx->d_tc_count;
-        }
-        hipLaunchKernelGGL(k_dense, dim3((unsigned)n), dim3(kWave), 0, st, a, ctx->d_sidx);
-        if (a.D.all_affine) hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
-        else hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
-        hipLaunchKernelGGL(k_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, n, out->n_valid,
-                           out->status, out->v, out->flags, out->pad_state, a.list, a.count, a.n_dev);
-    }
-    if (ev) HIPCHK(ctx, hipEventRecord(ev[3], st));
-    HIPCHK(ctx, hipGetLastError());
-    return 0;
+int tcr_integrate_f32_dev(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks_f32 *out, void *stream_)
+{
+    if (ready(ctx, false)) return -1;
+    if (!in || !out) return fail(ctx, "tcr_integrate_f32_dev: NULL argument");
+    if (ctx->d_probe) return fail(ctx, "the decision probe is an fp64 instrument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ensure_f32(ctx, stream_ ? (hipStream_t)stream_ : ctx->stream)) return -1;
+    return integrate_impl<float>(ctx, in, tracks_of<float>(out), stream_);
 }
 
 
-int tcr_integrate_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out)
+extern "C++" {
+namespace {
+template <typename R, typename T>
+int integrate_host_impl(tcr_ctx *ctx, const tcr_storms *in, const T *out)
 {
     if (ready(ctx, false)) return -1;
     if (!in || !out) return fail(ctx, "tcr_integrate_host: NULL argument");
@@ -660,9 +822,9 @@ int tcr_integrate_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out
     di.m0 = B.put(in->m0, n); di.h_bl = B.put(in->h_bl, n); di.slot = B.put(in->slot, n);
     di.phases = B.put(in->phases, n * 4 * N);
     di.n_dev = nullptr;
-    tcr_tracks dout{};
-    dout.lon = B.get<double>(n * ns); dout.lat = B.get<double>(n * ns); dout.v = B.get<double>(n * ns);
-    dout.m = B.get<double>(n * ns); dout.vmax = B.get<double>(n * ns); dout.envw = B.get<double>(n * ns * 4);
+    TracksT<R> dout{};
+    dout.lon = B.get<R>(n * ns); dout.lat = B.get<R>(n * ns); dout.v = B.get<R>(n * ns);
+    dout.m = B.get<R>(n * ns); dout.vmax = B.get<R>(n * ns); dout.envw = B.get<R>(n * ns * 4);
     dout.n_valid = B.get<int32_t>(n); dout.status = B.get<int32_t>(n); dout.flags = B.get<int32_t>(n);
     dout.nfev = B.get<int32_t>(n); dout.n_accept = B.get<int32_t>(n); dout.n_reject = B.get<int32_t>(n);
     if (!di.lon0 || !di.lat0 || !di.v0 || !di.m0 || !di.h_bl || !di.slot || !di.phases || !dout.lon ||
@@ -670,16 +832,30 @@ int tcr_integrate_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out
         !dout.flags || !dout.nfev || !dout.n_accept || !dout.n_reject)
         return fail(ctx, "tcr_integrate_host: device allocation / upload failed");
     dout.tc_rows_only = 0;             // host buffers come back whole: every row is produced
-    if (tcr_integrate_dev(ctx, &di, &dout, ctx->stream)) return -1;
+    if (!std::is_same<R, double>::value && ensure_f32(ctx, ctx->stream)) return -1;
+    if (integrate_impl<R>(ctx, &di, dout, ctx->stream)) return -1;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-#define D2H(field, count, T) \
-    if (out->field) HIPCHK(ctx, hipMemcpy(out->field, dout.field, (count) * sizeof(T), hipMemcpyDeviceToHost))
-    D2H(lon, n * ns, double); D2H(lat, n * ns, double); D2H(v, n * ns, double); D2H(m, n * ns, double);
-    D2H(vmax, n * ns, double); D2H(envw, n * ns * 4, double);
+#define D2H(field, count, TT) \
+    if (out->field) HIPCHK(ctx, hipMemcpy(out->field, dout.field, (count) * sizeof(TT), hipMemcpyDeviceToHost))
+    D2H(lon, n * ns, R); D2H(lat, n * ns, R); D2H(v, n * ns, R); D2H(m, n * ns, R);
+    D2H(vmax, n * ns, R); D2H(envw, n * ns * 4, R);
     D2H(n_valid, n, int32_t); D2H(status, n, int32_t); D2H(flags, n, int32_t); D2H(nfev, n, int32_t);
     D2H(n_accept, n, int32_t); D2H(n_reject, n, int32_t);
 #undef D2H
     return 0;
+}
+}  // namespace
+}  // extern "C++"
+
+int tcr_integrate_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out)
+{
+    return integrate_host_impl<double>(ctx, in, out);
+}
+
+int tcr_integrate_f32_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks_f32 *out)
+{
+    if (ctx && ctx->d_probe) return fail(ctx, "the decision probe is an fp64 instrument");
+    return integrate_host_impl<float>(ctx, in, out);
 }
 
 int tcr_integrate_probe_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out, uint8_t *dec, int32_t cap)
@@ -976,22 +1152,40 @@ int tcr_stats_dev(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const tcr_track
     return 0;
 }
 
-int tcr_pack_tracks_dev(tcr_ctx *ctx, const tcr_tracks *src, const int32_t *idx, const int64_t *count,
-                        int64_t cap, double *packed, int64_t row_stride, void *stream_)
+extern "C++" {
+namespace {
+template <typename R, typename T>
+int pack_impl(tcr_ctx *ctx, const T *src, const int32_t *idx, const int64_t *count, int64_t cap, double *packed,
+              int64_t row_stride, void *stream_)
 {
     if (!ctx) return -1;
     if (!ctx->have_prm) return fail(ctx, "tcr_params_set has not been called");
-    if (!src || !idx || !count || !packed) return fail(ctx, "tcr_pack_tracks_dev: NULL argument");
+    if (!src || !idx || !count || !packed) return fail(ctx, "tcr_pack_tracks: NULL argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (cap <= 0) return 0;
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
-    PackArgs a{};
-    a.src = *src; a.idx = idx; a.count = count; a.cap = cap; a.ns = ctx->prm.n_steps; a.packed = packed;
+    PackArgsT<R> a{};
+    a.lon = src->lon; a.lat = src->lat; a.v = src->v; a.m = src->m; a.vmax = src->vmax; a.envw = src->envw;
+    a.idx = idx; a.count = count; a.cap = cap; a.ns = ctx->prm.n_steps; a.packed = packed;
     a.row_stride = row_stride > 0 ? row_stride : 9 * (int64_t)ctx->prm.n_steps;
-    if (a.row_stride < 9 * (int64_t)ctx->prm.n_steps) return fail(ctx, "tcr_pack_tracks_dev: row_stride < 9 * n_steps");
-    hipLaunchKernelGGL(k_pack_tracks, dim3((unsigned)cap), dim3(256), 0, st, a);
+    if (a.row_stride < 9 * (int64_t)ctx->prm.n_steps) return fail(ctx, "tcr_pack_tracks: row_stride < 9 * n_steps");
+    hipLaunchKernelGGL(k_pack_tracks<R>, dim3((unsigned)cap), dim3(256), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
     return 0;
+}
+}  // namespace
+}  // extern "C++"
+
+int tcr_pack_tracks_dev(tcr_ctx *ctx, const tcr_tracks *src, const int32_t *idx, const int64_t *count,
+                        int64_t cap, double *packed, int64_t row_stride, void *stream_)
+{
+    return pack_impl<double>(ctx, src, idx, count, cap, packed, row_stride, stream_);
+}
+
+int tcr_pack_tracks_f32_dev(tcr_ctx *ctx, const tcr_tracks_f32 *src, const int32_t *idx, const int64_t *count,
+                            int64_t cap, double *packed, int64_t row_stride, void *stream_)
+{
+    return pack_impl<float>(ctx, src, idx, count, cap, packed, row_stride, stream_);
 }
 
 }  // extern "C"

@@ -156,8 +156,9 @@ __global__ __launch_bounds__(256) void k_stats(int64_t n, const int64_t *__restr
 
 // Pack selected tracks into fixed-size survivor records for the all-gather:
 // packed[row] = { lon[ns], lat[ns], v[ns], m[ns], vmax[ns], envw[ns*4] }  (9*ns doubles)
-struct PackArgs {
-    tcr_tracks src;
+template <typename R>
+struct PackArgsT {
+    const R *lon, *lat, *v, *m, *vmax, *envw;
     const int32_t *idx;
     const int64_t *count;       // device scalar written by k_compact_scan
     int64_t cap;
@@ -166,7 +167,8 @@ struct PackArgs {
     double *packed;
 };
 
-__global__ __launch_bounds__(256) void k_pack_tracks(PackArgs a)
+template <typename R>
+__global__ __launch_bounds__(256) void k_pack_tracks(PackArgsT<R> a)
 {
     const int64_t row = blockIdx.x;
     const int64_t cnt = *a.count < a.cap ? *a.count : a.cap;
@@ -174,10 +176,10 @@ __global__ __launch_bounds__(256) void k_pack_tracks(PackArgs a)
     const size_t j = (size_t)a.idx[row];
     const int ns = a.ns;
     double *dst = a.packed + (size_t)row * (size_t)a.row_stride;
-    const double *planes[5] = {a.src.lon, a.src.lat, a.src.v, a.src.m, a.src.vmax};
+    const R *planes[5] = {a.lon, a.lat, a.v, a.m, a.vmax};
     for (int p = 0; p < 5; ++p)
-        for (int i = threadIdx.x; i < ns; i += blockDim.x) dst[(size_t)p * ns + i] = planes[p][j * ns + i];
-    for (int i = threadIdx.x; i < ns * 4; i += blockDim.x) dst[(size_t)5 * ns + i] = a.src.envw[j * ns * 4 + i];
+        for (int i = threadIdx.x; i < ns; i += blockDim.x) dst[(size_t)p * ns + i] = (double)planes[p][j * ns + i];
+    for (int i = threadIdx.x; i < ns * 4; i += blockDim.x) dst[(size_t)5 * ns + i] = (double)a.envw[j * ns * 4 + i];
 }
 
 }  // namespace tcr

@@ -29,16 +29,18 @@
 
 namespace tcr {
 
-struct KArgs {
+template <typename R>
+struct KArgsT {
     tcr_params P;
     DevFields D;
+    EvalKT<R> K;             // host-built evaluation constants, copied to LDS by every workgroup
     int64_t n;
     const int64_t *n_dev;    // optional device scalar (tcr_storms.n_dev): only the first min(n, *n_dev) storms exist
-    const double *lon0, *lat0, *v0, *m0, *h_bl;
+    const double *lon0, *lat0, *v0, *m0, *h_bl;     // storm inputs are fp64 in both instantiations (tcr_storms)
     const int32_t *slot;
     const double *phases;    // [n][4][n_series]
-    double *fs;              // [n][n_steps][4]
-    double *srec;            // [n][max_rk_steps][kStepRec] accepted-step records
+    R *fs;                   // [n][n_steps][4]
+    double *srec;            // [n][max_rk_steps][step_rec_doubles<R>()] accepted-step records
     int32_t *n_valid, *status, *nfev, *n_accept, *n_reject;
     unsigned long long *queue;   // [kMaxPasses] work-queue heads, [kMaxPasses] parked-storm counts, then per pass
                                  // {wave cycles, live-lane cycles, wave wall-clock ticks, wave shader-clock ticks} (all zeroed before pass 0)
@@ -54,6 +56,7 @@ struct KArgs {
     uint8_t *probe;
     int probe_cap;
 };
+using KArgs = KArgsT<double>;
 constexpr int kMaxPasses = 16;
 constexpr int kParkRec = 16;     // doubles per parked storm: t, h, t_new, ha, g, y[4], f[4], 6 x int32
 
@@ -68,9 +71,19 @@ __device__ __forceinline__ int64_t n_eff(int64_t n, const int64_t *n_dev)
     return m < n ? m : n;
 }
 
+// one output sample of the four series: 32 B (fp64) or 16 B (fp32, rounded from the fp64 sums) in one go
+template <typename R>
+__device__ __forceinline__ void store_fs(R *__restrict__ dst, double a, double b, double c, double d)
+{
+    typedef typename VecT<R, 4>::type V4;
+    V4 v; v[0] = (R)a; v[1] = (R)b; v[2] = (R)c; v[3] = (R)d;
+    *reinterpret_cast<V4 *>(dst) = v;
+}
+
+template <typename R>
 __global__ __launch_bounds__(256) void k_fourier_direct(tcr_params P, int64_t n, const int64_t *__restrict__ n_dev,
                                                          const double *__restrict__ phases,
-                                                         double *__restrict__ fs)
+                                                         R *__restrict__ fs)
 {
     const int ns = P.n_steps, N = P.n_series;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -91,9 +104,7 @@ __global__ __launch_bounds__(256) void k_fourier_direct(tcr_params P, int64_t n,
         }
         out[s] = P.fs_amp * acc;
     }
-    double2 *o = reinterpret_cast<double2 *>(fs + gid * 4);
-    o[0] = make_double2(out[0], out[1]);
-    o[1] = make_double2(out[2], out[3]);
+    store_fs<R>(fs + gid * 4, out[0], out[1], out[2], out[3]);
 }
 
 // gen_f, periodic form.  With T_Fs = period * dt_out (the reference's defaults: 20 d
@@ -134,11 +145,12 @@ constexpr int kFsThreads = TCR_FS_THREADS;
 #endif
 constexpr int kFsPerThread = TCR_FS_PER_THREAD;
 
+template <typename R>
 __global__ __launch_bounds__(kFsThreads) void k_fourier_periodic(tcr_params P, int64_t n, const int64_t *__restrict__ n_dev,
                                                                   int period,
                                                                   const double2 *__restrict__ sc_table,
                                                                   const double2 *__restrict__ pf,
-                                                                  double *__restrict__ fs)
+                                                                  R *__restrict__ fs)
 {
     extern __shared__ double2 lds[];            // [period] one period of (sin, cos)
     if ((int64_t)blockIdx.x >= n_eff(n, n_dev)) return;
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(kFsThreads) void k_fourier_periodic(tcr_params P, i
     __syncthreads();
     // (persistent workgroups that stage the table once were measured slower: 0.51 vs 0.37 ms)
     const double2 *__restrict__ pfs = pf + storm * 4 * N;       // wave-uniform
-    double *out = fs + storm * ns * 4;
+    R *out = fs + storm * ns * 4;
     for (int base = 0; base < ns; base += kFsThreads * kFsPerThread) {
         int kk[kFsPerThread], j[kFsPerThread];
         double acc[kFsPerThread][4];
@@ -173,11 +185,8 @@ __global__ __launch_bounds__(kFsThreads) void k_fourier_periodic(tcr_params P, i
 #pragma unroll
         for (int u = 0; u < kFsPerThread; ++u) {
             const int k = base + u * kFsThreads + (int)threadIdx.x;
-            if (k < ns) {
-                double2 *o = reinterpret_cast<double2 *>(out + (size_t)k * 4);
-                o[0] = make_double2(P.fs_amp * acc[u][0], P.fs_amp * acc[u][1]);
-                o[1] = make_double2(P.fs_amp * acc[u][2], P.fs_amp * acc[u][3]);
-            }
+            if (k < ns)
+                store_fs<R>(out + (size_t)k * 4, P.fs_amp * acc[u][0], P.fs_amp * acc[u][1], P.fs_amp * acc[u][2], P.fs_amp * acc[u][3]);
         }
     }
 }
@@ -228,11 +237,22 @@ __device__ __forceinline__ int samples_upto(const tcr_params &P, double t_emit)
     return k + 1;
 }
 
+// np.interp(2 d, res.t, v) between two samples (compute.py:186-188): the fp64 expression on values widened from R
+template <typename R>
+__device__ __forceinline__ double interp_v2d(R v_lo, R v_hi, double t_lo, double t_hi, double t2d)
+{
+    return ((double)v_hi - (double)v_lo) / (t_hi - t_lo) * (t2d - t_lo) + (double)v_lo;
+}
+
 constexpr int kWave = 64;
 #ifndef TCR_INT_WPS
-#define TCR_INT_WPS 1      // waves per SIMD the integrator is register-budgeted for
+#define TCR_INT_WPS 1      // waves per SIMD the fp64 integrator is register-budgeted for
+#endif
+#ifndef TCR_INT_WPS_F32
+#define TCR_INT_WPS_F32 1  // ... and the fp32 instantiation: budgeted for 2 it spills 248 B per lane and is slower (1.38 vs 1.29 ms per step)
 #endif
 constexpr int kRunning = 99;
+template <typename R> constexpr int int_wps() { return sizeof(R) == 8 ? TCR_INT_WPS : TCR_INT_WPS_F32; }
 
 // k_integrate: the sequential part of a storm — RK45 steps until the terminal event.
 //
@@ -242,38 +262,48 @@ constexpr int kRunning = 99;
 // of a divergent state machine.  A lane whose storm ends pulls the next one from the
 // queue at the cycle boundary; a fresh storm spends slots 0 and 1 of its first cycle on
 // the two evaluations of RungeKutta.__init__ (f0 and select_initial_step's f1) and idles
-// for the other four.  Every accepted step leaves one kStepRec-double record
-// (t_old, h, t_new, y_old, K[7][4]) from which k_emit evaluates the hourly samples.
-template <bool AFFINE, bool PROBE>
-__global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
+// for the other four.  Every accepted step leaves one record (doubles t_old, h, t_new, -;
+// then R y_old[4], K[7][4]) from which k_emit evaluates the hourly samples.
+//
+// R = float (BASELINE config 5): state, stage derivatives and the RHS are fp32; what stays fp64 is
+// *time* (t, h, t_new, the stage times, the output grid) and the step-size controller: the error norm
+// is accumulated in fp64 from the fp32 stage derivatives, and err < 1, the factor 0.9 err^-0.2 and the
+// min-step test are the fp64 expressions of the fp64 build (every (double) cast below is the identity there).
+template <typename R, bool AFFINE, bool PROBE>
+__global__ __launch_bounds__(kWave, (int_wps<R>())) void k_integrate(KArgsT<R> a)
 {
     // Kl[(stage*4 + component)*64 + lane]
-    __shared__ double Kl[7 * 4 * kWave];
-    __shared__ EvalK K;
+    __shared__ R Kl[7 * 4 * kWave];
+    __shared__ EvalKT<R> K;
     const tcr_params &P = a.P;
     const DevFields &D = a.D;
     const int lane = threadIdx.x;
     const long long n_items = a.pass == 0 ? (long long)n_eff(a.n, a.n_dev) : (long long)a.queue[kMaxPasses + a.pass - 1];
     if (a.pass > 0 && (long long)blockIdx.x * kWave >= n_items) return;     // the list fits the first waves
     unsigned long long *const q_head = a.queue + a.pass;
-    if (lane == 0) make_eval_k(P, D, K);
+    for (unsigned w = lane; w < sizeof(EvalKT<R>) / 8; w += kWave)
+        reinterpret_cast<uint64_t *>(&K)[w] = reinterpret_cast<const uint64_t *>(&a.K)[w];
     __syncthreads();
     const int ns = P.n_steps;
     const double tb = P.total_time;
+    constexpr int REC = step_rec_doubles<R>();
+    typedef typename VecT<R, 4>::type V4;
 #define KS(j, i) Kl[((j) * 4 + (i)) * kWave + lane]
 
     // ---- per-lane storm state
     long long sid = -1;
     int status = kRunning, nfev = 0, nacc = 0, nrej = 0, next_out = 0;
     bool active = false, fresh = false, exhausted = false, rejected = false;
-    DevSlot S{};
-    const double *fs = nullptr;
+    const R *wind = nullptr, *thermo = nullptr;
+    const R *fs = nullptr;
     double *srec = nullptr;
-    double h_bl = 0.0;
-    double y[4] = {0, 0, 0, 0}, f[4] = {0, 0, 0, 0}, yn[4] = {0, 0, 0, 0};
-    double e[5] = {0, 0, 0, 0, 0};          // evaluation point: t, lon, lat, v, m
-    double t = 0, h = 0, ha = 0, h_abs = 0, t_new = 0, g = 0;
-    CornerCache CC;
+    R h_bl = R(0.0);
+    R y[4] = {0, 0, 0, 0}, f[4] = {0, 0, 0, 0}, yn[4] = {0, 0, 0, 0};
+    R e[4] = {0, 0, 0, 0};                  // evaluation point: lon, lat, v, m
+    double et = 0;                          // ... and its time
+    double t = 0, h = 0, ha = 0, h_abs = 0, t_new = 0;
+    R g = R(0.0);
+    CornerCacheT<R> CC;
     cache_reset(CC);
 
     auto finalize = [&]() {
@@ -295,10 +325,10 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
         ha = fabs(h);
         for (int i = 0; i < 4; ++i) {
             KS(0, i) = f[i];
-            const double dy = 0.0 + f[i] * A10;
-            e[1 + i] = y[i] + dy * h;
+            const R dy = R(0.0) + f[i] * R(A10);
+            e[i] = y[i] + dy * (R)h;
         }
-        e[0] = t + RK_C[1] * h;
+        et = t + RK_C[1] * h;
     };
     auto begin_step = [&]() {
         const double min_step = 10 * fabs(nextafter(t, INFINITY) - t);
@@ -327,18 +357,18 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
                 } else {
                     if (a.pass == 0) {
                         sid = item;
-                        y[0] = a.lon0[sid]; y[1] = a.lat0[sid]; y[2] = a.v0[sid]; y[3] = a.m0[sid];
+                        y[0] = (R)a.lon0[sid]; y[1] = (R)a.lat0[sid]; y[2] = (R)a.v0[sid]; y[3] = (R)a.m0[sid];
                         status = kRunning; nfev = 0; nacc = 0; nrej = 0; next_out = 0;
                         t = 0.0;
-                        e[0] = 0.0; e[1] = y[0]; e[2] = y[1]; e[3] = y[2]; e[4] = y[3];
+                        et = 0.0; e[0] = y[0]; e[1] = y[1]; e[2] = y[2]; e[3] = y[3];
                         fresh = true;
                     } else {
                         // restore a parked storm: the state between two attempts of _step_impl
                         const double2 *r = reinterpret_cast<const double2 *>(a.park_in + (size_t)item * kParkRec);
                         const double2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7];
-                        t = r0.x; h = r0.y; t_new = r1.x; ha = r1.y; g = r2.x;
-                        y[0] = r2.y; y[1] = r3.x; y[2] = r3.y; y[3] = r4.x;
-                        f[0] = r4.y; f[1] = r5.x; f[2] = r5.y; f[3] = r6.x;
+                        t = r0.x; h = r0.y; t_new = r1.x; ha = r1.y; g = (R)r2.x;
+                        y[0] = (R)r2.y; y[1] = (R)r3.x; y[2] = (R)r3.y; y[3] = (R)r4.x;
+                        f[0] = (R)r4.y; f[1] = (R)r5.x; f[2] = (R)r5.y; f[3] = (R)r6.x;
                         sid = __double_as_longlong(r6.y);
                         const long long c0 = __double_as_longlong(r7.x), c1 = __double_as_longlong(r7.y);
                         nfev = (int)(c0 & 0xffffffffll); nacc = (int)(c0 >> 32);
@@ -347,16 +377,17 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
                         // stage-2 input exactly as attempt_setup left it
                         for (int i = 0; i < 4; ++i) {
                             KS(0, i) = f[i];
-                            const double dy = 0.0 + f[i] * A10;
-                            e[1 + i] = y[i] + dy * h;
+                            const R dy = R(0.0) + f[i] * R(A10);
+                            e[i] = y[i] + dy * (R)h;
                         }
-                        e[0] = t + RK_C[1] * h;
+                        et = t + RK_C[1] * h;
                         fresh = false;
                     }
-                    S = D.slots[a.slot[sid]];
+                    const DevSlot S = D.slots[a.slot[sid]];
+                    wind = slot_wind<R>(S); thermo = slot_thermo<R>(S);
                     fs = a.fs + sid * ns * 4;
-                    srec = a.srec + sid * (long long)a.max_rk_steps * kStepRec;
-                    h_bl = a.h_bl[sid];
+                    srec = a.srec + sid * (long long)a.max_rk_steps * REC;
+                    h_bl = (R)a.h_bl[sid];
                     active = true;
                     cache_reset(CC);
                 }
@@ -374,9 +405,10 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
                 double2 *o = reinterpret_cast<double2 *>(a.park_out + item * kParkRec);
                 const long long c0 = (long long)(unsigned)nfev | ((long long)nacc << 32);
                 const long long c1 = (long long)(unsigned)nrej | ((long long)(rejected ? 1 : 0) << 31) | ((long long)next_out << 32);
-                o[0] = make_double2(t, h); o[1] = make_double2(t_new, ha); o[2] = make_double2(g, y[0]);
-                o[3] = make_double2(y[1], y[2]); o[4] = make_double2(y[3], f[0]); o[5] = make_double2(f[1], f[2]);
-                o[6] = make_double2(f[3], __longlong_as_double(sid));
+                o[0] = make_double2(t, h); o[1] = make_double2(t_new, ha); o[2] = make_double2((double)g, (double)y[0]);
+                o[3] = make_double2((double)y[1], (double)y[2]); o[4] = make_double2((double)y[3], (double)f[0]);
+                o[5] = make_double2((double)f[1], (double)f[2]);
+                o[6] = make_double2((double)f[3], __longlong_as_double(sid));
                 o[7] = make_double2(__longlong_as_double(c0), __longlong_as_double(c1));
             }
             break;
@@ -388,15 +420,15 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
 #pragma unroll 1
         for (int slot = 0; slot < 6; ++slot) {
             const bool live = active && !(fresh && slot >= 2);
-            Rhs r{};
+            RhsT<R> r{};
 #ifdef TCR_OPAQUE_K
             int koff = 0;
             asm volatile("" : "+s"(koff));      // opaque per iteration: the ~100 EvalK constants stay in LDS instead of being hoisted into registers
-            const EvalK &Kq = *reinterpret_cast<const EvalK *>(reinterpret_cast<const char *>(&K) + koff);
+            const EvalKT<R> &Kq = *reinterpret_cast<const EvalKT<R> *>(reinterpret_cast<const char *>(&K) + koff);
 #else
-            const EvalK &Kq = K;
+            const EvalKT<R> &Kq = K;
 #endif
-            if (live) r = rhs_eval_cached<AFFINE>(CC, Kq, S, fs, h_bl, e[0], e[1], e[2], e[3], e[4]);
+            if (live) r = rhs_eval_cached<R, AFFINE>(CC, Kq, wind, thermo, fs, h_bl, et, e[0], e[1], e[2], e[3]);
             if (PROBE && live) {
                 const int ev = fresh ? slot : nfev;          // index of this evaluation in the storm's call order
                 if (ev < a.probe_cap) a.probe[(size_t)sid * a.probe_cap + ev] = (uint8_t)r.dec;
@@ -408,28 +440,28 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
                 for (int i = 0; i < 4; ++i) KS(st, i) = r.d[i];
                 if (slot < 5) {
                     for (int i = 0; i < 4; ++i) {
-                        double dy = 0.0;
+                        R dy = R(0.0);
                         switch (slot) {
-                        case 0: dy += KS(0, i) * A20; dy += KS(1, i) * A21; break;
-                        case 1: dy += KS(0, i) * A30; dy += KS(1, i) * A31; dy += KS(2, i) * A32; break;
-                        case 2: dy += KS(0, i) * A40; dy += KS(1, i) * A41; dy += KS(2, i) * A42; dy += KS(3, i) * A43; break;
-                        case 3: dy += KS(0, i) * A50; dy += KS(1, i) * A51; dy += KS(2, i) * A52; dy += KS(3, i) * A53;
-                                dy += KS(4, i) * A54; break;
+                        case 0: dy += KS(0, i) * R(A20); dy += KS(1, i) * R(A21); break;
+                        case 1: dy += KS(0, i) * R(A30); dy += KS(1, i) * R(A31); dy += KS(2, i) * R(A32); break;
+                        case 2: dy += KS(0, i) * R(A40); dy += KS(1, i) * R(A41); dy += KS(2, i) * R(A42); dy += KS(3, i) * R(A43); break;
+                        case 3: dy += KS(0, i) * R(A50); dy += KS(1, i) * R(A51); dy += KS(2, i) * R(A52); dy += KS(3, i) * R(A53);
+                                dy += KS(4, i) * R(A54); break;
                         default:
-                            for (int j = 0; j < 6; ++j) dy += KS(j, i) * RK_B[j];
+                            for (int j = 0; j < 6; ++j) dy += KS(j, i) * R(RK_B[j]);
                             break;
                         }
-                        if (slot < 4) e[1 + i] = y[i] + dy * h;
-                        else { e[1 + i] = y[i] + h * dy; yn[i] = e[1 + i]; }     // y_new (rk.py:68)
+                        if (slot < 4) e[i] = y[i] + dy * (R)h;
+                        else { e[i] = y[i] + (R)h * dy; yn[i] = e[i]; }     // y_new (rk.py:68)
                     }
-                    e[0] = (slot < 4) ? t + RK_C[slot + 2] * h : t + h;
+                    et = (slot < 4) ? t + RK_C[slot + 2] * h : t + h;
                 } else {
-                    // f_new is in K[6]: error estimate and step-size control (rk.py:147-165)
+                    // f_new is in K[6]: error estimate and step-size control (rk.py:147-165), in fp64
                     double er[4];
                     for (int i = 0; i < 4; ++i) {
-                        const double sc = P.atol + fmax(fabs(y[i]), fabs(yn[i])) * P.rtol;
+                        const double sc = P.atol + fmax(fabs((double)y[i]), fabs((double)yn[i])) * P.rtol;
                         double acc = 0.0;
-                        for (int j = 0; j < 7; ++j) acc += KS(j, i) * RK_E[j];
+                        for (int j = 0; j < 7; ++j) acc += (double)KS(j, i) * RK_E[j];
                         er[i] = (acc * h) / sc;
                     }
                     const double err = rms4(er[0], er[1], er[2], er[3]);
@@ -438,16 +470,18 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
                         double fac = (err == 0) ? 10.0 : fmin(10.0, pw);
                         if (rejected && fac > 1) fac = 1;
                         ha *= fac;
-                        // step record for k_emit: t_old, h, t_new, -, y_old[4], K[7][4]
+                        // step record for k_emit: doubles t_old, h, t_new, -; then R y_old[4], K[7][4]
                         if (nacc < a.max_rk_steps) {
-                            double2 *o = reinterpret_cast<double2 *>(srec + (size_t)nacc * kStepRec);
+                            double *rec = srec + (size_t)nacc * REC;
+                            double2 *o = reinterpret_cast<double2 *>(rec);
                             o[0] = make_double2(t, h);
                             o[1] = make_double2(t_new, 0.0);
-                            o[2] = make_double2(y[0], y[1]);
-                            o[3] = make_double2(y[2], y[3]);
+                            V4 *body = reinterpret_cast<V4 *>(rec + kStepHdr);
+                            V4 v; v[0] = y[0]; v[1] = y[1]; v[2] = y[2]; v[3] = y[3];
+                            body[0] = v;
                             for (int j = 0; j < 7; ++j) {
-                                o[4 + 2 * j] = make_double2(KS(j, 0), KS(j, 1));
-                                o[5 + 2 * j] = make_double2(KS(j, 2), KS(j, 3));
+                                V4 kk; kk[0] = KS(j, 0); kk[1] = KS(j, 1); kk[2] = KS(j, 2); kk[3] = KS(j, 3);
+                                body[1 + j] = kk;
                             }
                         }
                         ++nacc;
@@ -458,10 +492,10 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
                         if (t - tb >= 0) status = TCR_STATUS_FINISHED;
                         // terminal event at the step end (ivp.py:673-693); g >= 0 always, so a trigger
                         // is g_new == 0 (root = step end) or g0 == 0 on the first step (root = t0)
-                        const double g_new = event_fn(P, y[0], y[1], y[2]);
+                        const R g_new = event_fn<R>(P, y[0], y[1], y[2]);
                         double t_emit = t;
-                        if (g == 0.0) { status = TCR_STATUS_EVENT; t_emit = t_old; }
-                        else if (g_new == 0.0) status = TCR_STATUS_EVENT;
+                        if (g == R(0.0)) { status = TCR_STATUS_EVENT; t_emit = t_old; }
+                        else if (g_new == R(0.0)) status = TCR_STATUS_EVENT;
                         g = g_new;
                         next_out = samples_upto(P, t_emit);         // t_eval emission count (ivp.py:706-723)
                         if (status == kRunning && nacc >= a.max_rk_steps) status = TCR_STATUS_STEP_OVERFLOW;
@@ -477,20 +511,20 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
             } else if (live && slot == 0) {
                 // fresh storm, fun(t0, y0): ventilation gate (coupled_fast.py:238-244) on the same
                 // lookups, then RungeKutta.__init__'s f0 and select_initial_step part 1 (common.py:112-126)
-                if (r.vpot > 0 && r.shear * r.chi / r.vpot >= 1) {
+                if (r.vpot > R(0) && r.shear * r.chi / r.vpot >= R(1)) {
                     status = TCR_STATUS_GATED;
                     finalize();
                     fresh = false;
                 } else {
                     nfev = 1;
                     double sc[4];
-                    for (int i = 0; i < 4; ++i) { f[i] = r.d[i]; sc[i] = P.atol + fabs(y[i]) * P.rtol; }
-                    const double d0 = rms4(y[0] / sc[0], y[1] / sc[1], y[2] / sc[2], y[3] / sc[3]);
-                    const double d1 = rms4(f[0] / sc[0], f[1] / sc[1], f[2] / sc[2], f[3] / sc[3]);
+                    for (int i = 0; i < 4; ++i) { f[i] = r.d[i]; sc[i] = P.atol + fabs((double)y[i]) * P.rtol; }
+                    const double d0 = rms4((double)y[0] / sc[0], (double)y[1] / sc[1], (double)y[2] / sc[2], (double)y[3] / sc[3]);
+                    const double d1 = rms4((double)f[0] / sc[0], (double)f[1] / sc[1], (double)f[2] / sc[2], (double)f[3] / sc[3]);
                     double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
                     h0 = h0 < tb ? h0 : tb;
-                    for (int i = 0; i < 4; ++i) e[1 + i] = y[i] + h0 * 1.0 * f[i];
-                    e[0] = t + h0 * 1.0;
+                    for (int i = 0; i < 4; ++i) e[i] = y[i] + (R)h0 * R(1.0) * f[i];
+                    et = t + h0 * 1.0;
                     h = h0;
                 }
             } else if (live && slot == 1) {
@@ -498,15 +532,15 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
                 ++nfev;
                 const double h0 = h;
                 double sc[4];
-                for (int i = 0; i < 4; ++i) sc[i] = P.atol + fabs(y[i]) * P.rtol;
-                const double d1 = rms4(f[0] / sc[0], f[1] / sc[1], f[2] / sc[2], f[3] / sc[3]);
-                const double d2 = rms4((r.d[0] - f[0]) / sc[0], (r.d[1] - f[1]) / sc[1],
-                                       (r.d[2] - f[2]) / sc[2], (r.d[3] - f[3]) / sc[3]) / h0;
+                for (int i = 0; i < 4; ++i) sc[i] = P.atol + fabs((double)y[i]) * P.rtol;
+                const double d1 = rms4((double)f[0] / sc[0], (double)f[1] / sc[1], (double)f[2] / sc[2], (double)f[3] / sc[3]);
+                const double d2 = rms4((double)(r.d[0] - f[0]) / sc[0], (double)(r.d[1] - f[1]) / sc[1],
+                                       (double)(r.d[2] - f[2]) / sc[2], (double)(r.d[3] - f[3]) / sc[3]) / h0;
                 double h1;
                 if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
                 else h1 = pow(0.01 / fmax(d1, d2), 0.2);
                 h_abs = fmin(fmin(100 * h0, h1), fmin(tb, P.max_step));
-                g = event_fn(P, y[0], y[1], y[2]);
+                g = event_fn<R>(P, y[0], y[1], y[2]);
                 begin_step();
             }
         }
@@ -534,26 +568,28 @@ __global__ __launch_bounds__(kWave, TCR_INT_WPS) void k_integrate(KArgs a)
 //            with util/sphere.py:15-30,58-83), NaN padding of the reference's [n_tracks][n_steps]
 //            planes (compute.py:124-133), "any v >= 15" / "any vmax >= threshold" bits;
 //   k_flags  thread per storm: accept tests 1 and 2 (compute.py:185-189, 205).
-struct EArgs {
+template <typename R>
+struct EArgsT {
     tcr_params P;
     DevFields D;
     int64_t n;
     const int64_t *n_dev;        // optional device scalar: only the first min(n, *n_dev) storms exist; flags of the rest are set to 0
     int max_rk_steps;
-    const double *srec;          // [n][max_rk_steps][kStepRec]
-    const double *fs;            // [n][n_steps][4]
+    const double *srec;          // [n][max_rk_steps][step_rec_doubles<R>()]
+    const R *fs;                 // [n][n_steps][4]
     const int32_t *slot;
     const int32_t *n_valid, *status, *n_accept;
-    double *lon, *lat, *v, *m, *vmax, *envw;
+    R *lon, *lat, *v, *m, *vmax, *envw;
     int32_t *flags;
     const int32_t *pad_state;    // rows are already NaN from this sample on (NULL / <0: unknown), see tcrisk_hip.h
     // TC-rows-only mode (tcr_tracks.tc_rows_only): the kernels run over list[0 .. *count) — the storms k_screen
     // found to pass accept test 1 — instead of over every storm of the batch (list == NULL)
     const int32_t *list;
     const int64_t *count;
-    EvalK K;                     // built on the host; k_emit's small workgroups copy it to LDS with one load per lane
+    EvalKT<R> K;                 // built on the host; k_emit's small workgroups copy it to LDS
 };
-static_assert(sizeof(EvalK) % 8 == 0, "EvalK is copied to LDS in eight-byte words");
+using EArgs = EArgsT<double>;
+static_assert(sizeof(EvalKT<double>) % 8 == 0 && sizeof(EvalKT<float>) % 8 == 0, "EvalK is copied to LDS in eight-byte words");
 constexpr int kBitAny15 = 1 << 8, kBitVmax = 1 << 9;     // scratch bits in flags[] between the kernels
 #ifndef TCR_POST_THREADS
 #define TCR_POST_THREADS 128
@@ -564,11 +600,16 @@ constexpr int kEmitSlotCache = 32;      // field-slot wind pointers kept in LDS 
 #define TCR_EMIT_WPS 3     // waves per SIMD k_emit is register-budgeted for (<= 168 VGPRs)
 #endif
 
+// body of an accepted-step record: R y_old[4], then K[7][4] (k_integrate) / Q[4][4] in its place (k_dense)
+template <typename R>
+__device__ __forceinline__ const R *rec_body(const double *rec) { return reinterpret_cast<const R *>(rec + kStepHdr); }
+
 // k_dense: one wave per storm, lane = (accepted step j, state component c).  Replaces the seven
 // stage derivatives K[q][c] of the step record by row c of the dense-output matrix
 // Q = K^T P (rk.py:179-181) — in place: every lane has loaded its K column before any lane
 // stores (one wave, lock step) — and tells every hourly sample which step it belongs to.
-__global__ __launch_bounds__(kWave) void k_dense(EArgs a, uint16_t *__restrict__ sidx)
+template <typename R>
+__global__ __launch_bounds__(kWave) void k_dense(EArgsT<R> a, uint16_t *__restrict__ sidx)
 {
     const tcr_params &P = a.P;
     if (a.list && (int64_t)blockIdx.x >= *a.count) return;
@@ -582,25 +623,27 @@ __global__ __launch_bounds__(kWave) void k_dense(EArgs a, uint16_t *__restrict__
     int nst = a.n_accept[sid];
     nst = nst < a.max_rk_steps ? nst : a.max_rk_steps;
     if (threadIdx.x == 0) a.flags[sid] = 0;
+    constexpr int REC = step_rec_doubles<R>();
+    typedef typename VecT<R, 4>::type V4;
     const int c = threadIdx.x & 3;
     for (int j0 = 0; j0 < nst; j0 += kWave / 4) {
         const int j = j0 + (threadIdx.x >> 2);
         const bool on = j < nst;
-        double *rj = const_cast<double *>(a.srec) + (sid * (int64_t)a.max_rk_steps + (on ? j : 0)) * kStepRec;
-        double kq[7];
-        for (int q = 0; q < 7; ++q) kq[q] = rj[8 + q * 4 + c];
+        double *rj = const_cast<double *>(a.srec) + (sid * (int64_t)a.max_rk_steps + (on ? j : 0)) * REC;
+        R *body = reinterpret_cast<R *>(rj + kStepHdr);
+        R kq[7];
+        for (int q = 0; q < 7; ++q) kq[q] = body[4 + q * 4 + c];
         const double t_old = rj[0], t_new = rj[2];
-        double Q[4];
+        R Q[4];
         for (int k = 0; k < 4; ++k) {
-            double acc = 0.0;
-            for (int q = 0; q < 7; ++q) acc += kq[q] * RK_P[q][k];
+            R acc = R(0.0);
+            for (int q = 0; q < 7; ++q) acc += kq[q] * R(RK_P[q][k]);
             Q[k] = acc;
         }
         // (all loads of the wave are complete here: Q depends on them)
         if (on) {
-            double2 *o = reinterpret_cast<double2 *>(rj + 8 + c * 4);
-            o[0] = make_double2(Q[0], Q[1]);
-            o[1] = make_double2(Q[2], Q[3]);
+            V4 qv; qv[0] = Q[0]; qv[1] = Q[1]; qv[2] = Q[2]; qv[3] = Q[3];
+            *reinterpret_cast<V4 *>(body + 4 + c * 4) = qv;
             if (c == 0) {
                 // samples of this step: t_old < ts <= t_new (the first step also owns ts = 0)
                 const int i_lo = (j == 0) ? 0 : samples_upto(P, t_old);
@@ -616,22 +659,24 @@ __global__ __launch_bounds__(kWave) void k_dense(EArgs a, uint16_t *__restrict__
 // either equal latitudes or equal longitudes.  The vanishing term is sin(0)^2 = 0 (same
 // latitude) or cos(lat1)*cos(lat2)*sin(0)^2 = +-0 (same longitude, latitudes finite), and
 // x + (+-0) = x for x >= 0, so dropping it — and with it two cosines — is bit-identical.
-__device__ __forceinline__ double haversine_same_lat_km(const tcr_params &P, double lon1, double lon2, double lat)
+template <typename R>
+__device__ __forceinline__ R haversine_same_lat_km(const tcr_params &P, R lon1, R lon2, R lat)
 {
-    const double d = kPi / 180.0;
+    const R d = R(kPi / 180.0);
     lon1 *= d; lon2 *= d; lat *= d;
-    const double sb = sin((lon2 - lon1) / 2), c = cos(lat);
-    const double aa = 0.0 + c * c * (sb * sb);
-    return (P.earth_R / 1000.) * (2 * asin(sqrt(aa)));
+    const R sb = sin((lon2 - lon1) / R(2)), c = cos(lat);
+    const R aa = R(0.0) + c * c * (sb * sb);
+    return R(P.earth_R / 1000.) * (R(2) * asin(sqrt(aa)));
 }
 
-__device__ __forceinline__ double haversine_same_lon_km(const tcr_params &P, double lat1, double lat2)
+template <typename R>
+__device__ __forceinline__ R haversine_same_lon_km(const tcr_params &P, R lat1, R lat2)
 {
-    const double d = kPi / 180.0;
+    const R d = R(kPi / 180.0);
     lat1 *= d; lat2 *= d;
-    const double sa = sin((lat2 - lat1) / 2);
-    const double aa = sa * sa;
-    return (P.earth_R / 1000.) * (2 * asin(sqrt(aa)));
+    const R sa = sin((lat2 - lat1) / R(2));
+    const R aa = sa * sa;
+    return R(P.earth_R / 1000.) * (R(2) * asin(sqrt(aa)));
 }
 
 // axi_to_max_wind (wind/tc_wind.py:6-21) for one sample, given its neighbours along the track.
@@ -639,41 +684,43 @@ __device__ __forceinline__ double haversine_same_lon_km(const tcr_params &P, dou
 // ug = v*(-sin th) + Ui*fac, vg = v*cos th + Vi*fac.  -sin(th) = Ui/|U| and cos(th) = Vi/|U| with
 // |U| = sqrt(Ui^2 + Vi^2), which the function has just computed, so the three transcendental calls
 // reduce to two divisions (|U| = 0: th = -0, i.e. (0, 1)); differs from libm's round trip by ~1 ulp.
-__device__ __forceinline__ double vmax_at(const tcr_params &P, double lon, double lat, double v, double us, double vs,
-                                          double lom, double lam, double lop, double lap)
+template <typename R>
+__device__ __forceinline__ R vmax_at(const tcr_params &P, R lon, R lat, R v, R us, R vs, R lom, R lam, R lop, R lap)
 {
-    const double dlon = 0.5 * (sign_of(lop - lom) * haversine_same_lat_km(P, lop, lom, lat));
-    const double dlat = 0.5 * (sign_of(lap - lam) * haversine_same_lon_km(P, lap, lam));
-    const double ut = dlon * 1000. / P.dt_out, vt = dlat * 1000. / P.dt_out;
-    const double G = fmin(1., 0.8 + 0.35 * (1. + tanh((lat - 35.) / 10.)));
-    const double Ui = G * ut + 0.1 * us * v / 15.;
-    const double Vi = G * vt + 0.1 * vs * v / 15.;
-    const double mag = sqrt(Ui * Ui + Vi * Vi);
-    const double fac = np_min((v * 0.50) / mag, 1.0);
-    const double msin = (mag == 0.0) ? 0.0 : Ui / mag;      // -sin(arctan2(-Ui, Vi))
-    const double mcos = (mag == 0.0) ? 1.0 : Vi / mag;      //  cos(arctan2(-Ui, Vi))
-    const double ug = v * msin + Ui * fac;
-    const double vg = v * mcos + Vi * fac;
+    const R dlon = R(0.5) * (sign_of(lop - lom) * haversine_same_lat_km<R>(P, lop, lom, lat));
+    const R dlat = R(0.5) * (sign_of(lap - lam) * haversine_same_lon_km<R>(P, lap, lam));
+    const R ut = dlon * R(1000.) / (R)P.dt_out, vt = dlat * R(1000.) / (R)P.dt_out;
+    const R G = fmin(R(1.), R(0.8) + R(0.35) * (R(1.) + tanh((lat - R(35.)) / R(10.))));
+    const R Ui = G * ut + R(0.1) * us * v / R(15.);
+    const R Vi = G * vt + R(0.1) * vs * v / R(15.);
+    const R mag = sqrt(Ui * Ui + Vi * Vi);
+    const R fac = np_min((v * R(0.50)) / mag, R(1.0));
+    const R msin = (mag == R(0.0)) ? R(0.0) : Ui / mag;      // -sin(arctan2(-Ui, Vi))
+    const R mcos = (mag == R(0.0)) ? R(1.0) : Vi / mag;      //  cos(arctan2(-Ui, Vi))
+    const R ug = v * msin + Ui * fac;
+    const R vg = v * mcos + Vi * fac;
     return sqrt(ug * ug + vg * vg);
 }
 
 // Dense output of a sample at time te inside accepted step `step` of a storm (rk.py:552-574):
-// y = y_old + h * Q . (x, x^2, x^3, x^4).
-template <int NC>
-__device__ __forceinline__ void dense_at(const double *__restrict__ srec_storm, int step, double te, double (&ye)[NC])
+// y = y_old + h * Q . (x, x^2, x^3, x^4).  x is formed in fp64 (times are fp64) and rounded to R.
+template <typename R, int NC>
+__device__ __forceinline__ void dense_at(const double *__restrict__ srec_storm, int step, double te, R (&ye)[NC])
 {
-    const double2 *s2 = reinterpret_cast<const double2 *>(srec_storm + (size_t)step * kStepRec);
-    const double2 h0 = s2[0];
-    const double hh = h0.y;
-    const double x = (te - h0.x) / hh;
-    const double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
+    typedef typename VecT<R, 4>::type V4;
+    const double *rec = srec_storm + (size_t)step * step_rec_doubles<R>();
+    const double2 h0 = *reinterpret_cast<const double2 *>(rec);
+    const V4 *body = reinterpret_cast<const V4 *>(rec + kStepHdr);
+    const R hh = (R)h0.y;
+    const R x = (R)((te - h0.x) / h0.y);
+    const R p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
+    const V4 y0 = body[0];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const double2 qa = s2[4 + 2 * c], qb = s2[5 + 2 * c];
-        const double y0 = (c & 1) ? s2[2 + (c >> 1)].y : s2[2 + (c >> 1)].x;
-        double acc = 0.0;
-        acc += qa.x * p1; acc += qa.y * p2; acc += qb.x * p3; acc += qb.y * p4;
-        ye[c] = hh * acc + y0;
+        const V4 q = body[1 + c];
+        R acc = R(0.0);
+        acc += q[0] * p1; acc += q[1] * p2; acc += q[2] * p3; acc += q[3] * p4;
+        ye[c] = hh * acc + y0[c];
     }
 }
 
@@ -682,11 +729,11 @@ __device__ __forceinline__ void dense_at(const double *__restrict__ srec_storm, 
 // outside neighbour themselves), planes written; the rest of the row is NaN padding.  The gathers
 // make this kernel wait on memory ~60 % of the time, so the transcendental-heavy vmax math of
 // the same sample runs in its shadow (as a kernel of its own it cost 0.34 ms per 100k storms).
-template <bool AFFINE>
-__global__ __launch_bounds__(kPostThreads, TCR_EMIT_WPS) void k_emit(EArgs a, const uint16_t *__restrict__ sidx)
+template <typename R, bool AFFINE>
+__global__ __launch_bounds__(kPostThreads, TCR_EMIT_WPS) void k_emit(EArgsT<R> a, const uint16_t *__restrict__ sidx)
 {
-    __shared__ EvalK K;
-    __shared__ const double *s_wind[kEmitSlotCache];
+    __shared__ EvalKT<R> K;
+    __shared__ const R *s_wind[kEmitSlotCache];
     const tcr_params &P = a.P;
     if (a.list && (int64_t)blockIdx.x >= *a.count) return;            // uniform per workgroup
     if (!a.list && (int64_t)blockIdx.x >= n_eff(a.n, a.n_dev)) return;
@@ -699,72 +746,70 @@ __global__ __launch_bounds__(kPostThreads, TCR_EMIT_WPS) void k_emit(EArgs a, co
     const uint16_t *sidx_storm = sidx + (size_t)sid * ns;
     const int my_step = (i < ns) ? sidx_storm[i] : 0;          // meaningful only if i < n
     const size_t o = (size_t)sid * ns + i;
-    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    const R nan = (R)__longlong_as_double(0x7ff8000000000000LL);
     const bool live_block = (int)(blockIdx.y * kPostThreads) < n;
     if (live_block) {
-        for (unsigned w = threadIdx.x; w < sizeof(EvalK) / 8; w += kPostThreads)       // any workgroup size (69 words)
+        for (unsigned w = threadIdx.x; w < sizeof(EvalKT<R>) / 8; w += kPostThreads)       // any workgroup size
             reinterpret_cast<uint64_t *>(&K)[w] = reinterpret_cast<const uint64_t *>(&a.K)[w];
-        if (threadIdx.x < kEmitSlotCache && (int)threadIdx.x < a.D.n_slots) s_wind[threadIdx.x] = a.D.slots[threadIdx.x].wind;
+        if (threadIdx.x < kEmitSlotCache && (int)threadIdx.x < a.D.n_slots) s_wind[threadIdx.x] = slot_wind<R>(a.D.slots[threadIdx.x]);
         __syncthreads();
     }
+    typedef typename VecT<R, 4>::type V4;
     const bool valid = i < n;
-    const double *srec_storm = a.srec + sid * (int64_t)a.max_rk_steps * kStepRec;
-    double ye[4] = {0, 0, 0, 0}, w[4] = {0, 0, 0, 0};
+    const double *srec_storm = a.srec + sid * (int64_t)a.max_rk_steps * step_rec_doubles<R>();
+    R ye[4] = {0, 0, 0, 0}, w[4] = {0, 0, 0, 0};
     if (valid) {
         const double te = ts_at(P, i);
-        dense_at<4>(srec_storm, my_step, te, ye);
-        DevSlot S{};
-        S.wind = (slot_id < kEmitSlotCache) ? s_wind[slot_id] : a.D.slots[slot_id].wind;
-        env_winds<AFFINE>(K, S, a.fs + sid * ns * 4, ye[0], ye[1], te, w);
+        dense_at<R, 4>(srec_storm, my_step, te, ye);
+        const R *wind = (slot_id < kEmitSlotCache) ? s_wind[slot_id] : slot_wind<R>(a.D.slots[slot_id]);
+        env_winds<R, AFFINE>(K, wind, a.fs + sid * ns * 4, ye[0], ye[1], te, w);
         a.lon[o] = ye[0]; a.lat[o] = ye[1]; a.v[o] = ye[2]; a.m[o] = ye[3];
-        double2 *eo = reinterpret_cast<double2 *>(a.envw + o * 4);
-        eo[0] = make_double2(w[0], w[1]);
-        eo[1] = make_double2(w[2], w[3]);
+        V4 wv; wv[0] = w[0]; wv[1] = w[1]; wv[2] = w[2]; wv[3] = w[3];
+        *reinterpret_cast<V4 *>(a.envw + o * 4) = wv;
     }
     // neighbours along the track: lanes +-1, except across the wave's edges
     const int lane = threadIdx.x & 63;
-    double lom = __shfl_up(ye[0], 1), lam = __shfl_up(ye[1], 1);
-    double lop = __shfl_down(ye[0], 1), lap = __shfl_down(ye[1], 1);
+    R lom = __shfl_up(ye[0], 1), lam = __shfl_up(ye[1], 1);
+    R lop = __shfl_down(ye[0], 1), lap = __shfl_down(ye[1], 1);
     if (valid && n > 1) {
         if (lane == 0 && i > 0) {
-            double q[2];
-            dense_at<2>(srec_storm, sidx_storm[i - 1], ts_at(P, i - 1), q);
+            R q[2];
+            dense_at<R, 2>(srec_storm, sidx_storm[i - 1], ts_at(P, i - 1), q);
             lom = q[0]; lam = q[1];
         }
         if (lane == 63 && i < n - 1) {
-            double q[2];
-            dense_at<2>(srec_storm, sidx_storm[i + 1], ts_at(P, i + 1), q);
+            R q[2];
+            dense_at<R, 2>(srec_storm, sidx_storm[i + 1], ts_at(P, i + 1), q);
             lop = q[0]; lap = q[1];
         }
         // linear extrapolation at both ends (sphere.py:66-69): the neighbour on the other side is
         // sample 1 / n-2, i.e. lop / lom of this very lane
-        const double lop_in = lop, lap_in = lap, lom_in = lom, lam_in = lam;
-        if (i == 0) { lom = 2 * ye[0] - lop_in; lam = 2 * ye[1] - lap_in; }
-        if (i == n - 1) { lop = 2 * ye[0] - lom_in; lap = 2 * ye[1] - lam_in; }
-        const double vm = vmax_at(P, ye[0], ye[1], ye[2], w[0] - w[2], w[1] - w[3], lom, lam, lop, lap);
+        const R lop_in = lop, lap_in = lap, lom_in = lom, lam_in = lam;
+        if (i == 0) { lom = R(2) * ye[0] - lop_in; lam = R(2) * ye[1] - lap_in; }
+        if (i == n - 1) { lop = R(2) * ye[0] - lom_in; lap = R(2) * ye[1] - lam_in; }
+        const R vm = vmax_at<R>(P, ye[0], ye[1], ye[2], w[0] - w[2], w[1] - w[3], lom, lam, lop, lap);
         a.vmax[o] = vm;
-        const bool hit_v = ye[2] >= P.v_thresh, hit_vm = vm >= P.vmax_thresh;
+        const bool hit_v = ye[2] >= (R)P.v_thresh, hit_vm = vm >= (R)P.vmax_thresh;
         const int bits = (__ballot(hit_v) ? kBitAny15 : 0) | (__ballot(hit_vm) ? kBitVmax : 0);
         if (bits && lane == (__ffsll((long long)__ballot(true)) - 1)) atomicOr(a.flags + sid, bits);
     } else if (valid) {                                   // n == 1: no translation speed, vmax stays NaN
         a.vmax[o] = nan;
-        if (ye[2] >= P.v_thresh) atomicOr(a.flags + sid, kBitAny15);
+        if (ye[2] >= (R)P.v_thresh) atomicOr(a.flags + sid, kBitAny15);
     } else {
         // NaN padding, only where the row is not known to be padded already
         int pad_to = a.pad_state ? a.pad_state[sid] : ns;
         pad_to = (pad_to < 0 || pad_to > ns) ? ns : pad_to;
         if (i < pad_to) {
             a.lon[o] = nan; a.lat[o] = nan; a.v[o] = nan; a.m[o] = nan; a.vmax[o] = nan;
-            double2 *eo = reinterpret_cast<double2 *>(a.envw + o * 4);
-            eo[0] = make_double2(nan, nan);
-            eo[1] = make_double2(nan, nan);
+            V4 nv; nv[0] = nan; nv[1] = nan; nv[2] = nan; nv[3] = nan;
+            *reinterpret_cast<V4 *>(a.envw + o * 4) = nv;
         }
     }
 }
 
 // k_screen: accept test 1 (util/compute.py:185-189) without producing a single row.  The reference
 // recomputes env winds, computes vmax and writes rows only for candidates that pass this test
-// (compute.py:190-204) — ~10 % of the integrated storms — and it needs only the hourly v series:
+// (compute.py:190-204) — ~6 % of the integrated storms — and it needs only the hourly v series:
 // `any(v >= 15)` and `np.interp(2 d, res.t, v) >= 6.5`.  So: 16 lanes per storm, lane = accepted step;
 // a lane forms row 2 (v) of its step's dense-output matrix Q = K^T P (rk.py:179-181) and walks the
 // hourly samples of its step (ivp.py:706-723).  The arithmetic is k_dense's and dense_at's, operation
@@ -774,9 +819,10 @@ constexpr int kScreenThreads = 256;
 constexpr int kScreenGroup = 16;                                   // lanes per storm
 constexpr int kScreenStorms = kScreenThreads / kScreenGroup;       // storms per workgroup
 
-__global__ __launch_bounds__(kScreenThreads) void k_screen(EArgs a)
+template <typename R>
+__global__ __launch_bounds__(kScreenThreads) void k_screen(EArgsT<R> a)
 {
-    __shared__ double cap[kScreenStorms][3];      // v at sample j2d, j2d + 1, n - 1
+    __shared__ R cap[kScreenStorms][3];      // v at sample j2d, j2d + 1, n - 1
     const tcr_params &P = a.P;
     const int g = threadIdx.x / kScreenGroup, l = threadIdx.x % kScreenGroup;
     const int64_t sid = (int64_t)blockIdx.x * kScreenStorms + g;
@@ -794,16 +840,19 @@ __global__ __launch_bounds__(kScreenThreads) void k_screen(EArgs a)
     const bool clamp2d = n > 0 && t2d >= ts_at(P, n - 1);
     const int j2d = clamp2d ? n - 1 : (int)floor(t2d / step_out);
     bool any15 = false;
-    const double *srec_storm = a.srec + sid * (int64_t)a.max_rk_steps * kStepRec;
+    constexpr int REC = step_rec_doubles<R>();
+    const double *srec_storm = a.srec + sid * (int64_t)a.max_rk_steps * REC;
     for (int j = l; j < nst && n > 0; j += kScreenGroup) {
-        const double *rj = srec_storm + (size_t)j * kStepRec;
-        const double t_old = rj[0], hh = rj[1], t_new = rj[2], y0 = rj[6];
-        double kq[7];
-        for (int q = 0; q < 7; ++q) kq[q] = rj[8 + q * 4 + 2];
-        double Q[4];
+        const double *rj = srec_storm + (size_t)j * REC;
+        const R *body = rec_body<R>(rj);
+        const double t_old = rj[0], h64 = rj[1], t_new = rj[2];
+        const R hh = (R)h64, y0 = body[2];
+        R kq[7];
+        for (int q = 0; q < 7; ++q) kq[q] = body[4 + q * 4 + 2];
+        R Q[4];
         for (int k = 0; k < 4; ++k) {
-            double acc = 0.0;
-            for (int q = 0; q < 7; ++q) acc += kq[q] * RK_P[q][k];
+            R acc = R(0.0);
+            for (int q = 0; q < 7; ++q) acc += kq[q] * R(RK_P[q][k]);
             Q[k] = acc;
         }
         const int i_lo = (j == 0) ? 0 : samples_upto(P, t_old);
@@ -811,12 +860,12 @@ __global__ __launch_bounds__(kScreenThreads) void k_screen(EArgs a)
         i_hi = i_hi < n ? i_hi : n;
         for (int i = i_lo; i < i_hi; ++i) {
             const double te = ts_at(P, i);
-            const double x = (te - t_old) / hh;
-            const double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
-            double acc = 0.0;
+            const R x = (R)((te - t_old) / h64);
+            const R p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
+            R acc = R(0.0);
             acc += Q[0] * p1; acc += Q[1] * p2; acc += Q[2] * p3; acc += Q[3] * p4;
-            const double v = hh * acc + y0;
-            any15 = any15 || (v >= P.v_thresh);
+            const R v = hh * acc + y0;
+            any15 = any15 || (v >= (R)P.v_thresh);
             if (i == j2d) cap[g][0] = v;
             if (i == j2d + 1) cap[g][1] = v;
             if (i == n - 1) cap[g][2] = v;
@@ -830,16 +879,17 @@ __global__ __launch_bounds__(kScreenThreads) void k_screen(EArgs a)
         int fl = 0;
         if (n > 0 && st != TCR_STATUS_GATED) {
             double v2d;
-            if (clamp2d) v2d = cap[g][2];
-            else v2d = (cap[g][1] - cap[g][0]) / (ts_at(P, j2d + 1) - ts_at(P, j2d)) * (t2d - ts_at(P, j2d)) + cap[g][0];
+            if (clamp2d) v2d = (double)cap[g][2];
+            else v2d = interp_v2d<R>(cap[g][0], cap[g][1], ts_at(P, j2d), ts_at(P, j2d + 1), t2d);
             if (any15 && v2d >= P.v_2d_thresh) fl = TCR_FLAG_IS_TC;
         }
         a.flags[sid] = fl;
     }
 }
 
+template <typename R>
 __global__ __launch_bounds__(256) void k_flags(tcr_params P, int64_t n_storms, const int32_t *__restrict__ n_valid,
-                                               const int32_t *__restrict__ status, const double *__restrict__ pv,
+                                               const int32_t *__restrict__ status, const R *__restrict__ pv,
                                                int32_t *__restrict__ flags, int32_t *__restrict__ pad_state,
                                                const int32_t *__restrict__ list, const int64_t *__restrict__ count,
                                                const int64_t *__restrict__ n_dev)
@@ -857,12 +907,12 @@ __global__ __launch_bounds__(256) void k_flags(tcr_params P, int64_t n_storms, c
         // np.interp(2 d, res.t, v) (compute.py:186-188)
         const double step_out = P.total_time / (double)(ns - 1);
         const double t2d = 2 * 86400.0;
-        const double *v = pv + (size_t)sid * ns;
+        const R *v = pv + (size_t)sid * ns;
         double v2d;
-        if (t2d >= ts_at(P, n - 1)) v2d = v[n - 1];
+        if (t2d >= ts_at(P, n - 1)) v2d = (double)v[n - 1];
         else {
             const int j = (int)floor(t2d / step_out);
-            v2d = (v[j + 1] - v[j]) / (ts_at(P, j + 1) - ts_at(P, j)) * (t2d - ts_at(P, j)) + v[j];
+            v2d = interp_v2d<R>(v[j], v[j + 1], ts_at(P, j), ts_at(P, j + 1), t2d);
         }
         if ((bits & kBitAny15) && v2d >= P.v_2d_thresh) {
             fl |= TCR_FLAG_IS_TC;
@@ -883,11 +933,11 @@ __global__ __launch_bounds__(64) void k_probe_rhs(tcr_params P, DevFields D, int
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const DevSlot S = D.slots[slot];
-    const Rhs r = rhs_eval<AFFINE>(K, S, fs, h_bl, t[i], lon[i], lat[i], v[i], m[i]);
+    const RhsT<double> r = rhs_eval<double, AFFINE>(K, S.wind, S.thermo, fs, h_bl, t[i], lon[i], lat[i], v[i], m[i]);
     for (int k = 0; k < 4; ++k) dydt[i * 4 + k] = r.d[k];
     alpha[i] = r.alpha;
     double w[4];
-    env_winds<AFFINE>(K, S, fs, lon[i], lat[i], t[i], w);
+    env_winds<double, AFFINE>(K, S.wind, fs, lon[i], lat[i], t[i], w);
     for (int k = 0; k < 4; ++k) envw[i * 4 + k] = w[k];
 }
 

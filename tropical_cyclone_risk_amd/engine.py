@@ -166,17 +166,20 @@ class TCEngine:
         return self
 
     # -------------------------------------------------------------- hot path
-    def integrate(self, storms, probe_cap=0):
+    def integrate(self, storms, probe_cap=0, dtype='f64'):
         """Integrate + post-process a batch given as host arrays (dict with lon, lat, v0,
         m0, h_bl, month (1..12), phases [n,4,N]); returns a dict of NumPy arrays.  probe_cap > 0 adds
-        'dec' [n, probe_cap] uint8, the per-evaluation `land == 1` decisions (tcr_integrate_probe_host)."""
+        'dec' [n, probe_cap] uint8, the per-evaluation `land == 1` decisions (tcr_integrate_probe_host).
+        dtype='f32': the fp32 variant (tcr_integrate_f32_host), rows come back as float32."""
         n = len(storms['lon'])
         ns = self.n_steps
         lon0, lat0, v0, m0, h_bl = (_f64(storms[k]) for k in ('lon', 'lat', 'v0', 'm0', 'h_bl'))
         slot = np.ascontiguousarray(np.asarray(storms['month']) - 1, dtype=np.int32)
         ph = _f64(storms['phases']).reshape(n, 4 * self.n_series)
-        out = {k: np.empty((n, ns)) for k in TRACK_F64}
-        out['envw'] = np.empty((n, ns, 4))
+        assert dtype in ('f64', 'f32') and not (probe_cap and dtype == 'f32')
+        rt = np.float64 if dtype == 'f64' else np.float32
+        out = {k: np.empty((n, ns), rt) for k in TRACK_F64}
+        out['envw'] = np.empty((n, ns, 4), rt)
         out.update({k: np.zeros(n, np.int32) for k in TRACK_I32})
         if n == 0:
             if probe_cap:
@@ -189,6 +192,8 @@ class TCEngine:
         if probe_cap:
             out['dec'] = np.full((n, int(probe_cap)), 0xff, np.uint8)
             self._ck(self.L.tcr_integrate_probe_host(self.h, C.byref(si), C.byref(so), out['dec'].ctypes.data, int(probe_cap)))
+        elif dtype == 'f32':
+            self._ck(self.L.tcr_integrate_f32_host(self.h, C.byref(si), C.byref(so)))
         else:
             self._ck(self.L.tcr_integrate_host(self.h, C.byref(si), C.byref(so)))
         return self._finish(out)

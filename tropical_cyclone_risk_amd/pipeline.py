@@ -20,7 +20,11 @@ I32 = torch.int32
 
 
 class DevicePipeline:
-    def __init__(self, engine, max_candidates, max_storms, device=None, sort_storms=False, tc_rows_only=False):
+    def __init__(self, engine, max_candidates, max_storms, device=None, sort_storms=False, tc_rows_only=False,
+                 dtype='f64'):
+        # dtype 'f32': the fp32 variant of the path (tcr_integrate_f32_dev): float32 rows; seeds stay fp64
+        assert dtype in ('f64', 'f32')
+        self.dtype = dtype
         # tc_rows_only: produce rows only for storms that pass accept test 1, as the reference does
         # (compute.py:190-204, tcr_tracks.tc_rows_only); False = every row (what parity tests compare)
         self.tc_rows_only = bool(tc_rows_only)
@@ -35,8 +39,9 @@ class DevicePipeline:
         # candidates carry no Fourier phases: they are drawn at selection time, only for seeds that pass
         self.cand = seeds(self.C, ph=False)   # one seeding round
         self.storms = seeds(self.B)           # the candidates that passed, dense
-        self.tracks = dict(lon=z(self.B, ns), lat=z(self.B, ns), v=z(self.B, ns), m=z(self.B, ns),
-                           vmax=z(self.B, ns), envw=z(self.B, ns, 4),
+        rt = F64 if dtype == 'f64' else torch.float32
+        self.tracks = dict(lon=z(self.B, ns, dtype=rt), lat=z(self.B, ns, dtype=rt), v=z(self.B, ns, dtype=rt),
+                           m=z(self.B, ns, dtype=rt), vmax=z(self.B, ns, dtype=rt), envw=z(self.B, ns, 4, dtype=rt),
                            n_valid=z(self.B, dtype=I32), status=z(self.B, dtype=I32),
                            flags=z(self.B, dtype=I32), nfev=z(self.B, dtype=I32),
                            n_accept=z(self.B, dtype=I32), n_reject=z(self.B, dtype=I32),
@@ -125,8 +130,8 @@ class DevicePipeline:
         si = _lib.Storms(n, *[s[k].data_ptr() for k in ('lon0', 'lat0', 'v0', 'm0', 'h_bl', 'slot', 'phases')],
                          n_dev.data_ptr() if n_dev is not None else None)
         so = self._tracks_struct()
-        self.eng._ck(self.eng.L.tcr_integrate_dev(self.eng.h, C.byref(si), C.byref(so),
-                                                  C.c_void_p(self._stream())))
+        fn = self.eng.L.tcr_integrate_dev if self.dtype == 'f64' else self.eng.L.tcr_integrate_f32_dev
+        self.eng._ck(fn(self.eng.h, C.byref(si), C.byref(so), C.c_void_p(self._stream())))
         self.n_done = n
 
     def add_stats(self, counters):
@@ -147,9 +152,10 @@ class DevicePipeline:
         """Survivor records of the first ``cap`` accepted tracks into ``packed`` [cap, >= 9*ns] (extra
         columns of a wider buffer are left to the caller)."""
         so = self._tracks_struct()
-        self.eng._ck(self.eng.L.tcr_pack_tracks_dev(self.eng.h, C.byref(so), self.acc_idx.data_ptr(),
-                                                    self.n_accepted.data_ptr(), int(cap), packed.data_ptr(),
-                                                    int(packed.stride(0)), C.c_void_p(self._stream())))
+        fn = self.eng.L.tcr_pack_tracks_dev if self.dtype == 'f64' else self.eng.L.tcr_pack_tracks_f32_dev
+        self.eng._ck(fn(self.eng.h, C.byref(so), self.acc_idx.data_ptr(),
+                        self.n_accepted.data_ptr(), int(cap), packed.data_ptr(),
+                        int(packed.stride(0)), C.c_void_p(self._stream())))
 
     def host_tracks(self, n=None):
         """Copy the per-storm outputs of the last integrate() back as NumPy arrays."""
