@@ -149,6 +149,10 @@ int tcr_params_set(tcr_ctx *ctx, const tcr_params *p);
 /* ---- field staging (once per experiment / year) --------------------------- */
 /* replaces: geo.read_bathy / geo.read_land (intensity/geo.py:9-34, coupled_fast.py:30-31) */
 int tcr_static_upload(tcr_ctx *ctx, const tcr_grid *hg, const double *land, const double *bathy);
+/* the same with the land mask and the bathymetry each on its own grid, as the two independent interpolators
+ * f_land / f_bath of the reference allow (intensity/geo.py:9-34); equal grids take the one-grid path */
+int tcr_static_upload2(tcr_ctx *ctx, const tcr_grid *land_grid, const double *land,
+                       const tcr_grid *bathy_grid, const double *bathy);
 /* replaces: BetaAdvectionTrack._load_wnd_stat (bam_track.py:76-91) +
  *           Coupled_FAST.init_fields (coupled_fast.py:217-225) for one month slot.
  */
@@ -239,6 +243,14 @@ int tcr_wind_stats_dev(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const 
                        const int32_t *day_start, int32_t n_days, double *out, void *stream);
 int tcr_wind_stats_host(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const double *const wnd[4],
                         const int32_t *day_start, int32_t n_days, double *out);
+/* The same for float32 planes — the dtype ERA5 u / v files hold and xarray keeps through .mean / .var / xr.cov:
+ * sums over time in float32 in time order, divisions through fp64 rounded back to float32, covariances
+ * (float32 sum / int64 count) in fp64, every statistic stored as fp64.  Both variants skip NaN samples as
+ * xarray's skipna does (per pair for the covariances). */
+int tcr_wind_stats_f32_dev(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const float *const wnd[4],
+                           const int32_t *day_start, int32_t n_days, double *out, void *stream);
+int tcr_wind_stats_f32_host(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const float *const wnd[4],
+                            const int32_t *day_start, int32_t n_days, double *out);
 
 /* ---- thermodynamic preprocessing ---------------------------- */
 /* replaces: np.load(thermo/entropy_table.npz) in CAPE_PI_vectorized (thermo/thermo.py:272-277):

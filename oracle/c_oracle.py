@@ -24,7 +24,7 @@ class _Grid(C.Structure):
 
 
 class _Env(C.Structure):
-    _fields_ = [('wg', _Grid), ('tg', _Grid), ('hg', _Grid),
+    _fields_ = [('wg', _Grid), ('tg', _Grid), ('hg', _Grid), ('bg', _Grid),
                 ('mean', _DP * 4), ('cov', _DP * 10),
                 ('vpot', _DP), ('chi', _DP), ('mld', _DP), ('strat', _DP),
                 ('land', _DP), ('bathy', _DP), ('box', C.c_double * 4)]
@@ -109,14 +109,17 @@ class CMonthEnv:
             setattr(e, name, _dp(crop(env.lon, env.lat, getattr(env, name)[month0])[2]))
         hl, ha, _ = crop(env.hlon, env.hlat, env.land)
         e.land = _dp(crop(env.hlon, env.hlat, env.land)[2])
-        e.bathy = _dp(crop(env.hlon, env.hlat, env.bathy)[2])
-        for g, (lo, la) in zip((e.wg, e.tg, e.hg), ((wl, wa), (tl, ta), (hl, ha))):
+        # the bathymetry is its own interpolator on its own grid (geo.py:9-20); env.blon / blat when it differs
+        blon, blat = getattr(env, 'blon', None), getattr(env, 'blat', None)
+        bl, ba, bb = crop(env.hlon if blon is None else blon, env.hlat if blat is None else blat, env.bathy)
+        e.bathy = _dp(bb)
+        for g, (lo, la) in zip((e.wg, e.tg, e.hg, e.bg), ((wl, wa), (tl, ta), (hl, ha), (bl, ba))):
             g.nlon, g.nlat, g.lon, g.lat = lo.size, la.size, _dp(lo), _dp(la)
-        keep += [wl, wa, tl, ta, hl, ha]
+        keep += [wl, wa, tl, ta, hl, ha, bl, ba]
         e.box = (C.c_double * 4)(*b)
         self.c = e
         self._keep = keep
-        self.grids = dict(w=(wl, wa), t=(tl, ta), h=(hl, ha))
+        self.grids = dict(w=(wl, wa), t=(tl, ta), h=(hl, ha), b=(bl, ba))
 
 
 def fourier_table(phases, prm=None):
@@ -139,7 +142,7 @@ def rhs_points(cme, Fs, h_bl, t, lon, lat, v, m, prm=None):
 
 
 def bilinear(cme, which, plane_name, lon, lat):
-    g = {'w': cme.c.wg, 't': cme.c.tg, 'h': cme.c.hg}[which]
+    g = {'w': cme.c.wg, 't': cme.c.tg, 'h': cme.c.hg if plane_name != 'bathy' else cme.c.bg}[which]
     plane = getattr(cme.c, plane_name)
     return np.array([lib().orc_bilinear(C.byref(g), plane, float(a), float(b)) for a, b in zip(lon, lat)])
 

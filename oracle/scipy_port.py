@@ -112,7 +112,8 @@ class MonthEnv:
         self.mld = _spline(b, env.lon, env.lat, env.mld[month0])
         self.strat = _spline(b, env.lon, env.lat, env.strat[month0])
         self.land = _spline(b, env.hlon, env.hlat, env.land)
-        self.bathy = _spline(b, env.hlon, env.hlat, env.bathy)
+        self.bathy = _spline(b, getattr(env, 'blon', None) if getattr(env, 'blon', None) is not None else env.hlon,
+                             getattr(env, 'blat', None) if getattr(env, 'blat', None) is not None else env.hlat, env.bathy)    # its own grid (geo.py:9-20)
 
     def inside(self, lon, lat, dx):
         x0, y0, x1, y1 = self.bounds

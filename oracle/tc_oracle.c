@@ -46,7 +46,7 @@ typedef struct {
 /* One (basin, month) field set, already cropped to the basin box.
  * Planes are [lat][lon] row-major (the reference's [lat, lon] arrays). */
 typedef struct {
-    orc_grid wg, tg, hg;
+    orc_grid wg, tg, hg, bg;          /* wind, thermo, land, bathymetry (two independent interpolators, geo.py:9-34) */
     const double *mean[NW];
     const double *cov[NCOV];          /* packed lower triangle (0,0),(1,0),(1,1),... */
     const double *vpot, *chi, *mld, *strat;
@@ -274,7 +274,7 @@ static double ocean_alpha(const orc_storm *s, double lon, double lat, const doub
     double gam = orc_bilinear(&e->tg, e->strat, lon, lat);
     double vp = vpot_here(e, lon, lat);
     double uT = sqrt(vb[0] * vb[0] + vb[1] * vb[1]);
-    double bathy = orc_bilinear(&e->hg, e->bathy, lon, lat);
+    double bathy = orc_bilinear(&e->bg, e->bathy, lon, lat);
     if (bathy >= 0 || -h_m <= bathy || gam == 0) return 1.0;
     double z = 0.01 * pow(gam, -0.4) * h_m * uT * vp / v;
     double zc = (z != z) ? z : (z > 0 ? z : 0.0);

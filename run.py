@@ -49,6 +49,14 @@ def main():
             strat=one('strat_climatology.nc'), land=one('land.nc'), bathy=one('bathymetry.nc'),
             basin_dir=os.path.join(a.fields, 'land')))
     rank, world, local = distributed.init_from_env()
+    if not a.synthetic and not a.fields and rank == 0:
+        # the reference's run.py:14: land.nc and the basin masks next to the sources, generated when missing
+        from tropical_cyclone_risk_amd import fields, masks
+        fl = fields.default_files(namelist)
+        try:
+            masks.generate_land_masks(fl['basin_dir'], land_file=fl['land'])
+        except FileNotFoundError as e:
+            print('land masks not generated: %s' % e)
     if a.preprocess and rank == 0:
         from tropical_cyclone_risk_amd import preprocess
         from tropical_cyclone_risk_amd.engine import TCEngine

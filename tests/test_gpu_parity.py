@@ -139,6 +139,41 @@ def test_two_grid_and_nonuniform_fields(built_lib, shape, basin):
     _check('%s-%s' % (shape, basin), got, ref, t_s, counters=('status', 'n_valid', 'nfev', 'n_accept', 'n_reject'))
 
 
+def test_independent_land_and_bathymetry_grids(built_lib):
+    """intensity/geo.py:9-34 builds f_bath and f_land as two independent interpolators; here the bathymetry sits on a
+    0.5-degree grid and the land mask on the 0.25-degree one (tcr_static_upload2, the SPLIT instantiations).
+    fp64 against the C oracle with the decision probe; the fp32 variant runs the same arrangement."""
+    import copy
+    from oracle import c_oracle
+    from tropical_cyclone_risk_amd import synthetic
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    env = copy.copy(synthetic.make_env('era5', seed=11))
+    env.blon, env.blat, env.bathy = env.hlon[::2].copy(), env.hlat[::2].copy(), np.ascontiguousarray(env.bathy[::2, ::2])
+    storms = synthetic.draw_storm_inputs(1500, 'WP', seed=17)
+    eng = TCEngine('WP', device=0).stage_env(env)
+    got = eng.integrate(storms, probe_cap=PROBE_CAP)
+    f32 = eng.integrate(storms, dtype='f32')
+    t_s = eng.t_s
+    # the probe kernel (single evaluations) on the same arrangement
+    cme = c_oracle.CMonthEnv(env, 'WP', 8)
+    rng = np.random.default_rng(2)
+    n = 400
+    t = rng.uniform(0, 15 * 86400.0, n); lon = rng.uniform(101, 179, n); lat = rng.uniform(1, 59, n)
+    v = rng.uniform(1, 70, n); m = rng.uniform(0, 1.1, n)
+    Fs = eng.fourier_table(storms['phases'][:1])[0]
+    dydt, envw, alpha = eng.probe_rhs(8, 1800.0, Fs, t, lon, lat, v, m)
+    eng.close()
+    o_dydt, o_envw, o_alpha = c_oracle.rhs_points(cme, Fs, 1800.0, t, lon, lat, v, m)
+    assert (np.abs(dydt - o_dydt) / np.abs(o_dydt).max(axis=0)).max() < 1e-12 and np.abs(alpha - o_alpha).max() < 1e-12
+    ref = c_oracle.run_ensemble(env, 'WP', storms, probe=True)
+    _check('split-static-WP', got, ref, t_s, counters=('status', 'n_valid', 'nfev', 'n_accept', 'n_reject'))
+    # and it matters: the same storms on the shared 0.25-degree bathymetry give different tracks
+    env1 = synthetic.make_env('era5', seed=11)
+    ref1 = c_oracle.run_ensemble(env1, 'WP', storms)
+    assert (ref1['n_valid'] != ref['n_valid']).any()
+    assert (f32['status'] == got['status']).mean() > 0.99 and (np.abs(f32['n_valid'] - got['n_valid']) <= 6).mean() > 0.97
+
+
 def _namelist_with(**over):
     import types
     from tropical_cyclone_risk_amd import namelist
@@ -365,6 +400,18 @@ def test_wind_stats_kernel_vs_oracle(built_lib):
     # sub-daily record with ragged days
     ds = np.array([0, 3, 4, 8, 12, 13, 17, 21, 25, 31], dtype=np.int32)
     assert np.array_equal(eng.wind_stats(planes, ds), ws.wind_stats(planes, ds))
+    # float32 planes — the dtype ERA5 u / v files hold: reduced in float32 exactly as NumPy does (np.nanmean /
+    # np.nanvar / the xr.cov steps, oracle/wind_stats.py), NaN samples skipped per statistic and per pair
+    p32 = [(p * (1 + 50 * (c == 2))).astype(np.float32) for c, p in enumerate(planes)]
+    assert np.array_equal(eng.wind_stats(p32), ws.wind_stats(p32))
+    assert not np.array_equal(eng.wind_stats(p32), eng.wind_stats([p.astype(np.float64) for p in p32]))   # it is not the fp64 reduction
+    p32[0][3, 10, 20] = np.nan; p32[2][3, 10, 20] = np.nan; p32[1][7, 10, 20] = np.nan; p32[3][:, 50, 60] = np.nan
+    with np.errstate(all='ignore'):
+        a, b = eng.wind_stats(p32), ws.wind_stats(p32)
+    assert np.array_equal(a, b, equal_nan=True) and np.isnan(a[3, 50, 60]) and not np.isnan(a[:, 10, 20]).any()
+    p64 = [p.copy() for p in planes]
+    p64[1][5, 2, 3] = np.nan
+    assert np.array_equal(eng.wind_stats(p64), ws.wind_stats(p64), equal_nan=True)
     # covariance matrix is symmetric positive semi-definite up to the ddof mix: check the diagonal dominates
     assert (got[4] > 0).all() and (got[6] > 0).all()
     # calc_wnd_stat: 6-hourly record over two months, 3 levels in Pa
@@ -374,7 +421,8 @@ def test_wind_stats_kernel_vs_oracle(built_lib):
     lev = [85000, 50000, 25000]
     out = pp.calc_wnd_stat(eng, ua, va, lev, 'Pa', times, 2001, 2)
     keep = pp.month_mask(times, 2001, 2)
-    sel = [ua[keep][:, 2], va[keep][:, 2], ua[keep][:, 0], va[keep][:, 0]]
+    sel = [ua[keep][:, 2], va[keep][:, 2], ua[keep][:, 0], va[keep][:, 0]]         # float32, like the files
+    assert sel[0].dtype == np.float32
     assert np.array_equal(out, ws.wind_stats(sel))                                  # the reference's `< 0` test: no grouping
     out_d = pp.calc_wnd_stat(eng, ua, va, lev, 'Pa', times, 2001, 2, group_days=True)
     assert np.array_equal(out_d, ws.wind_stats(sel, pp.day_groups([t for t, k in zip(times, keep) if k])))

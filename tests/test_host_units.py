@@ -132,6 +132,36 @@ def test_field_loader_round_trip(tmp_path, calendar):
         assert np.array_equal(got.basin_masks[b], env.basin_masks[b])
 
 
+def test_field_loader_keeps_independent_static_grids(tmp_path):
+    """land.nc and bathymetry.nc on different grids (two independent interpolators, intensity/geo.py:9-34) and
+    north-to-south latitudes (flipped like mat.interp2_fx does, util/mat.py:147-154)."""
+    from scipy.io import netcdf_file
+    from tropical_cyclone_risk_amd import fields, namelist
+    env = _small_env()
+    env.blon, env.blat, env.bathy = env.hlon[::2].copy(), env.hlat[::2].copy(), np.ascontiguousarray(env.bathy[::2, ::2])
+    files = fields.write_reference_files(env, str(tmp_path), 2003, namelist)
+    got = fields.load_year_env(2003, namelist, files)
+    assert np.array_equal(got.blon, env.blon) and np.array_equal(got.blat, env.blat)
+    assert np.array_equal(got.bathy, env.bathy) and np.array_equal(got.land, env.land) and got.bathy.shape != got.land.shape
+    # a descending-latitude basin mask and land file come back ascending
+    fn = files['basin_dir'] + '/NA.nc'
+    with netcdf_file(fn, 'r', mmap=False) as f:
+        lat, lon, m = f.variables['lat'][:].copy(), f.variables['lon'][:].copy(), f.variables['basin'][:].copy()
+    with netcdf_file(fn, 'w', version=2) as f:
+        f.createDimension('lat', len(lat)); f.createDimension('lon', len(lon))
+        v = f.createVariable('lat', 'd', ('lat',)); v[:] = lat[::-1]
+        v = f.createVariable('lon', 'd', ('lon',)); v[:] = lon
+        v = f.createVariable('basin', 'd', ('lat', 'lon')); v[:] = m[::-1]
+    for b in got.basin_masks:
+        if b != 'NA':
+            os.remove(files['basin_dir'] + '/%s.nc' % b)
+    again = fields.load_year_env(2003, namelist, files)
+    assert np.array_equal(again.basin_masks['NA'], got.basin_masks['NA'])
+    f2 = fields._interp2_fx(lon, lat[::-1], m[::-1])
+    f1 = fields._interp2_fx(lon, lat, m)
+    assert f2.ev(lon[5] + 0.1, lat[7] + 0.05) == f1.ev(lon[5] + 0.1, lat[7] + 0.05)
+
+
 def test_field_loader_time_semantics(tmp_path):
     """Monthly records stamped on the 1st: the 15th of each month is a blend of two records and
     December falls off the end of the year's slice -> vpot 0, chi 5 -> transform (compute.py:70-71, 108-113)."""
@@ -159,6 +189,57 @@ def test_field_loader_time_semantics(tmp_path):
     assert np.all(got.vpot[11] == 0.0)                                   # Dec 15 is past the last record
     assert np.allclose(got.chi[11], min(max(np.exp(np.log(5 + 1e-3) + namelist.log_chi_fac) + namelist.chi_fac, 1e-5), 5))
     assert np.isnan(got.rh_mid[11]).all()
+
+
+def test_loader_time_interp_known_answers(tmp_path):
+    """`DataArray.interp(time=the 15th)` (compute.py:108-113) is xarray.core.missing -> scipy.interpolate.interp1d(
+    kind='linear', bounds_error=False, fill_value=nan) along time.  SciPy is installed here, so fields.interp_time is
+    pinned against that very call — at record edges, exactly on records, and outside — plus hand-computed
+    calendar cases for standard and noleap axes and the inclusive year slice (compute.py:68-71)."""
+    from scipy.interpolate import interp1d
+    from scipy.io import netcdf_file
+    from tropical_cyclone_risk_amd import fields, namelist
+    rng = np.random.default_rng(3)
+    t = np.sort(rng.uniform(0, 400, 9)) * 86400.0
+    y = rng.normal(size=(9, 4, 5))
+    f = interp1d(t, y, kind='linear', axis=0, bounds_error=False, fill_value=np.nan)
+    for tq in list(t) + [t[0] - 1.0, t[-1] + 1.0, 0.5 * (t[3] + t[4]), t[0] + 1e-3, t[-1] - 1e-3, np.nextafter(t[2], np.inf)]:
+        assert np.array_equal(fields.interp_time(t, y, tq), f(tq), equal_nan=True), tq
+    assert np.isnan(fields.interp_time(t, y, t[0] - 1.0)).all() and not np.isnan(fields.interp_time(t, y, t[-1])).any()
+    # calendars: Feb 15 of a leap year between records on Feb 1 and Mar 1
+    for cal, w in (('standard', 14.0 / 29.0), ('noleap', 14.0 / 28.0)):
+        ax = fields.TimeAxis(np.array([31.0, 59.0 if cal == 'noleap' else 60.0]), dict(units='days since 2004-01-01', calendar=cal))
+        assert ax.at(2004, 2, 1) == ax.t[0] and ax.at(2004, 3, 1) == ax.t[1]
+        v = fields.interp_time(ax.t, np.array([[10.0], [30.0]]), ax.at(2004, 2, 15))
+        assert abs(v[0] - (10.0 + 20.0 * w)) < 1e-12, cal
+    assert fields._linear_seconds('noleap', 2004, 3, 1) - fields._linear_seconds('noleap', 2004, 2, 28) == 86400.0
+    assert fields._linear_seconds('standard', 2004, 3, 1) - fields._linear_seconds('standard', 2004, 2, 28) == 2 * 86400.0
+    assert fields._linear_seconds('noleap', 2005, 1, 1) - fields._linear_seconds('noleap', 2004, 1, 1) == 365 * 86400.0
+    # the year slice [Dec 31 of year-1, Dec 31 of year] is inclusive at both ends (ds.sel(time=slice(a, b))): records stamped
+    # exactly on those two days take part, records one day outside do not — visible in January / December of the result
+    env = _small_env()
+    files = fields.write_reference_files(env, str(tmp_path), 2003, namelist)
+    lat, lon = env.lat, env.lon
+    stamps = [datetime.date(2002, 12, 30), datetime.date(2002, 12, 31), datetime.date(2003, 7, 1), datetime.date(2003, 12, 31), datetime.date(2004, 1, 1)]
+    days = np.array([(d - datetime.date(2002, 1, 1)).days for d in stamps], dtype=float)
+    vals = np.array([1000.0, 10.0, 20.0, 40.0, 1000.0])
+    vm = vals[:, None, None] + np.zeros((5, len(lat), len(lon)))
+    fn = str(tmp_path / 'thermo_edges.nc')
+    with netcdf_file(fn, 'w', version=2) as fo:
+        fo.createDimension('time', 5); fo.createDimension('lat', len(lat)); fo.createDimension('lon', len(lon))
+        v = fo.createVariable('time', 'd', ('time',)); v[:] = days; v.units = 'days since 2002-01-01'
+        for name, arr in (('lat', lat), ('lon', lon)):
+            v = fo.createVariable(name, 'd', (name,)); v[:] = arr
+        for name in ('vmax', 'rh_mid', 'chi'):
+            v = fo.createVariable(name, 'd', ('time', 'lat', 'lon')); v[:] = vm
+    files['thermo'] = fn
+    got = fields.load_year_env(2003, namelist, files)
+    fac = namelist.PI_reduc * np.sqrt(namelist.Ck / namelist.Cd)
+    d0, d1, d2 = (datetime.date(2002, 12, 31), datetime.date(2003, 7, 1), datetime.date(2003, 12, 31))
+    jan = 10.0 + 10.0 * (datetime.date(2003, 1, 15) - d0).days / (d1 - d0).days          # the Dec-30 record (1000) is outside the slice
+    dec = 20.0 + 20.0 * (datetime.date(2003, 12, 15) - d1).days / (d2 - d1).days         # ... and so is Jan 1 of the next year
+    assert abs(got.vpot[0, 2, 2] - fac * jan) < 1e-12 and abs(got.vpot[11, 2, 2] - fac * dec) < 1e-12
+    assert abs(got.rh_mid[6, 2, 2] - (20.0 + 20.0 * 14 / (d2 - d1).days)) < 1e-12      # Jul 15
 
 
 def test_hdf5lite_reads_the_reference_land_mask():
@@ -211,6 +292,68 @@ def test_wind_stats_oracle_hand_case():
     s = np.array([[3.0], [1.0], [3.0], [2.0], [4.0], [12.0]])
     g = ws.wind_stats([s, s, s, s], day_start=np.array([0, 1, 3, 6]))
     assert np.allclose(g[0], [(3 + 2 + 6) / 3.0]) and np.allclose(g[4], [((3 - 11 / 3) ** 2 + (2 - 11 / 3) ** 2 + (6 - 11 / 3) ** 2) / 3])
+
+
+def test_wind_stats_float32_path_is_what_numpy_does():
+    """The documented float32 path of mean / var / xr.cov (oracle/wind_stats.py: np.nanmean / np.nanvar / the cov
+    steps) against explicit scalar loops: float32 sums in time order, divisions through fp64 rounded back to
+    float32, per-pair NaN masks and means for the covariances, cov = float32 sum / (n - 1) in fp64 — which is also
+    what k_wind_stats<float> does, operation for operation."""
+    from oracle import wind_stats as ws
+    f32 = np.float32
+    # accumulation order: 16777216 + 1 + 1 stays 16777216 in float32 when added in time order
+    big = np.array([[16777216.0], [1.0], [1.0]], dtype=f32)
+    one = np.ones((3, 1), dtype=f32)
+    out = ws.wind_stats([big, one, one, one])
+    assert out[0, 0] == float(f32(16777216.0 / 3.0)) and out.dtype == np.float64
+    rng = np.random.default_rng(5)
+    T, P = 29, 6
+    x = [(rng.normal(10 * c, 4, size=(T, P)) * (1 + 100 * (c == 2))).astype(f32) for c in range(4)]
+    x[0][3, 1] = np.nan; x[2][3, 1] = np.nan; x[1][7, 1] = np.nan; x[3][:, 4] = np.nan     # scattered and a whole column
+    got = ws.wind_stats(x)
+    want = np.zeros((14, P))
+    for p in range(P):
+        def nanmean(v, ok):
+            s, n = f32(0), 0
+            for t in range(T):
+                if ok[t]:
+                    s = f32(s + v[t]); n += 1
+            return (f32(np.float64(s) / n) if n else f32(np.nan)), n
+        col = [a[:, p] for a in x]
+        fin = [~np.isnan(c) for c in col]
+        k = 4
+        for i in range(4):
+            m, n = nanmean(col[i], fin[i])
+            want[i, p] = m
+        for i in range(4):
+            for j in range(i + 1):
+                if i == j:
+                    m, n = nanmean(col[i], fin[i])
+                    s = f32(0)
+                    for t in range(T):
+                        if fin[i][t]:
+                            d = f32(col[i][t] - m); s = f32(s + f32(d * d))
+                    want[k, p] = f32(np.float64(s) / n) if n else np.nan
+                else:
+                    both = fin[i] & fin[j]
+                    mi, n = nanmean(col[i], both); mj, _ = nanmean(col[j], both)
+                    s = f32(0)
+                    for t in range(T):
+                        if both[t]:
+                            s = f32(s + f32(f32(col[i][t] - mi) * f32(col[j][t] - mj)))
+                    want[k, p] = np.float64(s) / (n - 1) if n >= 1 else np.nan
+                k += 1
+    with np.errstate(all='ignore'):
+        assert np.array_equal(got, want, equal_nan=True)
+    assert np.isnan(got[3, 4]) and np.isnan(got[13, 4]) and np.isnan(got[10, 4]) and not np.isnan(got[0, 4])
+    # float64 planes take the same path in float64 (round-1 formula when there is no NaN)
+    y = [a.astype(np.float64) for a in x]
+    y[3][:, 4] = 1.0
+    for a in y:
+        a[np.isnan(a)] = 0.5
+    o64 = ws.wind_stats(y)
+    assert np.array_equal(o64[5], ((y[1] - y[1].mean(0)) * (y[0] - y[0].mean(0))).sum(0) / (T - 1))
+    assert np.array_equal(o64[4], ((y[0] - y[0].mean(0)) ** 2).mean(0))
 
 
 def test_wind_stats_host_logic():

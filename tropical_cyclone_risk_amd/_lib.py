@@ -27,7 +27,8 @@ EXPORTS = ('tcr_abi_version', 'tcr_ctx_create', 'tcr_ctx_destroy', 'tcr_last_err
            'tcr_timing_last', 'tcr_timing_sum', 'tcr_sync', 'tcr_compact_dev',
            'tcr_gather_seeds_dev', 'tcr_pack_tracks_dev', 'tcr_stats_dev', 'tcr_integrate_pass_stats', 'tcr_wind_stats_dev', 'tcr_wind_stats_host', 'tcr_entropy_table_upload',
            'tcr_potential_intensity_host', 'tcr_potential_intensity_dev', 'tcr_chi_rh_host',
-           'tcr_integrate_probe_host', 'tcr_integrate_f32_dev', 'tcr_integrate_f32_host', 'tcr_pack_tracks_f32_dev')
+           'tcr_integrate_probe_host', 'tcr_integrate_f32_dev', 'tcr_integrate_f32_host', 'tcr_pack_tracks_f32_dev',
+           'tcr_wind_stats_f32_dev', 'tcr_wind_stats_f32_host', 'tcr_static_upload2')
 
 
 class Grid(C.Structure):
@@ -126,6 +127,7 @@ def lib():
     L.tcr_ctx_destroy.argtypes = [C.c_void_p]
     L.tcr_params_set.argtypes = [C.c_void_p, C.POINTER(Params)]
     L.tcr_static_upload.argtypes = [C.c_void_p, C.POINTER(Grid), DP, DP]
+    L.tcr_static_upload2.argtypes = [C.c_void_p, C.POINTER(Grid), DP, C.POINTER(Grid), DP]
     L.tcr_fields_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Grid), C.POINTER(DP), C.POINTER(DP),
                                     C.POINTER(Grid), DP, DP, DP, DP]
     L.tcr_rh_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Grid), DP]
@@ -161,6 +163,8 @@ def lib():
     L.tcr_pack_tracks_dev.argtypes = [C.c_void_p, C.POINTER(Tracks), C.c_void_p, C.c_void_p,
                                       C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
     L.tcr_pack_tracks_f32_dev.argtypes = L.tcr_pack_tracks_dev.argtypes
+    L.tcr_wind_stats_f32_dev.argtypes = L.tcr_wind_stats_dev.argtypes
+    L.tcr_wind_stats_f32_host.argtypes = L.tcr_wind_stats_host.argtypes
     if L.tcr_abi_version() != TCR_ABI_VERSION:
         raise TcrError('libtcrisk_hip.so ABI version %d != binding version %d'
                        % (L.tcr_abi_version(), TCR_ABI_VERSION))

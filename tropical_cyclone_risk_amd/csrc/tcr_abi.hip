@@ -68,12 +68,15 @@ struct tcr_ctx {
     std::string err;
     tcr_params prm;
     bool have_prm = false;
-    GridStore wg, tg, hg, mg, rg;
+    GridStore wg, tg, hg, bg, mg, rg;           // wind, thermo, land (+ bathymetry when shared), bathymetry (when on its own grid), masks, rh
     std::vector<SlotStore> slots;
     DevSlot *d_slots = nullptr;
     size_t d_slots_cap = 0;
     bool slots_dirty = true;
-    double *d_stat = nullptr;
+    double *d_stat = nullptr;                   // [lat][lon][2] land, bathymetry interleaved (one shared grid)
+    double *d_land = nullptr, *d_bathy = nullptr;   // separate planes when the two grids differ (split_static)
+    float *d_land32 = nullptr, *d_bathy32 = nullptr;
+    bool split_static = false;
     uint8_t *d_run_mask = nullptr, *d_basin_masks = nullptr;
     // workspaces
     double *d_fs = nullptr, *d_srec = nullptr;    // forcing tables, accepted-step records
@@ -212,10 +215,11 @@ DevFields dev_fields(const tcr_ctx *ctx)
     DevFields D{};
     D.wg = dev_grid(ctx->wg); D.tg = dev_grid(ctx->tg); D.hg = dev_grid(ctx->hg); D.mg = dev_grid(ctx->mg);
     D.rg = dev_grid(ctx->rg);
-    D.slots = ctx->d_slots; D.n_slots = (int)ctx->slots.size(); D.stat = ctx->d_stat;
+    D.slots = ctx->d_slots; D.n_slots = (int)ctx->slots.size();
     D.run_mask = ctx->d_run_mask; D.basin_masks = ctx->d_basin_masks;
     D.all_affine = (ctx->wg.affine_lon && ctx->wg.affine_lat && ctx->tg.affine_lon && ctx->tg.affine_lat &&
-                    ctx->hg.affine_lon && ctx->hg.affine_lat) ? 1 : 0;
+                    ctx->hg.affine_lon && ctx->hg.affine_lat &&
+                    (!ctx->split_static || (ctx->bg.affine_lon && ctx->bg.affine_lat))) ? 1 : 0;
     return D;
 }
 
@@ -316,12 +320,24 @@ int timing_events(tcr_ctx *ctx, hipEvent_t **quad)
 }
 
 
-void launch_integrate_probe(const KArgsT<double> &a, bool affine, unsigned waves, hipStream_t st)
+// k_integrate<R, AFFINE, PROBE, SPLIT>: pick the instantiation
+template <typename R, bool PROBE>
+void launch_integrate_rp(const KArgsT<R> &a, bool affine, bool split, unsigned waves, hipStream_t st)
 {
-    if (affine) hipLaunchKernelGGL((k_integrate<double, true, true>), dim3(waves), dim3(kWave), 0, st, a);
-    else hipLaunchKernelGGL((k_integrate<double, false, true>), dim3(waves), dim3(kWave), 0, st, a);
+    if (affine && !split) hipLaunchKernelGGL((k_integrate<R, true, PROBE, false>), dim3(waves), dim3(kWave), 0, st, a);
+    else if (!affine && !split) hipLaunchKernelGGL((k_integrate<R, false, PROBE, false>), dim3(waves), dim3(kWave), 0, st, a);
+    else if (affine) hipLaunchKernelGGL((k_integrate<R, true, PROBE, true>), dim3(waves), dim3(kWave), 0, st, a);
+    else hipLaunchKernelGGL((k_integrate<R, false, PROBE, true>), dim3(waves), dim3(kWave), 0, st, a);
 }
-void launch_integrate_probe(const KArgsT<float> &, bool, unsigned, hipStream_t) {}      // fp64 instrument only
+void launch_integrate(const KArgsT<double> &a, bool affine, bool probe, bool split, unsigned waves, hipStream_t st)
+{
+    if (probe) launch_integrate_rp<double, true>(a, affine, split, waves, st);
+    else launch_integrate_rp<double, false>(a, affine, split, waves, st);
+}
+void launch_integrate(const KArgsT<float> &a, bool affine, bool, bool split, unsigned waves, hipStream_t st)
+{
+    launch_integrate_rp<float, false>(a, affine, split, waves, st);      // the decision probe is an fp64 instrument
+}
 
 // ---- fp32 staging: float knots (+ reciprocal widths and the affine test in float arithmetic) and float
 // copies of the interleaved field layouts, converted on the device from the fp64 arrays already staged
@@ -357,6 +373,7 @@ int grid_f32(tcr_ctx *ctx, GridStore &g, const char *what)
 int ensure_f32(tcr_ctx *ctx, hipStream_t st)
 {
     if (grid_f32(ctx, ctx->wg, "wind") || grid_f32(ctx, ctx->tg, "thermo") || grid_f32(ctx, ctx->hg, "static")) return -1;
+    if (ctx->split_static && grid_f32(ctx, ctx->bg, "bathymetry")) return -1;
     const size_t nw = ctx->wg.lon.size() * ctx->wg.lat.size() * kWindStride;
     const size_t nt = ctx->tg.lon.size() * ctx->tg.lat.size() * kThermoStride;
     const size_t nh = ctx->hg.lon.size() * ctx->hg.lat.size() * kStaticStride;
@@ -372,7 +389,10 @@ int ensure_f32(tcr_ctx *ctx, hipStream_t st)
         ctx->slots_dirty = true;
     }
     if (ctx->stat32_stale) {
-        if (conv(ctx->d_stat, &ctx->d_stat32, nh)) return -1;
+        if (ctx->split_static) {
+            if (conv(ctx->d_land, &ctx->d_land32, nh / kStaticStride)) return -1;
+            if (conv(ctx->d_bathy, &ctx->d_bathy32, ctx->bg.lon.size() * ctx->bg.lat.size())) return -1;
+        } else if (conv(ctx->d_stat, &ctx->d_stat32, nh)) return -1;
         ctx->stat32_stale = false;
     }
     HIPCHK(ctx, hipGetLastError());
@@ -405,9 +425,19 @@ void host_eval_k(const tcr_ctx *ctx, EvalKT<R> &K, bool *all_affine)
     K.wx = axis_of<R>(ctx->wg, true); K.wy = axis_of<R>(ctx->wg, false);
     K.tx = axis_of<R>(ctx->tg, true); K.ty = axis_of<R>(ctx->tg, false);
     K.hx = axis_of<R>(ctx->hg, true); K.hy = axis_of<R>(ctx->hg, false);
-    K.stat = std::is_same<R, double>::value ? reinterpret_cast<const R *>(ctx->d_stat) : reinterpret_cast<const R *>(ctx->d_stat32);
+    const bool f64 = std::is_same<R, double>::value;
+    if (ctx->split_static) {
+        K.bx = axis_of<R>(ctx->bg, true); K.by = axis_of<R>(ctx->bg, false);
+        K.stat = f64 ? reinterpret_cast<const R *>(ctx->d_land) : reinterpret_cast<const R *>(ctx->d_land32);
+        K.bathy = f64 ? reinterpret_cast<const R *>(ctx->d_bathy) : reinterpret_cast<const R *>(ctx->d_bathy32);
+    } else {
+        K.bx = K.hx; K.by = K.hy;
+        K.stat = f64 ? reinterpret_cast<const R *>(ctx->d_stat) : reinterpret_cast<const R *>(ctx->d_stat32);
+        K.bathy = nullptr;
+    }
     eval_k_scalars<R>(ctx->prm, K);
-    *all_affine = K.wx.affine && K.wy.affine && K.tx.affine && K.ty.affine && K.hx.affine && K.hy.affine;
+    *all_affine = K.wx.affine && K.wy.affine && K.tx.affine && K.ty.affine && K.hx.affine && K.hy.affine &&
+                  K.bx.affine && K.by.affine;
 }
 
 // Outputs of one precision: tcr_tracks (double planes) or tcr_tracks_f32 (float planes), same layout
@@ -504,11 +534,9 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
             a.threshold = last ? 0 : thr;
             a.park_in = ctx->d_park[(pass + 1) & 1];
             a.park_out = ctx->d_park[pass & 1];
-            if (std::is_same<R, double>::value && ctx->d_probe) {
-                a.probe = ctx->d_probe; a.probe_cap = ctx->probe_cap;
-                launch_integrate_probe(a, affine, waves, st);
-            } else if (affine) hipLaunchKernelGGL((k_integrate<R, true, false>), dim3(waves), dim3(kWave), 0, st, a);
-            else hipLaunchKernelGGL((k_integrate<R, false, false>), dim3(waves), dim3(kWave), 0, st, a);
+            const bool probe = std::is_same<R, double>::value && ctx->d_probe;
+            if (probe) { a.probe = ctx->d_probe; a.probe_cap = ctx->probe_cap; }
+            launch_integrate(a, affine, probe, ctx->split_static, waves, st);
             if (last) break;
             waves = (unsigned)(((size_t)waves * (size_t)(thr - 1) + kWave - 1) / kWave);
         }
@@ -589,12 +617,12 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (GridStore *g : {&ctx->wg, &ctx->tg, &ctx->hg, &ctx->mg, &ctx->rg}) {
+    for (GridStore *g : {&ctx->wg, &ctx->tg, &ctx->hg, &ctx->bg, &ctx->mg, &ctx->rg}) {
         (void)hipFree(g->d_lon); (void)hipFree(g->d_lat); (void)hipFree(g->d_rlon); (void)hipFree(g->d_rlat);
         (void)hipFree(g->d_lon32); (void)hipFree(g->d_lat32); (void)hipFree(g->d_rlon32); (void)hipFree(g->d_rlat32);
     }
     for (auto &s : ctx->slots) { (void)hipFree(s.wind); (void)hipFree(s.thermo); (void)hipFree(s.rh); (void)hipFree(s.wind32); (void)hipFree(s.thermo32); }
-    (void)hipFree(ctx->d_stat32);
+    (void)hipFree(ctx->d_stat32); (void)hipFree(ctx->d_land); (void)hipFree(ctx->d_bathy); (void)hipFree(ctx->d_land32); (void)hipFree(ctx->d_bathy32);
     (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_run_mask); (void)hipFree(ctx->d_basin_masks);
     (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_srec);
     for (auto &ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
@@ -636,19 +664,39 @@ int tcr_params_set(tcr_ctx *ctx, const tcr_params *p)
     return 0;
 }
 
-int tcr_static_upload(tcr_ctx *ctx, const tcr_grid *hg, const double *land, const double *bathy)
+int tcr_static_upload2(tcr_ctx *ctx, const tcr_grid *lg, const double *land, const tcr_grid *bg, const double *bathy)
 {
     if (!ctx) return -1;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (!land || !bathy) return fail(ctx, "tcr_static_upload: NULL plane");
-    if (stage_grid(ctx, ctx->hg, hg, "static")) return -1;
-    const size_t np = (size_t)hg->nlon * hg->nlat;
-    std::vector<double> h(np * kStaticStride);
-    for (size_t i = 0; i < np; ++i) { h[i * 2] = land[i]; h[i * 2 + 1] = bathy[i]; }
-    if (!ctx->d_stat && dev_alloc(ctx, &ctx->d_stat, h.size())) return -1;
-    HIPCHK(ctx, hipMemcpy(ctx->d_stat, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    if (!land || !bathy || !lg || !bg) return fail(ctx, "tcr_static_upload: NULL argument");
+    const bool shared = lg->nlon == bg->nlon && lg->nlat == bg->nlat && lg->lon && bg->lon && lg->lat && bg->lat &&
+                        memcmp(lg->lon, bg->lon, sizeof(double) * lg->nlon) == 0 &&
+                        memcmp(lg->lat, bg->lat, sizeof(double) * lg->nlat) == 0;
+    if (ctx->hg.set && shared == ctx->split_static)
+        return fail(ctx, "static fields were staged %s before; a context keeps one arrangement", ctx->split_static ? "on two grids" : "on one grid");
+    if (stage_grid(ctx, ctx->hg, lg, shared ? "static" : "land")) return -1;
+    const size_t np = (size_t)lg->nlon * lg->nlat;
+    if (shared) {
+        std::vector<double> h(np * kStaticStride);
+        for (size_t i = 0; i < np; ++i) { h[i * 2] = land[i]; h[i * 2 + 1] = bathy[i]; }
+        if (!ctx->d_stat && dev_alloc(ctx, &ctx->d_stat, h.size())) return -1;
+        HIPCHK(ctx, hipMemcpy(ctx->d_stat, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    } else {
+        if (stage_grid(ctx, ctx->bg, bg, "bathymetry")) return -1;
+        const size_t nb = (size_t)bg->nlon * bg->nlat;
+        if (!ctx->d_land && dev_alloc(ctx, &ctx->d_land, np)) return -1;
+        if (!ctx->d_bathy && dev_alloc(ctx, &ctx->d_bathy, nb)) return -1;
+        HIPCHK(ctx, hipMemcpy(ctx->d_land, land, sizeof(double) * np, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(ctx->d_bathy, bathy, sizeof(double) * nb, hipMemcpyHostToDevice));
+        ctx->split_static = true;
+    }
     ctx->stat32_stale = true;
     return 0;
+}
+
+int tcr_static_upload(tcr_ctx *ctx, const tcr_grid *hg, const double *land, const double *bathy)
+{
+    return tcr_static_upload2(ctx, hg, land, hg, bathy);
 }
 
 int tcr_fields_upload(tcr_ctx *ctx, int slot, const tcr_grid *wg, const double *const mean[TCR_NW],
@@ -976,8 +1024,11 @@ int tcr_chi_rh_host(tcr_ctx *ctx, int64_t n_points, const double *sst, const dou
     return 0;
 }
 
-int tcr_wind_stats_dev(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const double *const wnd[4],
-                       const int32_t *day_start, int32_t n_days, double *out, void *stream_)
+extern "C++" {
+namespace {
+template <typename T>
+int wind_stats_dev_impl(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const T *const wnd[4],
+                        const int32_t *day_start, int32_t n_days, double *out, void *stream_)
 {
     if (!ctx) return -1;
     if (!wnd || !out || n_samples <= 0 || n_points <= 0) return fail(ctx, "tcr_wind_stats_dev: bad argument");
@@ -985,36 +1036,63 @@ int tcr_wind_stats_dev(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const 
     if (n_days < 2) return fail(ctx, "tcr_wind_stats_dev: a covariance needs at least two days");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
-    WindStatArgs a{};
+    WindStatArgsT<T> a{};
     for (int c = 0; c < 4; ++c) a.w[c] = wnd[c];
     a.day_start = day_start; a.n_days = n_days; a.n_points = n_points; a.out = out;
     hipEvent_t *ev = nullptr;
     if (ctx->timing && timing_events(ctx, &ev)) return -1;
     if (ev) { HIPCHK(ctx, hipEventRecord(ev[0], st)); HIPCHK(ctx, hipEventRecord(ev[1], st)); }
-    hipLaunchKernelGGL(k_wind_stats, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_wind_stats<T>, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, st, a);
     if (ev) { HIPCHK(ctx, hipEventRecord(ev[2], st)); HIPCHK(ctx, hipEventRecord(ev[3], st)); }
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
 
-int tcr_wind_stats_host(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const double *const wnd[4],
-                        const int32_t *day_start, int32_t n_days, double *out)
+template <typename T>
+int wind_stats_host_impl(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const T *const wnd[4],
+                         const int32_t *day_start, int32_t n_days, double *out)
 {
     if (!ctx) return -1;
     if (!wnd || !out || n_samples <= 0 || n_points <= 0) return fail(ctx, "tcr_wind_stats_host: bad argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     DevBuf B;
-    const double *d_w[4];
+    const T *d_w[4];
     for (int c = 0; c < 4; ++c)
         if (!(d_w[c] = B.put(wnd[c], (size_t)n_samples * n_points))) return fail(ctx, "tcr_wind_stats_host: device allocation failed");
     const int32_t *d_ds = nullptr;
     if (day_start && !(d_ds = B.put(day_start, (size_t)n_days + 1))) return fail(ctx, "tcr_wind_stats_host: device allocation failed");
     double *d_out = B.get<double>((size_t)14 * n_points);
     if (!d_out) return fail(ctx, "tcr_wind_stats_host: device allocation failed");
-    if (tcr_wind_stats_dev(ctx, n_samples, n_points, d_w, d_ds, n_days, d_out, ctx->stream)) return -1;
+    if (wind_stats_dev_impl<T>(ctx, n_samples, n_points, d_w, d_ds, n_days, d_out, ctx->stream)) return -1;
     HIPCHK(ctx, hipMemcpyAsync(out, d_out, sizeof(double) * 14 * (size_t)n_points, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
+}
+}  // namespace
+}  // extern "C++"
+
+int tcr_wind_stats_dev(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const double *const wnd[4],
+                       const int32_t *day_start, int32_t n_days, double *out, void *stream_)
+{
+    return wind_stats_dev_impl<double>(ctx, n_samples, n_points, wnd, day_start, n_days, out, stream_);
+}
+
+int tcr_wind_stats_f32_dev(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const float *const wnd[4],
+                           const int32_t *day_start, int32_t n_days, double *out, void *stream_)
+{
+    return wind_stats_dev_impl<float>(ctx, n_samples, n_points, wnd, day_start, n_days, out, stream_);
+}
+
+int tcr_wind_stats_host(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const double *const wnd[4],
+                        const int32_t *day_start, int32_t n_days, double *out)
+{
+    return wind_stats_host_impl<double>(ctx, n_samples, n_points, wnd, day_start, n_days, out);
+}
+
+int tcr_wind_stats_f32_host(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const float *const wnd[4],
+                            const int32_t *day_start, int32_t n_days, double *out)
+{
+    return wind_stats_host_impl<float>(ctx, n_samples, n_points, wnd, day_start, n_days, out);
 }
 
 int tcr_probe_rhs_host(tcr_ctx *ctx, int slot, double h_bl, const double *Fs, int64_t n, const double *t,
@@ -1037,12 +1115,17 @@ int tcr_probe_rhs_host(tcr_ctx *ctx, int slot, double h_bl, const double *Fs, in
     if (!d_fs || !d_t || !d_lon || !d_lat || !d_v || !d_m || !d_dy || !d_w || !d_al)
         return fail(ctx, "tcr_probe_rhs_host: device allocation failed");
     const DevFields DF = dev_fields(ctx);
-    if (DF.all_affine)
-        hipLaunchKernelGGL(k_probe_rhs<true>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, ctx->prm,
-                           DF, slot, h_bl, d_fs, n, d_t, d_lon, d_lat, d_v, d_m, d_dy, d_w, d_al);
-    else
-        hipLaunchKernelGGL(k_probe_rhs<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, ctx->prm,
-                           DF, slot, h_bl, d_fs, n, d_t, d_lon, d_lat, d_v, d_m, d_dy, d_w, d_al);
+    EvalK EK{};
+    bool affine = false;
+    host_eval_k<double>(ctx, EK, &affine);
+    const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+#define PROBE_RHS(A, S) hipLaunchKernelGGL((k_probe_rhs<A, S>), grid, block, 0, ctx->stream, ctx->prm, DF, EK, slot, h_bl, \
+                                           d_fs, n, d_t, d_lon, d_lat, d_v, d_m, d_dy, d_w, d_al)
+    if (affine && !ctx->split_static) PROBE_RHS(true, false);
+    else if (!affine && !ctx->split_static) PROBE_RHS(false, false);
+    else if (affine) PROBE_RHS(true, true);
+    else PROBE_RHS(false, true);
+#undef PROBE_RHS
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipMemcpy(dydt, d_dy, sizeof(double) * n * 4, hipMemcpyDeviceToHost));

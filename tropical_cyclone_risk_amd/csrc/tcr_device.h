@@ -79,10 +79,9 @@ template <> __host__ __device__ inline const double *slot_thermo<double>(const D
 template <> __host__ __device__ inline const float *slot_thermo<float>(const DevSlot &S) { return S.thermo32; }
 
 struct DevFields {
-    DevGrid wg, tg, hg, mg, rg;   // wind, thermo, static hi-res, basin masks, (uncropped) rh grid
+    DevGrid wg, tg, hg, mg, rg;   // wind, thermo, static hi-res (land [+ bathymetry]), basin masks, (uncropped) rh grid
     const DevSlot *slots;    // device array
     int n_slots;
-    const double *stat;      // [nlat_h][nlon_h][2]: land, bathy
     const uint8_t *run_mask; // [nlat_m][nlon_m]
     const uint8_t *basin_masks;   // [7][nlat_m][nlon_m]
     int all_affine;          // wind, thermo and static axes are all affine
@@ -94,7 +93,12 @@ struct DevFields {
 template <typename R>
 struct EvalKT {
     AxisT<R> wx, wy, tx, ty, hx, hy;
+    // land and bathymetry are two independent interpolators in the reference (intensity/geo.py:9-34).  On one grid
+    // (what the reference ships: both 0.25 degree) they are staged interleaved, `stat` = [lat][lon][2], one gather;
+    // on different grids (SPLIT instantiations) `stat` is the land plane on (hx, hy) and `bathy` its own plane on (bx, by)
+    AxisT<R> bx, by;
     const R *stat;
+    const R *bathy;
     R earth_R, Ck, epsilon, kappa, u_beta, v_beta;
     R y_alpha[2], m_alpha[2], alpha_max[2], alpha_min[2], steering_coefs[2];
     double total_time, tstep, inv_tstep;        // time stays fp64 in both instantiations
@@ -117,13 +121,6 @@ __host__ __device__ inline void eval_k_scalars(const tcr_params &P, EvalKT<R> &K
     K.tstep = P.total_time / (double)(P.n_steps - 1);
     K.inv_tstep = (double)(P.n_steps - 1) / P.total_time;
     K.n_steps = P.n_steps; K.coupled_track = P.coupled_track;
-}
-
-__host__ __device__ inline void make_eval_k(const tcr_params &P, const DevFields &D, EvalK &K)
-{
-    K.wx = D.wg.ax; K.wy = D.wg.ay; K.tx = D.tg.ax; K.ty = D.tg.ay; K.hx = D.hg.ax; K.hy = D.hg.ay;
-    K.stat = D.stat;
-    eval_k_scalars<double>(P, K);
 }
 
 template <typename R>
@@ -440,10 +437,40 @@ __device__ __forceinline__ void rhs_tail(const EvalKT<R> &K, R h_bl, R lat, R v,
     r.d[3] = R(0.5) * RD(K.Ck) / h_bl * ((R(1) - m) * v - venti * m);
 }
 
+// land and bathymetry at (lon, lat): one interleaved gather, or (SPLIT) two planes on their own grids
+template <typename R, bool AFFINE, bool SPLIT>
+struct StaticLookup {
+    CellT<R> hx, hy, bx, by;
+    CornersT<R, 2, Widths<R>::H> CH;        // !SPLIT: (land, bathy) pairs
+    CornersT<R, 1, 1> CL, CB;               // SPLIT
+    __device__ __forceinline__ void issue(const EvalKT<R> &K, R lon, R lat)
+    {
+        hx = locate_t<R, AFFINE>(K.hx, lon); hy = locate_t<R, AFFINE>(K.hy, lat);
+        if (SPLIT) {
+            bx = locate_t<R, AFFINE>(K.bx, lon); by = locate_t<R, AFFINE>(K.by, lat);
+            gather<R, 1, 1, 1>(RD(K.stat), RD(K.hx.n), hx, hy, CL);
+            gather<R, 1, 1, 1>(RD(K.bathy), RD(K.bx.n), bx, by, CB);
+        } else {
+            gather<R, 2, kStaticStride, Widths<R>::H>(RD(K.stat), RD(K.hx.n), hx, hy, CH);
+        }
+    }
+    __device__ __forceinline__ void finish(R (&lb)[2]) const
+    {
+        if (SPLIT) {
+            R a[1], b[1];
+            blend<R, 1, 1>(CL, hx, hy, a);
+            blend<R, 1, 1>(CB, bx, by, b);
+            lb[0] = a[0]; lb[1] = b[0];
+        } else {
+            blend<R, 2, Widths<R>::H>(CH, hx, hy, lb);
+        }
+    }
+};
+
 // fun(t, y) = Coupled_FAST.dydt (coupled_fast.py:196-207): _calc_steering_coefs (:183-192),
 // _step_bam_track (bam_track.py:131-144) on _env_winds (:116-128), _dvdt (:141-150) with
 // _get_current_vpot (:54-58), _calc_alpha/_calc_z (:65-94), _dmdt (:175-180).
-template <typename R, bool AFFINE>
+template <typename R, bool AFFINE, bool SPLIT>
 __device__ __forceinline__ RhsT<R> rhs_eval(const EvalKT<R> &K, const R *__restrict__ wind, const R *__restrict__ thermo,
                                             const R *__restrict__ fs, R h_bl, double t, R lon, R lat, R v, R m)
 {
@@ -451,17 +478,16 @@ __device__ __forceinline__ RhsT<R> rhs_eval(const EvalKT<R> &K, const R *__restr
     // ---- address generation: pure ALU on affine grids
     const CellT<R> wx = locate_t<R, AFFINE>(K.wx, lon), wy = locate_t<R, AFFINE>(K.wy, lat);
     const CellT<R> tx = locate_t<R, AFFINE>(K.tx, lon), ty = locate_t<R, AFFINE>(K.ty, lat);
-    const CellT<R> hx = locate_t<R, AFFINE>(K.hx, lon), hy = locate_t<R, AFFINE>(K.hy, lat);
     const FsBracket fb = fs_bracket(K, t);
     // ---- one round of independent gathers
     CornersT<R, 14, Wd::W> CW;
     CornersT<R, 4, Wd::T> CT;
-    CornersT<R, 2, Wd::H> CH;
+    StaticLookup<R, AFFINE, SPLIT> SL;
     FsPairT<R> fp;
     gather<R, 14, kWindStride, Wd::W>(wind, RD(K.wx.n), wx, wy, CW);
     fs_gather<R>(fs, fb, fp);
     gather<R, 4, kThermoStride, Wd::T>(thermo, RD(K.tx.n), tx, ty, CT);
-    gather<R, 2, kStaticStride, Wd::H>(RD(K.stat), RD(K.hx.n), hx, hy, CH);
+    SL.issue(K, lon, lat);
     // ---- straight-line math
     RhsT<R> r;
     R q[14], F[4], th[4], lb[2];
@@ -469,7 +495,7 @@ __device__ __forceinline__ RhsT<R> rhs_eval(const EvalKT<R> &K, const R *__restr
     fs_blend<R>(fp, fb, t, F);
     winds_from_lookups<R>(q, F, lon, t, r.w);
     blend<R, 4, Wd::T>(CT, tx, ty, th);
-    blend<R, 2, Wd::H>(CH, hx, hy, lb);
+    SL.finish(lb);
     rhs_tail<R>(K, h_bl, lat, v, m, th, lb, r);
     return r;
 }
@@ -488,7 +514,7 @@ struct CornerCacheT {
 
 template <typename R> __device__ __forceinline__ void cache_reset(CornerCacheT<R> &C) { C.wi = C.wj = -1; }
 
-template <typename R, bool AFFINE>
+template <typename R, bool AFFINE, bool SPLIT>
 __device__ __forceinline__ RhsT<R> rhs_eval_cached(CornerCacheT<R> &C, const EvalKT<R> &K, const R *__restrict__ wind,
                                                    const R *__restrict__ thermo, const R *__restrict__ fs, R h_bl,
                                                    double t, R lon, R lat, R v, R m)
@@ -496,7 +522,6 @@ __device__ __forceinline__ RhsT<R> rhs_eval_cached(CornerCacheT<R> &C, const Eva
     typedef Widths<R> Wd;
     const CellT<R> wx = locate_t<R, AFFINE>(K.wx, lon), wy = locate_t<R, AFFINE>(K.wy, lat);
     const CellT<R> tx = locate_t<R, AFFINE>(K.tx, lon), ty = locate_t<R, AFFINE>(K.ty, lat);
-    const CellT<R> hx = locate_t<R, AFFINE>(K.hx, lon), hy = locate_t<R, AFFINE>(K.hy, lat);
     const FsBracket fb = fs_bracket(K, t);
     FsPairT<R> fp;
     fs_gather<R>(fs, fb, fp);
@@ -505,16 +530,16 @@ __device__ __forceinline__ RhsT<R> rhs_eval_cached(CornerCacheT<R> &C, const Eva
         C.wi = wx.i; C.wj = wy.i;
     }
     CornersT<R, 4, Wd::T> CT;
-    CornersT<R, 2, Wd::H> CH;
+    StaticLookup<R, AFFINE, SPLIT> SL;
     gather<R, 4, kThermoStride, Wd::T>(thermo, RD(K.tx.n), tx, ty, CT);
-    gather<R, 2, kStaticStride, Wd::H>(RD(K.stat), RD(K.hx.n), hx, hy, CH);
+    SL.issue(K, lon, lat);
     RhsT<R> r;
     R q[14], F[4], th[4], lb[2];
     blend<R, 14, Wd::W>(C.CW, wx, wy, q);
     fs_blend<R>(fp, fb, t, F);
     winds_from_lookups<R>(q, F, lon, t, r.w);
     blend<R, 4, Wd::T>(CT, tx, ty, th);
-    blend<R, 2, Wd::H>(CH, hx, hy, lb);
+    SL.finish(lb);
     rhs_tail<R>(K, h_bl, lat, v, m, th, lb, r);
     return r;
 }

@@ -269,7 +269,7 @@ template <typename R> constexpr int int_wps() { return sizeof(R) == 8 ? TCR_INT_
 // *time* (t, h, t_new, the stage times, the output grid) and the step-size controller: the error norm
 // is accumulated in fp64 from the fp32 stage derivatives, and err < 1, the factor 0.9 err^-0.2 and the
 // min-step test are the fp64 expressions of the fp64 build (every (double) cast below is the identity there).
-template <typename R, bool AFFINE, bool PROBE>
+template <typename R, bool AFFINE, bool PROBE, bool SPLIT>
 __global__ __launch_bounds__(kWave, (int_wps<R>())) void k_integrate(KArgsT<R> a)
 {
     // Kl[(stage*4 + component)*64 + lane]
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) void k_integrate(KArgsT<R> a
 #else
             const EvalKT<R> &Kq = K;
 #endif
-            if (live) r = rhs_eval_cached<R, AFFINE>(CC, Kq, wind, thermo, fs, h_bl, et, e[0], e[1], e[2], e[3]);
+            if (live) r = rhs_eval_cached<R, AFFINE, SPLIT>(CC, Kq, wind, thermo, fs, h_bl, et, e[0], e[1], e[2], e[3]);
             if (PROBE && live) {
                 const int ev = fresh ? slot : nfev;          // index of this evaluation in the storm's call order
                 if (ev < a.probe_cap) a.probe[(size_t)sid * a.probe_cap + ev] = (uint8_t)r.dec;
@@ -922,18 +922,18 @@ __global__ __launch_bounds__(256) void k_flags(tcr_params P, int64_t n_storms, c
     flags[sid] = fl;
 }
 
-template <bool AFFINE>
-__global__ __launch_bounds__(64) void k_probe_rhs(tcr_params P, DevFields D, int slot, double h_bl, const double *fs,
+template <bool AFFINE, bool SPLIT>
+__global__ __launch_bounds__(64) void k_probe_rhs(tcr_params P, DevFields D, EvalK K_host, int slot, double h_bl, const double *fs,
                             int64_t n, const double *t, const double *lon, const double *lat,
                             const double *v, const double *m, double *dydt, double *envw, double *alpha)
 {
     __shared__ EvalK K;
-    if (threadIdx.x == 0) make_eval_k(P, D, K);
+    if (threadIdx.x == 0) K = K_host;
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const DevSlot S = D.slots[slot];
-    const RhsT<double> r = rhs_eval<double, AFFINE>(K, S.wind, S.thermo, fs, h_bl, t[i], lon[i], lat[i], v[i], m[i]);
+    const RhsT<double> r = rhs_eval<double, AFFINE, SPLIT>(K, S.wind, S.thermo, fs, h_bl, t[i], lon[i], lat[i], v[i], m[i]);
     for (int k = 0; k < 4; ++k) dydt[i * 4 + k] = r.d[k];
     alpha[i] = r.alpha;
     double w[4];

@@ -115,13 +115,14 @@ class TCEngine:
         return g
 
     # --------------------------------------------------------------- staging
-    def stage_static(self, hlon, hlat, land, bathy):
-        """geo.read_land / read_bathy (intensity/geo.py:9-34): crop to the basin, stage."""
+    def stage_static(self, hlon, hlat, land, bathy, blon=None, blat=None):
+        """geo.read_land / read_bathy (intensity/geo.py:9-34): crop to the basin, stage.  The two are independent
+        interpolators in the reference; (blon, blat) is the bathymetry's own grid when it differs from the land mask's."""
         lo, la, land_b = self.basin.transform_global_field(hlon, hlat, land)
-        _, _, bathy_b = self.basin.transform_global_field(hlon, hlat, bathy)
-        g = self._grid(lo, la)
+        blo, bla, bathy_b = self.basin.transform_global_field(hlon if blon is None else blon, hlat if blat is None else blat, bathy)
+        g, gb = self._grid(lo, la), self._grid(blo, bla)
         land_b, bathy_b = _f64(land_b), _f64(bathy_b)
-        self._ck(self.L.tcr_static_upload(self.h, C.byref(g), _dp(land_b), _dp(bathy_b)))
+        self._ck(self.L.tcr_static_upload2(self.h, C.byref(g), _dp(land_b), C.byref(gb), _dp(bathy_b)))
 
     def stage_month(self, slot, wlon, wlat, wnd_mean, wnd_cov, lon, lat, vpot, chi, mld, strat, rh_mid=None):
         """One month's field set: `_load_wnd_stat` (bam_track.py:76-91) + `init_fields`
@@ -156,7 +157,7 @@ class TCEngine:
 
     def stage_env(self, env, months=range(12)):
         """Stage a ``synthetic.SyntheticEnv``-shaped object (12 monthly field sets)."""
-        self.stage_static(env.hlon, env.hlat, env.land, env.bathy)
+        self.stage_static(env.hlon, env.hlat, env.land, env.bathy, getattr(env, 'blon', None), getattr(env, 'blat', None))
         for mo in months:
             self.stage_month(mo, env.wlon, env.wlat, env.wnd_mean[mo], env.wnd_cov[mo], env.lon, env.lat,
                              env.vpot[mo], env.chi[mo], env.mld[mo], env.strat[mo], env.rh_mid[mo])

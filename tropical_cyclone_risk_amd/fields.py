@@ -257,9 +257,7 @@ def load_year_env(year, nl=None, files=None):
     bathy = np.asarray(db['bathymetry'], dtype=np.float64)
     blon, blat = np.asarray(db['lon'], dtype=np.float64), np.asarray(db['lat'], dtype=np.float64)
     blat, bathy = _ascending_lat(blat, bathy)
-    if bathy.shape != land.shape or not (np.array_equal(blon, hlon) and np.array_equal(blat, hlat)):
-        raise NotImplementedError('land.nc and bathymetry.nc are on different grids; tcr_static_upload takes one grid '
-                                  '(the reference ships both at 0.25 degrees)')
+    same_static = bathy.shape == land.shape and np.array_equal(blon, hlon) and np.array_equal(blat, hlat)
     masks = {}
     mgrid = None
     for b in list(BASIN_IDS) + ['GL']:
@@ -279,6 +277,8 @@ def load_year_env(year, nl=None, files=None):
                        hlon=hlon, hlat=hlat, land=land, bathy=bathy, basin_masks=masks, seed=0, shape='files')
     if mgrid is not None and not (np.array_equal(mgrid[0], hlon) and np.array_equal(mgrid[1], hlat)):
         env.mlon, env.mlat = mgrid
+    if not same_static:                  # land.nc and bathymetry.nc each keep their own grid (intensity/geo.py:9-34)
+        env.blon, env.blat = blon, blat
     return env
 
 
@@ -361,8 +361,10 @@ def write_reference_files(env, out_dir, year, nl=None, calendar='standard', last
             put(f, var, X, ('lat', 'lon', 'month'))
     for key, var, arr in (('land', 'land', env.land), ('bathy', 'bathymetry', env.bathy)):
         fn = files[key] = '%s/%s.nc' % (out_dir, 'land' if key == 'land' else 'bathymetry')
-        with new(fn, dict(lat=len(env.hlat), lon=len(env.hlon))) as f:
-            put(f, 'lat', env.hlat, ('lat',)); put(f, 'lon', env.hlon, ('lon',))
+        own = key == 'bathy' and getattr(env, 'blon', None) is not None
+        glon, glat = (env.blon, env.blat) if own else (env.hlon, env.hlat)
+        with new(fn, dict(lat=len(glat), lon=len(glon))) as f:
+            put(f, 'lat', glat, ('lat',)); put(f, 'lon', glon, ('lon',))
             put(f, var, arr, ('lat', 'lon'))
     files['basin_dir'] = out_dir + '/land'
     mlon, mlat = getattr(env, 'mlon', env.hlon), getattr(env, 'mlat', env.hlat)

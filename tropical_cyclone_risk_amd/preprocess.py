@@ -10,8 +10,8 @@ Two things of the reference are reproduced on purpose and named:
   * `dt_step = 1 day - step` is tested with `< 0`, so the per-day averaging only happens for records
     *coarser* than daily — sub-daily records are reduced sample by sample (group_days='reference').
     group_days=True gives what the comment in the reference says (daily means first).
-Inputs are converted to float64; the reference inherits float32 from ERA5 files, so its own numbers
-carry ~1e-7 relative rounding that this path does not.
+The reduction runs in the dtype of the input, as xarray's does: float32 planes (ERA5 files) are reduced in
+float32 (`tcr_wind_stats_f32_*`), anything else in float64; NaN samples are skipped (`skipna`).
 """
 import ctypes as C
 import datetime
@@ -53,7 +53,8 @@ def calc_wnd_stat(engine, ua, va, levels, level_units, times, year, month, group
     keep = month_mask(times, year, month)
     t_sel = [t for t, k in zip(times, keep) if k]
     iu, il = pick_levels(levels, level_units)
-    planes = [np.ascontiguousarray(a[keep][:, lev], dtype=np.float64)
+    dt = np.float32 if (ua.dtype == np.float32 and va.dtype == np.float32) else np.float64
+    planes = [np.ascontiguousarray(a[keep][:, lev], dtype=dt)
               for a, lev in ((ua, iu), (va, iu), (ua, il), (va, il))]
     step = (times[1] - times[0]).total_seconds()
     if group_days == 'reference':
@@ -63,8 +64,10 @@ def calc_wnd_stat(engine, ua, va, levels, level_units, times, year, month, group
 
 
 def wind_stats_host(engine, planes, day_start=None):
-    """planes: 4 float64 arrays [n_samples, ...] (same trailing shape) -> [14, ...]."""
-    planes = [np.ascontiguousarray(p, dtype=np.float64) for p in planes]
+    """planes: 4 arrays [n_samples, ...] (same trailing shape) -> float64 [14, ...].  All float32: reduced in
+    float32 like xarray does on ERA5 files; otherwise in float64."""
+    f32 = all(np.asarray(p).dtype == np.float32 for p in planes)
+    planes = [np.ascontiguousarray(p, dtype=np.float32 if f32 else np.float64) for p in planes]
     n = planes[0].shape[0]
     shape = planes[0].shape[1:]
     npts = int(np.prod(shape))
@@ -75,8 +78,8 @@ def wind_stats_host(engine, planes, day_start=None):
     ptrs = (C.c_void_p * 4)(*[p.ctypes.data for p in planes])
     ds = None if day_start is None else np.ascontiguousarray(day_start, dtype=np.int32)
     nd = 0 if ds is None else len(ds) - 1
-    engine._ck(engine.L.tcr_wind_stats_host(engine.h, n, npts, ptrs, None if ds is None else ds.ctypes.data, nd,
-                                            out.ctypes.data))
+    fn = engine.L.tcr_wind_stats_f32_host if f32 else engine.L.tcr_wind_stats_host
+    engine._ck(fn(engine.h, n, npts, ptrs, None if ds is None else ds.ctypes.data, nd, out.ctypes.data))
     return out
 
 

@@ -83,6 +83,8 @@ class SyntheticEnv:
     basin_masks: dict = field(default_factory=dict)   # id -> [721,1440] float64 0/1
     seed: int = 0
     shape: str = 'era5'
+    blon: np.ndarray = None   # the bathymetry's own grid when it differs from the land mask's (intensity/geo.py:9-34)
+    blat: np.ndarray = None
 
     def cov_matrix(self, month):
         """Dense symmetric [4,4,nlat,nlon] view of one month's covariances."""
