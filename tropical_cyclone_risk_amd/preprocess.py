@@ -53,7 +53,8 @@ def calc_wnd_stat(engine, ua, va, levels, level_units, times, year, month, group
     keep = month_mask(times, year, month)
     t_sel = [t for t, k in zip(times, keep) if k]
     iu, il = pick_levels(levels, level_units)
-    dt = np.float32 if (ua.dtype == np.float32 and va.dtype == np.float32) else np.float64
+    is_f32 = lambda a: a.dtype.kind == 'f' and a.dtype.itemsize == 4        # any byte order (NetCDF-3 is big-endian)
+    dt = np.float32 if (is_f32(ua) and is_f32(va)) else np.float64
     planes = [np.ascontiguousarray(a[keep][:, lev], dtype=dt)
               for a, lev in ((ua, iu), (va, iu), (ua, il), (va, il))]
     step = (times[1] - times[0]).total_seconds()
@@ -66,7 +67,7 @@ def calc_wnd_stat(engine, ua, va, levels, level_units, times, year, month, group
 def wind_stats_host(engine, planes, day_start=None):
     """planes: 4 arrays [n_samples, ...] (same trailing shape) -> float64 [14, ...].  All float32: reduced in
     float32 like xarray does on ERA5 files; otherwise in float64."""
-    f32 = all(np.asarray(p).dtype == np.float32 for p in planes)
+    f32 = all(np.asarray(p).dtype.kind == 'f' and np.asarray(p).dtype.itemsize == 4 for p in planes)
     planes = [np.ascontiguousarray(p, dtype=np.float32 if f32 else np.float64) for p in planes]
     n = planes[0].shape[0]
     shape = planes[0].shape[1:]
