@@ -81,6 +81,8 @@ struct tcr_ctx {
     // workspaces
     double *d_fs = nullptr, *d_srec = nullptr;    // forcing tables, accepted-step records
     size_t fs_cap = 0, srec_cap = 0;
+    double *d_vrec = nullptr;                     // the v part of the step records, packed (k_integrate -> k_screen)
+    size_t vrec_cap = 0;
     int32_t *d_tiles = nullptr;
     size_t tiles_cap = 0;
     unsigned long long *d_queue = nullptr;      // work-queue heads and parked-storm counts of k_integrate's passes
@@ -495,6 +497,7 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
     if (grow(ctx, &ctx->d_fs, &ctx->fs_cap, ((size_t)n * ns * 4 * sizeof(R) + 7) / 8)) return -1;
     const int max_rk = P.max_rk_steps > 0 ? P.max_rk_steps : 64;
     if (grow(ctx, &ctx->d_srec, &ctx->srec_cap, (size_t)n * max_rk * REC)) return -1;
+    if (grow(ctx, &ctx->d_vrec, &ctx->vrec_cap, (size_t)n * max_rk * kVRec)) return -1;
     if (max_rk > 65535) return fail(ctx, "tcr_params.max_rk_steps must be <= 65535");
     {
         double *p = reinterpret_cast<double *>(ctx->d_sidx);        // [n][n_steps] uint16: step of each sample
@@ -515,7 +518,7 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
         KArgsT<R> a{};
         a.P = P; a.D = dev_fields(ctx); a.K = EK; a.n = n; a.n_dev = in->n_dev;
         a.lon0 = in->lon0; a.lat0 = in->lat0; a.v0 = in->v0; a.m0 = in->m0; a.h_bl = in->h_bl;
-        a.slot = in->slot; a.phases = in->phases; a.fs = fs; a.srec = ctx->d_srec; a.max_rk_steps = max_rk;
+        a.slot = in->slot; a.phases = in->phases; a.fs = fs; a.srec = ctx->d_srec; a.vrec = ctx->d_vrec; a.max_rk_steps = max_rk;
         a.n_valid = out.n_valid; a.status = out.status; a.nfev = out.nfev;
         a.n_accept = out.n_accept; a.n_reject = out.n_reject;
         a.queue = ctx->d_queue;
@@ -544,7 +547,7 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
     if (ev) HIPCHK(ctx, hipEventRecord(ev[2], st));
     {
         EArgsT<R> a{};
-        a.P = P; a.D = dev_fields(ctx); a.n = n; a.n_dev = in->n_dev; a.max_rk_steps = max_rk; a.srec = ctx->d_srec; a.fs = fs;
+        a.P = P; a.D = dev_fields(ctx); a.n = n; a.n_dev = in->n_dev; a.max_rk_steps = max_rk; a.srec = ctx->d_srec; a.vrec = ctx->d_vrec; a.fs = fs;
         a.slot = in->slot; a.n_valid = out.n_valid; a.status = out.status; a.n_accept = out.n_accept;
         a.lon = out.lon; a.lat = out.lat; a.v = out.v; a.m = out.m; a.vmax = out.vmax;
         a.envw = out.envw; a.flags = out.flags; a.pad_state = out.pad_state;
@@ -624,7 +627,7 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     for (auto &s : ctx->slots) { (void)hipFree(s.wind); (void)hipFree(s.thermo); (void)hipFree(s.rh); (void)hipFree(s.wind32); (void)hipFree(s.thermo32); }
     (void)hipFree(ctx->d_stat32); (void)hipFree(ctx->d_land); (void)hipFree(ctx->d_bathy); (void)hipFree(ctx->d_land32); (void)hipFree(ctx->d_bathy32);
     (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_run_mask); (void)hipFree(ctx->d_basin_masks);
-    (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_srec);
+    (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_srec); (void)hipFree(ctx->d_vrec);
     for (auto &ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
     (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_tab);
     (void)hipStreamDestroy(ctx->stream);

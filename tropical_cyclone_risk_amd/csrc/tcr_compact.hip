@@ -121,7 +121,13 @@ __global__ __launch_bounds__(256) void k_gather_seeds(GatherSeedArgs a)
         const double *sp = a.src.phases + (size_t)j * a.phases_per_storm;
         for (int k = lane; k < a.phases_per_storm; k += 64) dp[k] = sp[k];
     } else {
-        for (int k = lane; k < a.phases_per_storm; k += 64) dp[k] = phase_at(a.seed, a.year, a.cand0 + j, k);
+        // one Philox block yields the pair (2p, 2p + 1): a lane per pair, not per phase
+        for (int p = lane; 2 * p < a.phases_per_storm; p += 64) {
+            double p0, p1;
+            uniform2_raw(a.seed, a.year, a.cand0 + j, 2u, (uint32_t)p, p0, p1);
+            dp[2 * p] = p0;
+            if (2 * p + 1 < a.phases_per_storm) dp[2 * p + 1] = p1;
+        }
     }
 }
 

@@ -55,8 +55,12 @@ struct KArgsT {
     // that lands differently from the oracle's (oracle/parity.py)
     uint8_t *probe;
     int probe_cap;
+    // what accept test 1 needs of an accepted step, packed: t_old, h, t_new, v_old, K[0..6][v], - (12 doubles, 96 B);
+    // k_screen reads these instead of pulling the whole 288-byte records of every storm through the cache
+    double *vrec;                // [n][max_rk_steps][kVRec]
 };
 using KArgs = KArgsT<double>;
+constexpr int kVRec = 12;
 constexpr int kMaxPasses = 16;
 constexpr int kParkRec = 16;     // doubles per parked storm: t, h, t_new, ha, g, y[4], f[4], 6 x int32
 
@@ -253,6 +257,15 @@ constexpr int kWave = 64;
 #endif
 constexpr int kRunning = 99;
 template <typename R> constexpr int int_wps() { return sizeof(R) == 8 ? TCR_INT_WPS : TCR_INT_WPS_F32; }
+// Register cap of the integrator (build knob for the experiment in DESIGN.md §9): amdgpu_num_vgpr(N) makes the kernel
+// allocate 256 + (2N - 256) registers of the SIMD's 512, so that the small kernels of the batches other streams have in
+// flight (Fourier table, post-processing: 64-96 registers) could be resident on the same SIMD and issue in the
+// integrator's stalls.  Measured: the spills cost more than the overlap gains (N = 224 / 208 / 192: +4 % / 0 / +20 % per step).
+#ifdef TCR_INT_NUM_VGPR
+#define TCR_INT_CAP __attribute__((amdgpu_num_vgpr(TCR_INT_NUM_VGPR)))
+#else
+#define TCR_INT_CAP
+#endif
 
 // k_integrate: the sequential part of a storm — RK45 steps until the terminal event.
 //
@@ -270,7 +283,7 @@ template <typename R> constexpr int int_wps() { return sizeof(R) == 8 ? TCR_INT_
 // is accumulated in fp64 from the fp32 stage derivatives, and err < 1, the factor 0.9 err^-0.2 and the
 // min-step test are the fp64 expressions of the fp64 build (every (double) cast below is the identity there).
 template <typename R, bool AFFINE, bool PROBE, bool SPLIT>
-__global__ __launch_bounds__(kWave, (int_wps<R>())) void k_integrate(KArgsT<R> a)
+__global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate(KArgsT<R> a)
 {
     // Kl[(stage*4 + component)*64 + lane]
     __shared__ R Kl[7 * 4 * kWave];
@@ -483,6 +496,13 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) void k_integrate(KArgsT<R> a
                                 V4 kk; kk[0] = KS(j, 0); kk[1] = KS(j, 1); kk[2] = KS(j, 2); kk[3] = KS(j, 3);
                                 body[1 + j] = kk;
                             }
+                            double2 *vr = reinterpret_cast<double2 *>(a.vrec + (sid * (long long)a.max_rk_steps + nacc) * kVRec);
+                            vr[0] = make_double2(t, h);
+                            vr[1] = make_double2(t_new, (double)y[2]);
+                            vr[2] = make_double2((double)KS(0, 2), (double)KS(1, 2));
+                            vr[3] = make_double2((double)KS(2, 2), (double)KS(3, 2));
+                            vr[4] = make_double2((double)KS(4, 2), (double)KS(5, 2));
+                            vr[5] = make_double2((double)KS(6, 2), 0.0);
                         }
                         ++nacc;
                         const double t_old = t;
@@ -576,6 +596,7 @@ struct EArgsT {
     const int64_t *n_dev;        // optional device scalar: only the first min(n, *n_dev) storms exist; flags of the rest are set to 0
     int max_rk_steps;
     const double *srec;          // [n][max_rk_steps][step_rec_doubles<R>()]
+    const double *vrec;          // [n][max_rk_steps][kVRec]: the v part of every step record (k_screen)
     const R *fs;                 // [n][n_steps][4]
     const int32_t *slot;
     const int32_t *n_valid, *status, *n_accept;
@@ -840,15 +861,14 @@ __global__ __launch_bounds__(kScreenThreads) void k_screen(EArgsT<R> a)
     const bool clamp2d = n > 0 && t2d >= ts_at(P, n - 1);
     const int j2d = clamp2d ? n - 1 : (int)floor(t2d / step_out);
     bool any15 = false;
-    constexpr int REC = step_rec_doubles<R>();
-    const double *srec_storm = a.srec + sid * (int64_t)a.max_rk_steps * REC;
+    const double *vrec_storm = a.vrec + sid * (int64_t)a.max_rk_steps * kVRec;
     for (int j = l; j < nst && n > 0; j += kScreenGroup) {
-        const double *rj = srec_storm + (size_t)j * REC;
-        const R *body = rec_body<R>(rj);
-        const double t_old = rj[0], h64 = rj[1], t_new = rj[2];
-        const R hh = (R)h64, y0 = body[2];
-        R kq[7];
-        for (int q = 0; q < 7; ++q) kq[q] = body[4 + q * 4 + 2];
+        // (values were stored widened to fp64; narrowing back gives the R values k_dense reads from the full record)
+        const double2 *rj = reinterpret_cast<const double2 *>(vrec_storm + (size_t)j * kVRec);
+        const double2 r0 = rj[0], r1 = rj[1], r2 = rj[2], r3 = rj[3], r4 = rj[4], r5 = rj[5];
+        const double t_old = r0.x, h64 = r0.y, t_new = r1.x;
+        const R hh = (R)h64, y0 = (R)r1.y;
+        const R kq[7] = {(R)r2.x, (R)r2.y, (R)r3.x, (R)r3.y, (R)r4.x, (R)r4.y, (R)r5.x};
         R Q[4];
         for (int k = 0; k < 4; ++k) {
             R acc = R(0.0);
@@ -858,18 +878,35 @@ __global__ __launch_bounds__(kScreenThreads) void k_screen(EArgsT<R> a)
         const int i_lo = (j == 0) ? 0 : samples_upto(P, t_old);
         int i_hi = samples_upto(P, t_new);
         i_hi = i_hi < n ? i_hi : n;
-        for (int i = i_lo; i < i_hi; ++i) {
-            const double te = ts_at(P, i);
-            const R x = (R)((te - t_old) / h64);
+        // dense output of v at sample i, exactly as dense_at forms it: x = (t_i - t_old) / h
+        auto v_at = [&](int i) -> R {
+            const R x = (R)((ts_at(P, i) - t_old) / h64);
             const R p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
             R acc = R(0.0);
             acc += Q[0] * p1; acc += Q[1] * p2; acc += Q[2] * p3; acc += Q[3] * p4;
-            const R v = hh * acc + y0;
-            any15 = any15 || (v >= (R)P.v_thresh);
-            if (i == j2d) cap[g][0] = v;
-            if (i == j2d + 1) cap[g][1] = v;
-            if (i == n - 1) cap[g][2] = v;
+            return hh * acc + y0;
+        };
+        // `any(v >= v_thresh)`: this kernel is bound by fp64 issue and the division per sample is two thirds of the
+        // loop, so every sample is first judged with x = (t_i - t_old) * (1 / h) and Horner's form — within 1e-13 (fp32:
+        // 1e-5) of the exact value — and only a sample that lands within `band` of the threshold is evaluated exactly
+        // (a wave-uniform branch the compiler cannot turn into straight-line code): the decision is the exact one
+        const double rh = 1.0 / h64;
+        const R thr = (R)P.v_thresh, band = sizeof(R) == 8 ? R(1e-9) : R(2e-3);
+        for (int i = i_lo; i < i_hi; ++i) {
+            const R x = (R)((ts_at(P, i) - t_old) * rh);
+            const R v_f = hh * (x * (Q[0] + x * (Q[1] + x * (Q[2] + x * Q[3])))) + y0;
+            bool hit = v_f >= thr + band;
+            const bool amb = !hit && v_f >= thr - band;
+            if (__ballot(amb)) {
+                asm volatile("" ::: "memory");
+                if (amb) hit = v_at(i) >= thr;
+            }
+            any15 = any15 || hit;
         }
+        // the samples np.interp(2 d, res.t, v) can read: exact
+        if (i_lo <= j2d && j2d < i_hi) cap[g][0] = v_at(j2d);
+        if (i_lo <= j2d + 1 && j2d + 1 < i_hi) cap[g][1] = v_at(j2d + 1);
+        if (i_lo <= n - 1 && n - 1 < i_hi) cap[g][2] = v_at(n - 1);
     }
     int hit = any15 ? 1 : 0;
     for (int off = kScreenGroup / 2; off > 0; off >>= 1) hit |= __shfl_xor(hit, off);       // every lane takes part
