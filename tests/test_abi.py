@@ -45,6 +45,44 @@ def test_struct_layout_matches_header(built_lib):
     assert sizes == mine
 
 
+def test_integration_stub_is_complete():
+    """INTEGRATION.md's reference-side binding: the code block compiles, every name it uses is defined in it
+    (imported, assigned, a parameter, a builtin), every library function it calls is declared in the header, and its
+    ctypes mirrors have the sizes of the package's checked mirrors."""
+    import ast
+    import builtins
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    code = text.split('```python')[1].split('```')[0]
+    tree = ast.parse(code)
+    defined = set(dir(builtins))
+    for node in ast.walk(tree):
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            defined |= {(a.asname or a.name).split('.')[0] for a in node.names}
+        elif isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+            defined.add(node.name)
+            if isinstance(node, ast.FunctionDef):
+                defined |= {a.arg for a in node.args.args + node.args.kwonlyargs}
+        elif isinstance(node, ast.Lambda):
+            defined |= {a.arg for a in node.args.args}
+        elif isinstance(node, ast.Name) and isinstance(node.ctx, ast.Store):
+            defined.add(node.id)
+        elif isinstance(node, ast.comprehension):
+            defined |= {n.id for n in ast.walk(node.target) if isinstance(n, ast.Name)}
+    used = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
+    assert not (used - defined), sorted(used - defined)
+    called = set(re.findall(r'_L\.(tcr_[a-z_0-9]+)', code))
+    assert called and called <= set(_declared()), sorted(called - set(_declared()))
+    # struct mirrors: same sizes as the package's (which are checked against the C compiler's sizeof)
+    ns = {}
+    mirrors = code.split('def _f64')[0].replace("_L = C.CDLL('libtcrisk_hip.so')", '_L = None').replace('_L.tcr_last_error', '# ')
+    mirrors = '\n'.join(l for l in mirrors.splitlines() if not l.startswith(('import xarray', 'import namelist', 'from ')))
+    exec(compile(mirrors, 'INTEGRATION.md', 'exec'), ns)
+    from tropical_cyclone_risk_amd import _lib
+    for a, b in (('Grid', _lib.Grid), ('Params', _lib.Params), ('Storms', _lib.Storms), ('Tracks', _lib.Tracks), ('Seeds', _lib.Seeds)):
+        assert ctypes.sizeof(ns[a]) == ctypes.sizeof(b), a
+        assert [f[0] for f in ns[a]._fields_] == [f[0] for f in b._fields_], a
+
+
 def test_no_gpu_fails_loudly(built_lib):
     """Without a HIP device the product path must raise, not fall back."""
     import torch
