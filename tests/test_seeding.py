@@ -243,3 +243,33 @@ def test_run_py_is_rank_count_invariant(built_lib, tmp_path):
     for k in ('lon_trks', 'lat_trks', 'v_trks', 'm_trks', 'vmax_trks', 'u250_trks', 'tc_month', 'tc_basins', 'seeds_per_month'):
         assert np.array_equal(out['one'][k], out['two'][k], equal_nan=(out['one'][k].dtype.kind == 'f')), k
     assert out['one']['lon_trks'].shape == (24, 361)
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_path(built_lib, tmp_path):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU) — here two ranks
+    sharing this GPU with gloo as the collective backend: the step includes select / pack of the accepted tracks
+    and the deferred all-gather of survivor records; the JSON line carries the whole-job aggregate."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TCR_DIST_BACKEND='gloo')
+    out = {}
+    for world in (1, 2):
+        cmd = [sys.executable] + (['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr',
+                                   '127.0.0.1', '--master-port', '29531'] if world > 1 else []) + \
+              [os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', '4', '--warmup', '1', '--storms', '6000',
+               '--streams', '2', '--no-cpu-baseline']
+        r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[world] = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    one, two = out[1], out[2]
+    assert two['n_gpus'] == 2 and two['scaling'] == 'weak' and two['value'] > 0 and two['steps'] == 4
+    cfg = two['config']
+    # the same per-rank work: two ranks integrate twice the storms of one
+    assert abs(cfg['storm_steps_per_storm'] - one['config']['storm_steps_per_storm']) / one['config']['storm_steps_per_storm'] < 0.05
+    assert cfg['allgather_rows'] > 0 and cfg['allgather_rows_clipped'] == 0
+    # every accepted track of both ranks went through the all-gather
+    assert cfg['allgather_rows'] == round(cfg['accepted_fraction'] * 6000 * 4 * 2)
+    assert two['roofline']['frac'] > 0 and two['cpu_baseline'] is None and one['config']['allgather_rows'] is None

@@ -27,7 +27,7 @@ for k, cs in acc.items():
         e[c + '_per_dispatch'] = v / n
         e['dispatches_' + c] = n
     res[k] = e
-batches = {c: n for (k, c), s in disp.items() if k == 'tcr::k_dense' for n in [len(s)]}
+batches = {c: n for (k, c), s in disp.items() if k.startswith('tcr::k_dense') for n in [len(s)]}
 for k, e in res.items():
     for c in ('FETCH_SIZE', 'WRITE_SIZE', 'TCC_HIT_sum', 'TCC_MISS_sum', 'TCC_REQ_sum'):
         if c + '_per_dispatch' in e and batches.get(c):

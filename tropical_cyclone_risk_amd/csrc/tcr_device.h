@@ -524,7 +524,13 @@ __device__ __forceinline__ RhsT<R> rhs_eval_cached(CornerCacheT<R> &C, const Eva
     const CellT<R> tx = locate_t<R, AFFINE>(K.tx, lon), ty = locate_t<R, AFFINE>(K.ty, lat);
     const FsBracket fb = fs_bracket(K, t);
     FsPairT<R> fp;
+#ifdef TCR_ABLATE_FS_READ
+    // timing experiment of DESIGN.md §9 only (values are wrong): what the integrator would gain if the forcing-table
+    // read cost nothing.  The bracket arithmetic stays; the gather becomes a cheap per-lane constant.
+    for (int k = 0; k < 4 / FsPairT<R>::L; ++k) for (int q = 0; q < FsPairT<R>::L; ++q) { fp.a[k][q] = (R)(1e-3 * fb.lo); fp.b[k][q] = (R)(1e-3 * fb.lo); }
+#else
     fs_gather<R>(fs, fb, fp);
+#endif
     if (wx.i != C.wi || wy.i != C.wj) {
         gather<R, 14, kWindStride, Wd::W>(wind, RD(K.wx.n), wx, wy, C.CW);
         C.wi = wx.i; C.wj = wy.i;
