@@ -438,6 +438,8 @@ void host_eval_k(const tcr_ctx *ctx, EvalKT<R> &K, bool *all_affine)
         K.bathy = nullptr;
     }
     eval_k_scalars<R>(ctx->prm, K);
+    K.tw_same = (ctx->wg.lon == ctx->tg.lon && ctx->wg.lat == ctx->tg.lat) ? 1 : 0;       // same knots: the same cells and weights
+    K.pad_ = 0;
     *all_affine = K.wx.affine && K.wy.affine && K.tx.affine && K.ty.affine && K.hx.affine && K.hy.affine &&
                   K.bx.affine && K.by.affine;
 }

@@ -103,6 +103,8 @@ struct EvalKT {
     R y_alpha[2], m_alpha[2], alpha_max[2], alpha_min[2], steering_coefs[2];
     double total_time, tstep, inv_tstep;        // time stays fp64 in both instantiations
     int n_steps, coupled_track;
+    int tw_same;             // the thermo grid IS the wind grid (ERA5: both 1 degree): one cell search serves both
+    int pad_;
 };
 using EvalK = EvalKT<double>;
 
@@ -378,7 +380,7 @@ struct RhsT {
     R d[4];     // d lon/dt, d lat/dt, dv/dt, dm/dt
     R w[4];     // raw env winds at the point (what _env_winds returns)
     R alpha;    // ocean feedback (probe only)
-    R shear, vpot, chi;   // what the ventilation gate needs (coupled_fast.py:238-244)
+    R vpot, chi;   // what the ventilation gate needs besides the raw winds (coupled_fast.py:238-244)
     int dec;    // decision probe (tests only; dead code elsewhere): bit0 `land == 1`, bit1 PI != 0, bit2 |land - 1| <= 1e-12
 };
 
@@ -388,10 +390,6 @@ __device__ __forceinline__ void rhs_tail(const EvalKT<R> &K, R h_bl, R lat, R v,
                                          const R (&th)[4], const R (&lb)[2], RhsT<R> &r)
 {
     const R z = R(0.0);
-    {
-        const R du = r.w[0] - r.w[2], dw = r.w[1] - r.w[3];
-        r.shear = sqrt(du * du + dw * dw);
-    }
     // steering coefficients
     R c0, c1;
     {
@@ -477,7 +475,8 @@ __device__ __forceinline__ RhsT<R> rhs_eval(const EvalKT<R> &K, const R *__restr
     typedef Widths<R> Wd;
     // ---- address generation: pure ALU on affine grids
     const CellT<R> wx = locate_t<R, AFFINE>(K.wx, lon), wy = locate_t<R, AFFINE>(K.wy, lat);
-    const CellT<R> tx = locate_t<R, AFFINE>(K.tx, lon), ty = locate_t<R, AFFINE>(K.ty, lat);
+    CellT<R> tx = wx, ty = wy;
+    if (!RD(K.tw_same)) { tx = locate_t<R, AFFINE>(K.tx, lon); ty = locate_t<R, AFFINE>(K.ty, lat); }      // wave-uniform
     const FsBracket fb = fs_bracket(K, t);
     // ---- one round of independent gathers
     CornersT<R, 14, Wd::W> CW;
@@ -521,7 +520,8 @@ __device__ __forceinline__ RhsT<R> rhs_eval_cached(CornerCacheT<R> &C, const Eva
 {
     typedef Widths<R> Wd;
     const CellT<R> wx = locate_t<R, AFFINE>(K.wx, lon), wy = locate_t<R, AFFINE>(K.wy, lat);
-    const CellT<R> tx = locate_t<R, AFFINE>(K.tx, lon), ty = locate_t<R, AFFINE>(K.ty, lat);
+    CellT<R> tx = wx, ty = wy;
+    if (!RD(K.tw_same)) { tx = locate_t<R, AFFINE>(K.tx, lon); ty = locate_t<R, AFFINE>(K.ty, lat); }      // wave-uniform
     const FsBracket fb = fs_bracket(K, t);
     FsPairT<R> fp;
 #ifdef TCR_ABLATE_FS_READ

@@ -531,7 +531,10 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
             } else if (live && slot == 0) {
                 // fresh storm, fun(t0, y0): ventilation gate (coupled_fast.py:238-244) on the same
                 // lookups, then RungeKutta.__init__'s f0 and select_initial_step part 1 (common.py:112-126)
-                if (r.vpot > R(0) && r.shear * r.chi / r.vpot >= R(1)) {
+                // S = |shear| of the raw env winds (coupled_fast.py:115-122): only this branch needs it
+                const R sdu = r.w[0] - r.w[2], sdw = r.w[1] - r.w[3];
+                const R shear = sqrt(sdu * sdu + sdw * sdw);
+                if (r.vpot > R(0) && shear * r.chi / r.vpot >= R(1)) {
                     status = TCR_STATUS_GATED;
                     finalize();
                     fresh = false;
