@@ -246,6 +246,37 @@ def test_run_py_is_rank_count_invariant(built_lib, tmp_path):
 
 
 @pytest.mark.gpu
+def test_run_tracks_fp32_knob(golden_env, built_lib):
+    """namelist.gpu_dtype = 'f32' runs the product's accept loop on the fp32 variant (BASELINE config 5): the 9-tuple
+    is float64 like the reference's, the kept candidates are the fp64 run's except where an accept decision flipped
+    (0.1 % of the accepted tracks in the 100k study), and the rows agree to the fp32 tolerance."""
+    import types
+    from tropical_cyclone_risk_amd import compute, namelist
+    from tropical_cyclone_risk_amd.basins import TC_Basin
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    nl32 = types.SimpleNamespace(**{k: getattr(namelist, k) for k in dir(namelist) if not k.startswith('__')})
+    nl32.gpu_dtype = 'f32'
+    out = {}
+    for tag, nl in (('f64', namelist), ('f32', nl32)):
+        eng = TCEngine('NA', device=0, nl=nl).stage_env(golden_env)
+        info = {}
+        out[tag] = (compute.run_tracks(2003, 60, TC_Basin('NA'), engine=eng, per_rank=4096, nl=nl, info=info), info['cand'])
+        eng.close()
+    (a, ca), (b, cb) = out['f64'], out['f32']
+    assert b[0].dtype == np.float64 and b[0].shape == (60, 361)
+    same = np.intersect1d(ca, cb)
+    assert len(same) >= 58                                             # at most a flipped decision or two
+    ia, ib = np.searchsorted(ca, same), np.searchsorted(cb, same)
+    nva, nvb = (~np.isnan(a[0][ia])).sum(1), (~np.isnan(b[0][ib])).sum(1)
+    ok = np.abs(nva - nvb) <= 1
+    assert ok.mean() > 0.9
+    m = np.minimum(nva, nvb)
+    dv = [np.abs(a[2][i, :k] - b[2][j, :k]).max() for i, j, k, o in zip(ia, ib, m, ok) if o]
+    assert np.median(dv) < 1e-3 and np.percentile(dv, 90) < 0.5
+    assert np.array_equal(a[6][ia], b[6][ib]) and list(a[7][ia]) == list(b[7][ib])
+
+
+@pytest.mark.gpu
 def test_bench_multi_rank_path(built_lib, tmp_path):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU) — here two ranks
     sharing this GPU with gloo as the collective backend: the step includes select / pack of the accepted tracks

@@ -128,7 +128,7 @@ class GpuRound:
         self.eng = engine
         self.year = int(year)
         self.seed = experiment_seed
-        self.pipe = DevicePipeline(engine, per_rank, per_rank, tc_rows_only=True)
+        self.pipe = DevicePipeline(engine, per_rank, per_rank, tc_rows_only=True, dtype=getattr(engine.nl, 'gpu_dtype', 'f64'))
         # every candidate of a round could be accepted: 26 kB per row
         self.packed = torch.zeros(per_rank, ROW_VARS * engine.n_steps + N_META, dtype=torch.float64, device=self.pipe.dev)
         self.ar = torch.arange(per_rank, device=self.pipe.dev)

@@ -167,20 +167,24 @@ __global__ __launch_bounds__(kFsThreads) void k_fourier_periodic(tcr_params P, i
     const double2 *__restrict__ pfs = pf + storm * 4 * N;       // wave-uniform
     R *out = fs + storm * ns * 4;
     for (int base = 0; base < ns; base += kFsThreads * kFsPerThread) {
-        int kk[kFsPerThread], j[kFsPerThread];
+        // (n * k) mod period, built incrementally and kept as the byte offset of the table entry; the wrap is an
+        // unsigned min (j < period ? j : j - period) — three integer instructions per (sample, harmonic) instead of five
+        unsigned kk16[kFsPerThread], j16[kFsPerThread];
+        const unsigned p16 = (unsigned)period * (unsigned)sizeof(double2);
         double acc[kFsPerThread][4];
 #pragma unroll
         for (int u = 0; u < kFsPerThread; ++u) {
-            kk[u] = (base + u * kFsThreads + (int)threadIdx.x) % period;
-            j[u] = 0;                                            // (n * k) mod period, built incrementally
+            kk16[u] = (unsigned)((base + u * kFsThreads + (int)threadIdx.x) % period) * (unsigned)sizeof(double2);
+            j16[u] = 0;
             acc[u][0] = acc[u][1] = acc[u][2] = acc[u][3] = 0.0;
         }
         for (int h = 0; h < N; ++h) {
             const double2 b0 = pfs[h * 4 + 0], b1 = pfs[h * 4 + 1], b2 = pfs[h * 4 + 2], b3 = pfs[h * 4 + 3];
 #pragma unroll
             for (int u = 0; u < kFsPerThread; ++u) {
-                j[u] += kk[u]; if (j[u] >= period) j[u] -= period;
-                const double2 a = tab[j[u]];
+                j16[u] += kk16[u];
+                j16[u] = min(j16[u], j16[u] - p16);
+                const double2 a = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(tab) + j16[u]);
                 // sin(A + B) = sinA cosB + cosA sinB, accumulated with explicit FMAs (2 per term)
                 acc[u][0] = fma(a.x, b0.y, fma(a.y, b0.x, acc[u][0])); acc[u][1] = fma(a.x, b1.y, fma(a.y, b1.x, acc[u][1]));
                 acc[u][2] = fma(a.x, b2.y, fma(a.y, b2.x, acc[u][2])); acc[u][3] = fma(a.x, b3.y, fma(a.y, b3.x, acc[u][3]));
