@@ -356,6 +356,33 @@ def test_wind_stats_float32_path_is_what_numpy_does():
     assert np.array_equal(o64[4], ((y[0] - y[0].mean(0)) ** 2).mean(0))
 
 
+def test_multi_file_monthly_inputs(tmp_path):
+    """preprocess.MultiFile = xr.open_mfdataset(fns, concat_dim="time", combine="nested") (util/input.py:14-21):
+    records of several files concatenated in list order, each time axis decoded with its own units."""
+    from scipy.io import netcdf_file
+    from tropical_cyclone_risk_amd import preprocess as pp
+    rng = np.random.default_rng(1)
+    recs = rng.normal(size=(5, 3, 4))
+    spec = [(slice(0, 2), 'days since 2001-01-01', [14.0, 45.0]), (slice(2, 5), 'hours since 2001-01-01', [73 * 24.0, 104 * 24.0, 134 * 24.0])]
+    fns = []
+    for j, (sl, units, tv) in enumerate(spec):
+        fn = str(tmp_path / ('v_%d.nc' % j)); fns.append(fn)
+        with netcdf_file(fn, 'w', version=2) as f:
+            f.createDimension('time', len(tv)); f.createDimension('lat', 3); f.createDimension('lon', 4)
+            v = f.createVariable('time', 'd', ('time',)); v[:] = tv; v.units = units; v.calendar = 'standard'
+            v = f.createVariable('lat', 'd', ('lat',)); v[:] = [0, 1, 2]
+            v = f.createVariable('lon', 'd', ('lon',)); v[:] = [0, 1, 2, 3]
+            v = f.createVariable('x', 'd', ('time', 'lat', 'lon')); v[:] = recs[sl]
+    m = pp.MultiFile(fns)
+    assert [(t.month, t.day) for t in m.times] == [(1, 15), (2, 15), (3, 15), (4, 15), (5, 15)]
+    assert np.array_equal(m['x'], recs) and np.array_equal(m['lat'], [0, 1, 2])
+    for i in range(5):
+        assert np.array_equal(m.record('x', i), recs[i])
+    assert np.array_equal(pp.MultiFile(fns[0])['x'], recs[:2])
+    with pytest.raises(ValueError, match='time order'):
+        pp.MultiFile(fns[::-1])
+
+
 def test_wind_stats_host_logic():
     from tropical_cyclone_risk_amd import preprocess as pp
     times = [datetime.datetime(2001, 1, 30) + datetime.timedelta(hours=12 * k) for k in range(8)]

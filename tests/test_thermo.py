@@ -147,9 +147,13 @@ def test_file_drivers_wind_and_thermo(cases, table, built_lib, tmp_path):
     _nc3(str(tmp_path / 'sp.nc'), d2, dict(ax, sp=(('time', 'latitude', 'longitude'), np.stack([psl, psl]), dict(units='Pa'))))
     d3 = dict(d2, level=len(p))
     axl = dict(ax, level=(('level',), p[::-1] / 100.0, dict(units='hPa')))              # top-down in hPa, as ERA5 delivers
-    _nc3(str(tmp_path / 't.nc'), d3, dict(axl, t=(('time', 'level', 'latitude', 'longitude'), np.stack([T[::-1], T[::-1]]), {})))
+    # temperature comes as two files of one record each (open_mfdataset over a sorted glob, util/input.py:14-58)
+    d31 = dict(d3, time=1)
+    for j, day in enumerate(tm):
+        ax1 = dict(axl, time=(('time',), np.array([day]), dict(units='days since 2001-01-01', calendar='standard')))
+        _nc3(str(tmp_path / ('t_%d.nc' % j)), d31, dict(ax1, t=(('time', 'level', 'latitude', 'longitude'), T[::-1][None], {})))
     _nc3(str(tmp_path / 'q.nc'), d3, dict(axl, q=(('time', 'level', 'latitude', 'longitude'), np.stack([r[::-1], r[::-1]]), {})))
-    out = pp.gen_thermo(eng, str(tmp_path / 'sst.nc'), str(tmp_path / 'sp.nc'), str(tmp_path / 't.nc'), str(tmp_path / 'q.nc'),
+    out = pp.gen_thermo(eng, str(tmp_path / 'sst.nc'), [str(tmp_path / 'sp.nc')], [str(tmp_path / 't_0.nc'), str(tmp_path / 't_1.nc')], str(tmp_path / 'q.nc'),
                         str(tmp_path / 'thermo.nc'), nl, table=(table['p'], table['s'], table['T']))
     ds = fields._Dataset(out)
     assert ds['vmax'].shape == (2, nla, nlo)

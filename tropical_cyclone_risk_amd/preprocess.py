@@ -229,20 +229,57 @@ def _cov_names():
     return [cov_name(i, j) for i in range(4) for j in range(i + 1)]
 
 
+class MultiFile:
+    """`xr.open_mfdataset(fns, concat_dim="time", combine="nested")` (util/input.py:14-21) over the dataset facade:
+    one file or a list of files of one variable; records are concatenated along time in the order of the list (the
+    reference passes its sorted glob), coordinates and attributes come from the first file, and every file's time axis
+    is decoded with its own units / calendar."""
+
+    def __init__(self, fns):
+        from . import fields
+        fns = [fns] if isinstance(fns, str) else list(fns)
+        if not fns:
+            raise ValueError('no input file')
+        self.parts = [fields._Dataset(f) for f in fns]
+        self.attrs = self.parts[0].attrs
+        self.n_time = [len(np.atleast_1d(p['time'])) for p in self.parts]
+        self.times = [t for p in self.parts for t in _datetimes(fields.TimeAxis(p['time'], p.attrs['time']))]
+        if any(b < a for a, b in zip(self.times, self.times[1:])):
+            raise ValueError('files are not in time order: %s' % fns)
+
+    def __getitem__(self, k):
+        first = np.asarray(self.parts[0][k])
+        if len(self.parts) == 1 or first.ndim == 0 or first.shape[0] != self.n_time[0] or k in ('lat', 'lon', 'latitude', 'longitude'):
+            return self.parts[0][k]                       # a coordinate: the first file's
+        return np.concatenate([np.asarray(p[k]) for p in self.parts], axis=0)
+
+    def record(self, k, i):
+        """Record i (along the concatenated time axis) of variable k without concatenating the files."""
+        for p, n in zip(self.parts, self.n_time):
+            if i < n:
+                return np.asarray(p[k])[i]
+            i -= n
+        raise IndexError(i)
+
+
 def gen_thermo(engine, fn_sst, fn_mslp, fn_temp, fn_sp_hum, out_fn, nl=None, table=None):
     """thermo/calc_thermo.gen_thermo + compute_thermo (:24-117) for monthly sst / mslp / temperature /
     specific-humidity files: sst is regridded bilinearly (after nan_to_num) onto the atmospheric grid
     (:37-41, Celsius -> Kelvin by the units attribute), PI / chi / rh_mid come from the GPU kernels, and
     records are stamped on the 15th of their month (:101-106).  Axes must ascend in latitude (the
-    reference's RectBivariateSpline regridding needs that too)."""
+    reference's RectBivariateSpline regridding needs that too).  Every fn_* is one file or a list of files in time
+    order, as the reference's `open_mfdataset` over its sorted glob (util/input.py:14-58)."""
     from . import fields, namelist as default_namelist
     nl = nl or default_namelist
     vk = nl.var_keys[nl.dataset_type]
     if table is not None:
         stage_entropy_table(engine, *table)
-    ds_sst, ds_psl, ds_ta, ds_q = (fields._Dataset(f) for f in (fn_sst, fn_mslp, fn_temp, fn_sp_hum))
+    ds_sst, ds_psl, ds_ta, ds_q = (MultiFile(f) for f in (fn_sst, fn_mslp, fn_temp, fn_sp_hum))
     dt_start, dt_end = _bounding_times(nl)
-    times = _datetimes(fields.TimeAxis(ds_psl['time'], ds_psl.attrs['time']))
+    times = ds_psl.times
+    for d in (ds_sst, ds_ta, ds_q):
+        if d.times != times:
+            raise ValueError('the monthly variables do not share one time axis')
     keep = [i for i, t in enumerate(times) if dt_start <= t <= dt_end]
     lon_a, lat_a = np.asarray(ds_ta[vk['lon']], dtype=np.float64), np.asarray(ds_ta[vk['lat']], dtype=np.float64)
     lev = ds_ta[vk['lvl']]
@@ -250,11 +287,12 @@ def gen_thermo(engine, fn_sst, fn_mslp, fn_temp, fn_sp_hum, out_fn, nl=None, tab
     celsius = 'C' in str(ds_sst.attrs[vk['sst']].get('units', 'K'))
     vmax, chi, rh = [], [], []
     for i in keep:
-        sst = fields.interp_2d_grid(ds_sst[vk['lon']], ds_sst[vk['lat']], np.nan_to_num(np.asarray(ds_sst[vk['sst']][i], dtype=np.float64)),
+        sst = fields.interp_2d_grid(ds_sst[vk['lon']], ds_sst[vk['lat']], np.nan_to_num(np.asarray(ds_sst.record(vk['sst'], i), dtype=np.float64)),
                                     lon_a, lat_a)
         if celsius:
             sst = sst + 273.15
-        v, c, r = compute_thermo(engine, sst, ds_psl[vk['mslp']][i], lev, lev_units, ds_ta[vk['temp']][i], ds_q[vk['sp_hum']][i], nl)
+        v, c, r = compute_thermo(engine, sst, ds_psl.record(vk['mslp'], i), lev, lev_units, ds_ta.record(vk['temp'], i),
+                                 ds_q.record(vk['sp_hum'], i), nl)
         vmax.append(v); chi.append(c); rh.append(r)
     stamps = [datetime.datetime(times[i].year, times[i].month, 15) for i in keep]
     year0 = stamps[0].year
@@ -275,7 +313,7 @@ def glob_prefix(nl, var_key):
 
 def run_preprocessing(engine, nl=None, table=None):
     """What the reference's run.py does before the downscaling (run.py:14-15): write env_wnd_*.nc and
-    thermo_*.nc next to the data unless they exist.  Monthly variables must be one file each."""
+    thermo_*.nc next to the data unless they exist."""
     import os
     from . import fields, namelist as default_namelist
     nl = nl or default_namelist
@@ -289,10 +327,9 @@ def run_preprocessing(engine, nl=None, table=None):
     if not os.path.exists(fl['thermo']):
         one = {}
         for k in ('sst', 'mslp', 'temp', 'sp_hum'):
-            f = glob_prefix(nl, vk[k])
-            if len(f) != 1:
-                raise NotImplementedError('%d files for %s: this driver reads one file per monthly variable' % (len(f), vk[k]))
-            one[k] = f[0]
+            one[k] = glob_prefix(nl, vk[k])                  # all files of the variable, in name order (input._load_var)
+            if not one[k]:
+                raise FileNotFoundError('no %s file under %s' % (vk[k], nl.base_directory))
         gen_thermo(engine, one['sst'], one['mslp'], one['temp'], one['sp_hum'], fl['thermo'], nl,
                    table=table or load_entropy_table(nl=nl))
         print('Saved %s' % fl['thermo'])
