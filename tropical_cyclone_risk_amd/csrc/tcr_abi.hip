@@ -77,7 +77,7 @@ struct tcr_ctx {
     double *d_land = nullptr, *d_bathy = nullptr;   // separate planes when the two grids differ (split_static)
     float *d_land32 = nullptr, *d_bathy32 = nullptr;
     bool split_static = false;
-    uint8_t *d_run_mask = nullptr, *d_basin_masks = nullptr;
+    uint8_t *d_mask_bits = nullptr;             // the eight mask planes as the bits of one byte per grid point
     // workspaces
     double *d_fs = nullptr, *d_srec = nullptr;    // forcing tables, accepted-step records
     size_t fs_cap = 0, srec_cap = 0;
@@ -218,7 +218,7 @@ DevFields dev_fields(const tcr_ctx *ctx)
     D.wg = dev_grid(ctx->wg); D.tg = dev_grid(ctx->tg); D.hg = dev_grid(ctx->hg); D.mg = dev_grid(ctx->mg);
     D.rg = dev_grid(ctx->rg);
     D.slots = ctx->d_slots; D.n_slots = (int)ctx->slots.size();
-    D.run_mask = ctx->d_run_mask; D.basin_masks = ctx->d_basin_masks;
+    D.mask_bits = ctx->d_mask_bits;
     D.all_affine = (ctx->wg.affine_lon && ctx->wg.affine_lat && ctx->tg.affine_lon && ctx->tg.affine_lat &&
                     ctx->hg.affine_lon && ctx->hg.affine_lat &&
                     (!ctx->split_static || (ctx->bg.affine_lon && ctx->bg.affine_lat))) ? 1 : 0;
@@ -569,7 +569,9 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
             if (tcr_compact_dev(ctx, n, out.flags, TCR_FLAG_IS_TC, n, ctx->d_tc_idx, ctx->d_tc_count, st)) return -1;
             a.list = ctx->d_tc_idx; a.count = ctx->d_tc_count;
         }
-        hipLaunchKernelGGL(k_dense<R>, dim3((unsigned)n), dim3(kWave), 0, st, a, ctx->d_sidx);
+        // k_dense, TC rows only: a bounded grid of waves walks the device-side list (one wave per storm otherwise)
+        const unsigned gx = out.tc_rows_only ? (unsigned)(n < 16384 ? n : 16384) : (unsigned)n;
+        hipLaunchKernelGGL(k_dense<R>, dim3(gx), dim3(kWave), 0, st, a, ctx->d_sidx);
         if (affine) hipLaunchKernelGGL((k_emit<R, true>), dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
         else hipLaunchKernelGGL((k_emit<R, false>), dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
         hipLaunchKernelGGL(k_flags<R>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, n, out.n_valid,
@@ -628,7 +630,7 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     }
     for (auto &s : ctx->slots) { (void)hipFree(s.wind); (void)hipFree(s.thermo); (void)hipFree(s.rh); (void)hipFree(s.wind32); (void)hipFree(s.thermo32); }
     (void)hipFree(ctx->d_stat32); (void)hipFree(ctx->d_land); (void)hipFree(ctx->d_bathy); (void)hipFree(ctx->d_land32); (void)hipFree(ctx->d_bathy32);
-    (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_run_mask); (void)hipFree(ctx->d_basin_masks);
+    (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_mask_bits);
     (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_srec); (void)hipFree(ctx->d_vrec);
     for (auto &ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
     (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_tab);
@@ -761,13 +763,15 @@ int tcr_masks_upload(tcr_ctx *ctx, const tcr_grid *mg, const uint8_t *run_mask,
     if (!run_mask || !basin_masks) return fail(ctx, "tcr_masks_upload: NULL mask");
     if (stage_grid(ctx, ctx->mg, mg, "mask")) return -1;
     const size_t np = (size_t)mg->nlon * mg->nlat;
-    if (!ctx->d_run_mask && dev_alloc(ctx, &ctx->d_run_mask, np)) return -1;
-    if (!ctx->d_basin_masks && dev_alloc(ctx, &ctx->d_basin_masks, np * TCR_N_BASINS)) return -1;
-    HIPCHK(ctx, hipMemcpy(ctx->d_run_mask, run_mask, np, hipMemcpyHostToDevice));
+    static_assert(TCR_N_BASINS == 7, "seven basin masks + the run basin's fill one byte");
+    std::vector<uint8_t> bits(np, 0);
     for (int b = 0; b < TCR_N_BASINS; ++b) {
         if (!basin_masks[b]) return fail(ctx, "tcr_masks_upload: NULL basin mask");
-        HIPCHK(ctx, hipMemcpy(ctx->d_basin_masks + np * b, basin_masks[b], np, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < np; ++i) bits[i] |= (uint8_t)((basin_masks[b][i] ? 1u : 0u) << b);
     }
+    for (size_t i = 0; i < np; ++i) bits[i] |= (uint8_t)((run_mask[i] ? 1u : 0u) << 7);
+    if (!ctx->d_mask_bits && dev_alloc(ctx, &ctx->d_mask_bits, np)) return -1;
+    HIPCHK(ctx, hipMemcpy(ctx->d_mask_bits, bits.data(), np, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -1219,7 +1223,7 @@ int tcr_gather_seeds_dev(tcr_ctx *ctx, const tcr_seeds *src, const int32_t *idx,
     GatherSeedArgs a{};
     a.src = *src; a.dst = *dst; a.idx = idx; a.n_out = n_out; a.phases_per_storm = 4 * ctx->prm.n_series;
     a.seed = experiment_seed; a.year = year; a.cand0 = cand0; a.count = count;
-    const int64_t threads = n_out * 64;
+    const int64_t threads = n_out * kGatherLanes;
     hipLaunchKernelGGL(k_gather_seeds, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
     return 0;

@@ -102,14 +102,18 @@ struct GatherSeedArgs {
     const int64_t *count;       // device scalar from tcr_compact_dev: rows >= *count are not valid (NULL: all are)
 };
 
+// 16 lanes per output row (four rows per wave: the kernel is bound by its two dependent loads — idx[row], then
+// src[idx] — so rows per wave is what counts): lane 15 copies the scalars, the others draw / copy the phases.
+constexpr int kGatherLanes = 16;
+
 __global__ __launch_bounds__(256) void k_gather_seeds(GatherSeedArgs a)
 {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t row = gid / 64;           // one wave per output row: lanes copy the phases
-    const int lane = (int)(gid & 63);
+    const int64_t row = gid / kGatherLanes;
+    const int lane = (int)(gid % kGatherLanes);
     if (row >= a.n_out || (a.count && row >= *a.count)) return;
     const int32_t j = a.idx[row];
-    if (lane == 0) {
+    if (lane == kGatherLanes - 1) {
         a.dst.lon0[row] = a.src.lon0[j]; a.dst.lat0[row] = a.src.lat0[j];
         a.dst.v0[row] = a.src.v0[j]; a.dst.m0[row] = a.src.m0[j]; a.dst.h_bl[row] = a.src.h_bl[j];
         a.dst.slot[row] = a.src.slot[j];
@@ -119,10 +123,10 @@ __global__ __launch_bounds__(256) void k_gather_seeds(GatherSeedArgs a)
     double *dp = a.dst.phases + (size_t)row * a.phases_per_storm;
     if (a.src.phases) {
         const double *sp = a.src.phases + (size_t)j * a.phases_per_storm;
-        for (int k = lane; k < a.phases_per_storm; k += 64) dp[k] = sp[k];
+        for (int k = lane; k < a.phases_per_storm; k += kGatherLanes) dp[k] = sp[k];
     } else {
         // one Philox block yields the pair (2p, 2p + 1): a lane per pair, not per phase
-        for (int p = lane; 2 * p < a.phases_per_storm; p += 64) {
+        for (int p = lane; 2 * p < a.phases_per_storm; p += kGatherLanes) {
             double p0, p1;
             uniform2_raw(a.seed, a.year, a.cand0 + j, 2u, (uint32_t)p, p0, p1);
             dp[2 * p] = p0;

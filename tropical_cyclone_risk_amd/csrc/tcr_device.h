@@ -82,8 +82,7 @@ struct DevFields {
     DevGrid wg, tg, hg, mg, rg;   // wind, thermo, static hi-res (land [+ bathymetry]), basin masks, (uncropped) rh grid
     const DevSlot *slots;    // device array
     int n_slots;
-    const uint8_t *run_mask; // [nlat_m][nlon_m]
-    const uint8_t *basin_masks;   // [7][nlat_m][nlon_m]
+    const uint8_t *mask_bits;     // [nlat_m][nlon_m]: bit b < 7 = basin mask b (sorted ids), bit 7 = the run basin's mask
     int all_affine;          // wind, thermo and static axes are all affine
 };
 

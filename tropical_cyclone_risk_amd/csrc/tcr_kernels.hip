@@ -640,44 +640,48 @@ template <typename R>
 __global__ __launch_bounds__(kWave) void k_dense(EArgsT<R> a, uint16_t *__restrict__ sidx)
 {
     const tcr_params &P = a.P;
-    if (a.list && (int64_t)blockIdx.x >= *a.count) return;
-    if (!a.list && (int64_t)blockIdx.x >= n_eff(a.n, a.n_dev)) {
-        if (threadIdx.x == 0) a.flags[blockIdx.x] = 0;
-        return;
-    }
-    const int64_t sid = a.list ? (int64_t)a.list[blockIdx.x] : (int64_t)blockIdx.x;
-    const int ns = P.n_steps;
-    const int n = a.n_valid[sid];
-    int nst = a.n_accept[sid];
-    nst = nst < a.max_rk_steps ? nst : a.max_rk_steps;
-    if (threadIdx.x == 0) a.flags[sid] = 0;
-    constexpr int REC = step_rec_doubles<R>();
-    typedef typename VecT<R, 4>::type V4;
-    const int c = threadIdx.x & 3;
-    for (int j0 = 0; j0 < nst; j0 += kWave / 4) {
-        const int j = j0 + (threadIdx.x >> 2);
-        const bool on = j < nst;
-        double *rj = const_cast<double *>(a.srec) + (sid * (int64_t)a.max_rk_steps + (on ? j : 0)) * REC;
-        R *body = reinterpret_cast<R *>(rj + kStepHdr);
-        R kq[7];
-        for (int q = 0; q < 7; ++q) kq[q] = body[4 + q * 4 + c];
-        const double t_old = rj[0], t_new = rj[2];
-        R Q[4];
-        for (int k = 0; k < 4; ++k) {
-            R acc = R(0.0);
-            for (int q = 0; q < 7; ++q) acc += kq[q] * R(RK_P[q][k]);
-            Q[k] = acc;
+    // work items: the listed storms (TC-rows-only: a bounded grid walks the list) or every row of the batch
+    const int64_t n_items = a.list ? *a.count : a.n;
+    const int64_t n_exist = a.list ? n_items : n_eff(a.n, a.n_dev);
+    for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        if (item >= n_exist) {
+            if (threadIdx.x == 0) a.flags[item] = 0;
+            continue;
         }
-        // (all loads of the wave are complete here: Q depends on them)
-        if (on) {
-            V4 qv; qv[0] = Q[0]; qv[1] = Q[1]; qv[2] = Q[2]; qv[3] = Q[3];
-            *reinterpret_cast<V4 *>(body + 4 + c * 4) = qv;
-            if (c == 0) {
-                // samples of this step: t_old < ts <= t_new (the first step also owns ts = 0)
-                const int i_lo = (j == 0) ? 0 : samples_upto(P, t_old);
-                int i_hi = samples_upto(P, t_new);
-                i_hi = i_hi < n ? i_hi : n;
-                for (int i = i_lo; i < i_hi; ++i) sidx[(size_t)sid * ns + i] = (uint16_t)j;
+        const int64_t sid = a.list ? (int64_t)a.list[item] : item;
+        const int ns = P.n_steps;
+        const int n = a.n_valid[sid];
+        int nst = a.n_accept[sid];
+        nst = nst < a.max_rk_steps ? nst : a.max_rk_steps;
+        if (threadIdx.x == 0) a.flags[sid] = 0;
+        constexpr int REC = step_rec_doubles<R>();
+        typedef typename VecT<R, 4>::type V4;
+        const int c = threadIdx.x & 3;
+        for (int j0 = 0; j0 < nst; j0 += kWave / 4) {
+            const int j = j0 + (threadIdx.x >> 2);
+            const bool on = j < nst;
+            double *rj = const_cast<double *>(a.srec) + (sid * (int64_t)a.max_rk_steps + (on ? j : 0)) * REC;
+            R *body = reinterpret_cast<R *>(rj + kStepHdr);
+            R kq[7];
+            for (int q = 0; q < 7; ++q) kq[q] = body[4 + q * 4 + c];
+            const double t_old = rj[0], t_new = rj[2];
+            R Q[4];
+            for (int k = 0; k < 4; ++k) {
+                R acc = R(0.0);
+                for (int q = 0; q < 7; ++q) acc += kq[q] * R(RK_P[q][k]);
+                Q[k] = acc;
+            }
+            // (all loads of the wave are complete here: Q depends on them)
+            if (on) {
+                V4 qv; qv[0] = Q[0]; qv[1] = Q[1]; qv[2] = Q[2]; qv[3] = Q[3];
+                *reinterpret_cast<V4 *>(body + 4 + c * 4) = qv;
+                if (c == 0) {
+                    // samples of this step: t_old < ts <= t_new (the first step also owns ts = 0)
+                    const int i_lo = (j == 0) ? 0 : samples_upto(P, t_old);
+                    int i_hi = samples_upto(P, t_new);
+                    i_hi = i_hi < n ? i_hi : n;
+                    for (int i = i_lo; i < i_hi; ++i) sidx[(size_t)sid * ns + i] = (uint16_t)j;
+                }
             }
         }
     }

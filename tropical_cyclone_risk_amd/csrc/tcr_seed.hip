@@ -72,16 +72,28 @@ __device__ __forceinline__ void uniform2(const SeedArgs &a, int64_t cand, uint32
     u1 = ((double)(o[2] >> 5) * 67108864.0 + (double)(o[3] >> 6)) / 9007199254740992.0;
 }
 
-// bilinear lookup of a uint8 0/1 plane, FITPACK order (mat.interp2_fx on a bool DataArray)
-__device__ __forceinline__ double mask_at(const DevGrid &g, const uint8_t *__restrict__ m, const Cell &cx,
-                                          const Cell &cy)
+// The eight 0/1 mask planes (run basin + 7 basins) are staged as the bits of ONE byte per grid point, so a
+// candidate's nine mask lookups read four bytes instead of thirty-six.
+struct MaskCorners {
+    unsigned c00, c01, c10, c11;        // the bytes at (x0,y0), (x0,y1), (x1,y0), (x1,y1)
+};
+
+__device__ __forceinline__ MaskCorners mask_corners(const DevGrid &g, const uint8_t *__restrict__ m, const Cell &cx, const Cell &cy)
 {
     const uint8_t *r0 = m + (size_t)cy.i * g.nlon + cx.i, *r1 = r0 + g.nlon;
+    MaskCorners c;
+    c.c00 = r0[0]; c.c01 = r1[0]; c.c10 = r0[1]; c.c11 = r1[1];
+    return c;
+}
+
+// bilinear lookup of mask plane `bit`, FITPACK order (mat.interp2_fx on a bool DataArray)
+__device__ __forceinline__ double mask_at(const MaskCorners &c, int bit, const Cell &cx, const Cell &cy)
+{
     double sp = 0.0;
-    sp = sp + (double)r0[0] * cx.w0 * cy.w0;
-    sp = sp + (double)r1[0] * cx.w0 * cy.w1;
-    sp = sp + (double)r0[1] * cx.w1 * cy.w0;
-    sp = sp + (double)r1[1] * cx.w1 * cy.w1;
+    sp = sp + (double)((c.c00 >> bit) & 1u) * cx.w0 * cy.w0;
+    sp = sp + (double)((c.c01 >> bit) & 1u) * cx.w0 * cy.w1;
+    sp = sp + (double)((c.c10 >> bit) & 1u) * cx.w1 * cy.w0;
+    sp = sp + (double)((c.c11 >> bit) & 1u) * cx.w1 * cy.w1;
     return sp;
 }
 
@@ -108,13 +120,15 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a)
     Cell cx = locate(D.mg.ax, lon);
     Cell cy = locate(D.mg.ay, lat);
     int redraw = 0;
-    while (mask_at(D.mg, D.run_mask, cx, cy) < 1e-2 && redraw < kMaxRedraw) {
+    MaskCorners mc = mask_corners(D.mg, D.mask_bits, cx, cy);
+    while (mask_at(mc, 7, cx, cy) < 1e-2 && redraw < kMaxRedraw) {
         ++redraw;                                           // compute.py:146-148: uniform in lat
         uniform2(a, cand, 0u, (uint32_t)redraw, u0, u1);
         lon = P.box[0] + (P.box[2] - P.box[0]) * u0;
         lat = P.box[1] + (P.box[3] - P.box[1]) * u1;
         cx = locate(D.mg.ax, lon);
         cy = locate(D.mg.ay, lat);
+        mc = mask_corners(D.mg, D.mask_bits, cx, cy);
     }
     double um, ul;
     uniform2(a, cand, 1u, 0u, um, ul);
@@ -122,11 +136,10 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a)
     month = month > 12 ? 12 : month;
 
     // genesis basin = argmax of the 7 basin masks (compute.py:155-158), first max wins
-    const size_t np = (size_t)D.mg.nlon * D.mg.nlat;
-    double best = mask_at(D.mg, D.basin_masks, cx, cy);
+    double best = mask_at(mc, 0, cx, cy);
     int bidx = 0;
     for (int b = 1; b < TCR_N_BASINS; ++b) {
-        const double val = mask_at(D.mg, D.basin_masks + np * b, cx, cy);
+        const double val = mask_at(mc, b, cx, cy);
         if (val > best) { best = val; bidx = b; }
     }
     // PI at genesis from the month's field set (compute.py:162)
