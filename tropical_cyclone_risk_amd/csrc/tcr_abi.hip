@@ -473,9 +473,20 @@ int launch_fourier(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const double *
             if (grow(ctx, &p, &ctx->pf_cap, (size_t)nf * 2)) { ctx->d_pf = nullptr; return -1; }
             ctx->d_pf = reinterpret_cast<double2 *>(p);
         }
-        hipLaunchKernelGGL(k_phase_factors, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, P, n, n_dev, phases, ctx->d_pf);
-        hipLaunchKernelGGL(k_fourier_periodic<R>, dim3((unsigned)n), dim3(kFsThreads), lds, st, P, n, n_dev,
-                           ctx->fs_period, ctx->d_sc_table, ctx->d_pf, fs);
+        if (TCR_FS_MFMA && 2 * P.n_series <= 4 * kFsMfmaKSteps && P.n_steps <= kFsMfmaMaxSamples) {
+            // matrix-core form: phase factors in MFMA fragment order (4 KB per 4 storms <= the 3.84 KB of d_pf's layout + padding)
+            const int64_t tiles = (n + 3) / 4;
+            double *p = reinterpret_cast<double *>(ctx->d_pf);
+            if (grow(ctx, &p, &ctx->pf_cap, (size_t)tiles * kFsMfmaKSteps * 64)) { ctx->d_pf = nullptr; return -1; }
+            ctx->d_pf = reinterpret_cast<double2 *>(p);
+            hipLaunchKernelGGL(k_phase_factors_frag, dim3((unsigned)tiles), dim3(256), 0, st, P, n, n_dev, phases, p);
+            const unsigned wgs = (unsigned)std::min<int64_t>(tiles, (int64_t)ctx->cu_count * kFsMfmaWgsPerCu);
+            hipLaunchKernelGGL(k_fourier_mfma<R>, dim3(wgs), dim3(64 * kFsMfmaWaves), 0, st, P, n, n_dev, ctx->fs_period, ctx->d_sc_table, p, fs);
+        } else {
+            hipLaunchKernelGGL(k_phase_factors, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, P, n, n_dev, phases, ctx->d_pf);
+            hipLaunchKernelGGL(k_fourier_periodic<R>, dim3((unsigned)n), dim3(kFsThreads), lds, st, P, n, n_dev,
+                               ctx->fs_period, ctx->d_sc_table, ctx->d_pf, fs);
+        }
     } else {
         const int64_t total = n * (int64_t)P.n_steps;
         hipLaunchKernelGGL(k_fourier_direct<R>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, n, n_dev, phases, fs);

@@ -383,10 +383,15 @@ struct RhsT {
     int dec;    // decision probe (tests only; dead code elsewhere): bit0 `land == 1`, bit1 PI != 0, bit2 |land - 1| <= 1e-12
 };
 
-// Everything of dydt after the lookups: steering, beta-advection, _dvdt, ocean feedback, _dmdt.
+// dydt after the lookups, in two parts so that the integrator can start the next stage point's gathers between them.
+// Part 1 — what the *position* derivatives need: steering coefficients, beta-advection (bam_track.py:131-144).
 template <typename R>
-__device__ __forceinline__ void rhs_tail(const EvalKT<R> &K, R h_bl, R lat, R v, R m,
-                                         const R (&th)[4], const R (&lb)[2], RhsT<R> &r)
+struct TrackMidT {
+    R vb0, vb1;     // translation velocity (zero poleward of 80 deg)
+};
+
+template <typename R>
+__device__ __forceinline__ void rhs_track(const EvalKT<R> &K, R lat, R v, RhsT<R> &r, TrackMidT<R> &mid)
 {
     const R z = R(0.0);
     // steering coefficients
@@ -413,7 +418,20 @@ __device__ __forceinline__ void rhs_tail(const EvalKT<R> &K, R h_bl, R lat, R v,
     vb1 = polar ? z : vb1;
     r.d[0] = vb0 / RD(K.earth_R) * R(180.) / R(kPi) / cos(lat * R(kPi) / R(180.));
     r.d[1] = vb1 / RD(K.earth_R) * R(180.) / R(kPi);
-    // intensity
+    mid.vb0 = vb0; mid.vb1 = vb1;
+}
+
+// Part 2 — intensity and moisture: _dvdt (coupled_fast.py:141-150) with _get_current_vpot (:54-58),
+// _calc_alpha / _calc_z (:65-94), _dmdt (:175-180).
+template <typename R>
+__device__ __forceinline__ void rhs_intensity(const EvalKT<R> &K, R h_bl, R lat, R v, R m, const R (&th)[4],
+                                              const R (&lb)[2], const TrackMidT<R> &mid, RhsT<R> &r)
+{
+    const R z = R(0.0);
+    const bool polar = fabs(lat) >= R(80);
+    const R w0 = polar ? z : r.w[0], w1 = polar ? z : r.w[1];
+    const R w2 = polar ? z : r.w[2], w3 = polar ? z : r.w[3];
+    const R vb0 = mid.vb0, vb1 = mid.vb1;
     const R vp = (lb[0] == R(1.0)) ? z : th[0];                        // coupled_fast.py:35-58
     r.dec = (lb[0] == R(1.0) ? 1 : 0) | (th[0] != z ? 2 : 0) | (fabs(lb[0] - R(1.0)) <= R(1e-12) ? 4 : 0);
     const R h_m = th[2], gam = th[3], bathy = lb[1];
@@ -432,6 +450,15 @@ __device__ __forceinline__ void rhs_tail(const EvalKT<R> &K, R h_bl, R lat, R v,
     r.vpot = vp; r.chi = th[1];
     r.d[2] = (dv != dv) ? z : dv;
     r.d[3] = R(0.5) * RD(K.Ck) / h_bl * ((R(1) - m) * v - venti * m);
+}
+
+template <typename R>
+__device__ __forceinline__ void rhs_tail(const EvalKT<R> &K, R h_bl, R lat, R v, R m,
+                                         const R (&th)[4], const R (&lb)[2], RhsT<R> &r)
+{
+    TrackMidT<R> mid;
+    rhs_track<R>(K, lat, v, r, mid);
+    rhs_intensity<R>(K, h_bl, lat, v, m, th, lb, mid, r);
 }
 
 // land and bathymetry at (lon, lat): one interleaved gather, or (SPLIT) two planes on their own grids
@@ -512,42 +539,99 @@ struct CornerCacheT {
 
 template <typename R> __device__ __forceinline__ void cache_reset(CornerCacheT<R> &C) { C.wi = C.wj = -1; }
 
+// One evaluation of fun for the sequential integrator, cut at the two points where its data dependencies allow the
+// next stage point's memory round trip to start early (k_integrate):
+//   issue      cell searches and every gather of the point (lon, lat, t) — needs nothing but the point;
+//   track      raw env winds and d lon/dt, d lat/dt — all the *next* stage point depends on; also reduces the thermo /
+//              static corners to their bilinear values, so the load registers are free for the next issue;
+//   intensity  dv/dt, dm/dt — runs in the shadow of the next point's gathers.
+// The operations and their order per value are those of rhs_eval; only independent work is reordered.
 template <typename R, bool AFFINE, bool SPLIT>
-__device__ __forceinline__ RhsT<R> rhs_eval_cached(CornerCacheT<R> &C, const EvalKT<R> &K, const R *__restrict__ wind,
-                                                   const R *__restrict__ thermo, const R *__restrict__ fs, R h_bl,
-                                                   double t, R lon, R lat, R v, R m)
-{
+struct RhsPipeT {
     typedef Widths<R> Wd;
-    const CellT<R> wx = locate_t<R, AFFINE>(K.wx, lon), wy = locate_t<R, AFFINE>(K.wy, lat);
-    CellT<R> tx = wx, ty = wy;
-    if (!RD(K.tw_same)) { tx = locate_t<R, AFFINE>(K.tx, lon); ty = locate_t<R, AFFINE>(K.ty, lat); }      // wave-uniform
-    const FsBracket fb = fs_bracket(K, t);
+    CellT<R> wx, wy, tx, ty;
+    FsBracket fb;
     FsPairT<R> fp;
-#ifdef TCR_ABLATE_FS_READ
-    // timing experiment of DESIGN.md §9 only (values are wrong): what the integrator would gain if the forcing-table
-    // read cost nothing.  The bracket arithmetic stays; the gather becomes a cheap per-lane constant.
-    for (int k = 0; k < 4 / FsPairT<R>::L; ++k) for (int q = 0; q < FsPairT<R>::L; ++q) { fp.a[k][q] = (R)(1e-3 * fb.lo); fp.b[k][q] = (R)(1e-3 * fb.lo); }
-#else
-    fs_gather<R>(fs, fb, fp);
-#endif
-    if (wx.i != C.wi || wy.i != C.wj) {
-        gather<R, 14, kWindStride, Wd::W>(wind, RD(K.wx.n), wx, wy, C.CW);
-        C.wi = wx.i; C.wj = wy.i;
-    }
     CornersT<R, 4, Wd::T> CT;
     StaticLookup<R, AFFINE, SPLIT> SL;
-    gather<R, 4, kThermoStride, Wd::T>(thermo, RD(K.tx.n), tx, ty, CT);
-    SL.issue(K, lon, lat);
-    RhsT<R> r;
-    R q[14], F[4], th[4], lb[2];
-    blend<R, 14, Wd::W>(C.CW, wx, wy, q);
-    fs_blend<R>(fp, fb, t, F);
-    winds_from_lookups<R>(q, F, lon, t, r.w);
-    blend<R, 4, Wd::T>(CT, tx, ty, th);
-    SL.finish(lb);
-    rhs_tail<R>(K, h_bl, lat, v, m, th, lb, r);
-    return r;
-}
+
+    __device__ __forceinline__ void issue(CornerCacheT<R> &C, const EvalKT<R> &K, const R *__restrict__ wind,
+                                          const R *__restrict__ thermo, const R *__restrict__ fs, double t, R lon, R lat)
+    {
+        wx = locate_t<R, AFFINE>(K.wx, lon); wy = locate_t<R, AFFINE>(K.wy, lat);
+        tx = wx; ty = wy;
+        if (!RD(K.tw_same)) { tx = locate_t<R, AFFINE>(K.tx, lon); ty = locate_t<R, AFFINE>(K.ty, lat); }      // wave-uniform
+        fb = fs_bracket(K, t);
+#ifdef TCR_ABLATE_UNIFORM_ADDR
+        // timing experiment only (values are wrong): every lane gathers at lane 0's cells — one cache line per load
+        // instruction instead of up to 64 — which separates the per-lane cost of a gather from its per-line cost
+        wx.i = __builtin_amdgcn_readfirstlane(wx.i); wy.i = __builtin_amdgcn_readfirstlane(wy.i);
+        tx.i = __builtin_amdgcn_readfirstlane(tx.i); ty.i = __builtin_amdgcn_readfirstlane(ty.i);
+        fb.lo = __builtin_amdgcn_readfirstlane(fb.lo);
+        {
+            auto first64 = [](unsigned long long v) {
+                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+                return ((unsigned long long)hi << 32) | lo;
+            };
+            fs = reinterpret_cast<const R *>(first64((unsigned long long)fs));
+            wind = reinterpret_cast<const R *>(first64((unsigned long long)wind));
+            thermo = reinterpret_cast<const R *>(first64((unsigned long long)thermo));
+            lon = (R)__longlong_as_double((long long)first64((unsigned long long)__double_as_longlong((double)lon)));
+            lat = (R)__longlong_as_double((long long)first64((unsigned long long)__double_as_longlong((double)lat)));
+        }
+#endif
+#if defined(TCR_ABLATE_FS_READ) || defined(TCR_ABLATE_ALL_READS)
+        // timing experiment of DESIGN.md §9 only (values are wrong): what the integrator would gain if the forcing-table
+        // read cost nothing.  The bracket arithmetic stays; the gather becomes a cheap per-lane constant.
+        for (int k = 0; k < 4 / FsPairT<R>::L; ++k) for (int q = 0; q < FsPairT<R>::L; ++q) { fp.a[k][q] = (R)(1e-3 * fb.lo); fp.b[k][q] = (R)(1e-3 * fb.lo); }
+#else
+        fs_gather<R>(fs, fb, fp);
+#endif
+#ifdef TCR_ABLATE_ALL_READS
+        // timing experiment only (values are not physical): every gather of the evaluation replaced by per-lane constants
+        {
+            const R eps = (R)(1e-6 * wx.i);
+            for (int f = 0; f < 14; ++f) {
+                const R c = ((f == 4 || f == 6 || f == 9 || f == 13) ? R(10) : (f < 4 ? R(3) : R(0.1))) + eps;
+                C.CW.c00[f / Wd::W][f % Wd::W] = c; C.CW.c01[f / Wd::W][f % Wd::W] = c;
+                C.CW.c10[f / Wd::W][f % Wd::W] = c; C.CW.c11[f / Wd::W][f % Wd::W] = c;
+            }
+            const R tv[4] = {R(60), R(0.5), R(50), R(0.05)};
+            for (int f = 0; f < 4; ++f) {
+                const R c = tv[f] + eps;
+                CT.c00[f / Wd::T][f % Wd::T] = c; CT.c01[f / Wd::T][f % Wd::T] = c;
+                CT.c10[f / Wd::T][f % Wd::T] = c; CT.c11[f / Wd::T][f % Wd::T] = c;
+            }
+            SL.hx = locate_t<R, AFFINE>(K.hx, lon); SL.hy = locate_t<R, AFFINE>(K.hy, lat);
+            const R sv[2] = {R(0), R(-3000)};
+            for (int f = 0; f < 2; ++f) {
+                const R c = sv[f] + eps;
+                SL.CH.c00[f / Wd::H][f % Wd::H] = c; SL.CH.c01[f / Wd::H][f % Wd::H] = c;
+                SL.CH.c10[f / Wd::H][f % Wd::H] = c; SL.CH.c11[f / Wd::H][f % Wd::H] = c;
+            }
+        }
+#else
+        if (wx.i != C.wi || wy.i != C.wj) {
+            gather<R, 14, kWindStride, Wd::W>(wind, RD(K.wx.n), wx, wy, C.CW);
+            C.wi = wx.i; C.wj = wy.i;
+        }
+        gather<R, 4, kThermoStride, Wd::T>(thermo, RD(K.tx.n), tx, ty, CT);
+        SL.issue(K, lon, lat);
+#endif
+    }
+
+    __device__ __forceinline__ void track(const CornerCacheT<R> &C, const EvalKT<R> &K, double t, R lon, R lat, R v,
+                                          RhsT<R> &r, TrackMidT<R> &mid, R (&th)[4], R (&lb)[2]) const
+    {
+        R q[14], F[4];
+        blend<R, 14, Wd::W>(C.CW, wx, wy, q);
+        fs_blend<R>(fp, fb, t, F);
+        winds_from_lookups<R>(q, F, lon, t, r.w);
+        blend<R, 4, Wd::T>(CT, tx, ty, th);
+        SL.finish(lb);
+        rhs_track<R>(K, lat, v, r, mid);
+    }
+};
 
 // coupled_fast.py:246-256 with util/basins.py:32-37 (dx = 1); always >= 0
 template <typename R>

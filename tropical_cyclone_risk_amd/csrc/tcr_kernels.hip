@@ -199,6 +199,181 @@ __global__ __launch_bounds__(kFsThreads) void k_fourier_periodic(tcr_params P, i
     }
 }
 
+// k_fourier_mfma: the same table as a matrix product on the fp64 matrix cores.
+//
+//   fs[storm][sample][series] = amp * sum_h ( S[(h+1) k mod period] * cb[storm][h][series] + C[...] * sb[storm][h][series] )
+//
+// is Out[(series, storm), sample] = A[(series, storm), 2N] x B[2N, sample] with A the storms' phase factors and B the
+// one-period table laid out per (harmonic, sample) — the same B for every storm.  A workgroup of four waves owns all
+// samples (wave w: column tiles 6w .. 6w+5 of 16 samples; 24 tiles = 384 samples), keeps its B fragments in registers
+// for its whole life (96 VGPRs) and walks row tiles of 4 storms x 4 series: 8 coalesced loads of the A fragment
+// (written in fragment order by k_phase_factors_frag), 8 x v_mfma_f64_16x16x4_f64 per column tile on six independent
+// accumulator chains, and — rows ordered series-major — a lane ends up with the four series of one (storm, sample) in
+// its four accumulator registers: one 32-byte store per lane, 512 contiguous bytes per storm and instruction.
+// No LDS, no index arithmetic in the loop; 43 k FMAs per storm run on the matrix pipe (the fp64 matrix peak of gfx950
+// equals its vector peak, so the gain is the table reads and integer work of k_fourier_periodic, not a higher ceiling).
+// Summation order differs from k_fourier_periodic (k ascending within an MFMA, fused) at the 1e-16 level; the bound
+// against NumPy's own evaluation stays the one stated in tests/test_gpu_parity.py.
+#ifndef TCR_FS_MFMA
+#define TCR_FS_MFMA 1      // 0: k_fourier_periodic (vector FMAs on an LDS table) for every shape
+#endif
+#ifndef TCR_FS_MFMA_TILES
+#define TCR_FS_MFMA_TILES 6
+#endif
+#ifndef TCR_FS_MFMA_WPS
+#define TCR_FS_MFMA_WPS 2
+#endif
+constexpr int kFsMfmaColTiles = TCR_FS_MFMA_TILES;          // column tiles per wave (6 / 4 / 3: four / six / eight waves per workgroup)
+constexpr int kFsMfmaWaves = 24 / kFsMfmaColTiles;
+constexpr int kFsMfmaWgsPerCu = TCR_FS_MFMA_WPS * 4 / kFsMfmaWaves > 0 ? TCR_FS_MFMA_WPS * 4 / kFsMfmaWaves : 1;
+constexpr int kFsMfmaKSteps = 8;            // K = 32 >= 2 * n_series
+constexpr int kFsMfmaMaxSamples = 24 * 16;
+
+// A fragments: [row tile of 4 storms][k step][lane]; lane l supplies A[i = l & 15][k = (l >> 4) + 4 * kstep],
+// i = series * 4 + storm_in_tile, k = 2 * harmonic + (0: weight * cos 2 pi x, 1: weight * sin 2 pi x); zero padding.
+__global__ __launch_bounds__(256) void k_phase_factors_frag(tcr_params P, int64_t n, const int64_t *__restrict__ n_dev,
+                                                            const double *__restrict__ phases, double *__restrict__ frag)
+{
+    const int N = P.n_series;
+    const int64_t ne = n_eff(n, n_dev);
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // (tile, kstep, lane) pairs: one thread writes k and k + 1
+    const int64_t tiles = (ne + 3) / 4;
+    if (gid >= tiles * 16 * 16) return;
+    const int64_t tile = gid / 256;
+    const int r = (int)(gid - tile * 256), h = r >> 4, i = r & 15;             // harmonic 0..15, row 0..15
+    const int s = i >> 2;
+    const int64_t storm = tile * 4 + (i & 3);
+    double cb = 0.0, sb = 0.0;
+    if (h < N && storm < ne) {
+        const double x = phases[storm * 4 * N + s * N + h];                     // phases are [storm][series][harmonic]
+        const double wgt = P.fs_wgt[h];
+        sb = wgt * sinpi(2.0 * x); cb = wgt * cospi(2.0 * x);
+    }
+    const int k = 2 * h;                                                        // k & 3 is 0 or 2: k and k + 1 share a k step
+    double *o = frag + tile * (kFsMfmaKSteps * 64) + (k >> 2) * 64 + i;
+    o[(k & 3) * 16] = cb;
+    o[((k & 3) + 1) * 16] = sb;
+}
+
+template <typename R>
+__global__ __launch_bounds__(64 * kFsMfmaWaves, TCR_FS_MFMA_WPS) void k_fourier_mfma(tcr_params P, int64_t n, const int64_t *__restrict__ n_dev,
+                                                         int period, const double2 *__restrict__ sc_table,
+                                                         const double *__restrict__ frag, R *__restrict__ fs)
+{
+    typedef double D4 __attribute__((ext_vector_type(4)));
+    __shared__ double stage[kFsMfmaWaves][4 * 16 * 4];     // per wave: one output tile, [storm][sample][series]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int N = P.n_series, ns = P.n_steps;
+    const int64_t ne = n_eff(n, n_dev);
+    const int64_t tiles = (ne + 3) / 4;
+    // B fragments of this wave's column tiles: lane l supplies B[k = (l >> 4) + 4 * kstep][sample = tile * 16 + (l & 15)]
+    double B[kFsMfmaColTiles][kFsMfmaKSteps];
+#pragma unroll
+    for (int t = 0; t < kFsMfmaColTiles; ++t) {
+        const int col = (wave * kFsMfmaColTiles + t) * 16 + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < kFsMfmaKSteps; ++ks) {
+            const int k = (lane >> 4) + 4 * ks, h = k >> 1;
+            // branch-free so that the 48 gathers of a lane go out together; (h + 1) * col < 2^31
+            const bool used = h < N && col < ns;
+            const double *e = reinterpret_cast<const double *>(sc_table + (used ? (unsigned)((h + 1) * col) % (unsigned)period : 0u));
+            const double v = e[k & 1];              // k even: pairs with the cos factor -> sin entry; odd: cos entry
+            B[t][ks] = used ? v : 0.0;
+        }
+    }
+    const double amp = P.fs_amp;
+    const int q = lane >> 4, j = lane & 15;
+    // Epilogue of one 16 x 16 output tile, cut into eight pieces that are issued *between* the eight MFMAs of the next
+    // tile (one MFMA occupies the matrix pipe for 64 cycles; the wave's other instructions fit underneath).
+    // D: column = lane & 15 (sample), row = (lane >> 4) + 4 * reg = series * 4 + storm  ->  reg = series, lane >> 4 =
+    // storm: a lane holds the four series of one (storm, sample) = 32 contiguous bytes of the table (fp32: 16).
+    // fp64: two 16-byte stores per lane straight from the accumulators would each write half of every 32-byte sector
+    // (measured: the kernel then runs at the speed of its stores, 0.36 ms for 1.16 GB, MFMAs or not), so the tile goes
+    // through a wave-private 2 KB of LDS and leaves as full lines: 16 bytes per lane, 512 contiguous bytes per storm,
+    // two storms per instruction.  LDS executes a wave's instructions in order; the wavefront fences only keep the
+    // compiler from reordering the staging writes and reads, which are to different addresses of the same lane.
+    struct Epilogue {
+        D4 v;
+        double2 d0, d1;
+        int64_t tile;
+        int k0;
+        bool live;
+    } ep;
+    ep.live = false; ep.tile = 0; ep.k0 = 0; ep.v = D4{0, 0, 0, 0}; ep.d0 = ep.d1 = make_double2(0, 0);
+    double *const stg = stage[wave];
+    auto epilogue_piece = [&](int piece) {
+        if (!ep.live) return;                                   // wave-uniform
+        if (sizeof(R) == 8) {
+            switch (piece) {
+            case 0: ep.v[0] = amp * ep.v[0]; ep.v[1] = amp * ep.v[1]; ep.v[2] = amp * ep.v[2]; ep.v[3] = amp * ep.v[3]; break;
+            case 1: *reinterpret_cast<D4 *>(&stg[(q * 16 + j) * 4]) = ep.v; break;
+            case 2: __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); break;
+            case 3: ep.d0 = *reinterpret_cast<const double2 *>(&stg[lane * 2]);
+                    ep.d1 = *reinterpret_cast<const double2 *>(&stg[128 + lane * 2]); break;
+            case 4: __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); break;
+            case 5: case 6: {
+                const int i = piece - 5;
+                const int64_t storm = ep.tile * 4 + 2 * i + (lane >> 5);
+                const int k = ep.k0 + ((lane & 31) >> 1);
+                const double2 d = i ? ep.d1 : ep.d0;
+#if defined(TCR_FS_ABLATE) && TCR_FS_ABLATE == 1
+                if (storm < ne && k < ns && d.x == 1.2345e300)    // timing experiment: no stores
+#else
+                if (storm < ne && k < ns)
+#endif
+                    *reinterpret_cast<double2 *>(reinterpret_cast<double *>(fs) + (storm * (int64_t)ns + ep.k0) * 4 + (lane & 31) * 2) = d;
+                break;
+            }
+            default: break;
+            }
+        } else if (piece == 5) {
+            const int64_t storm = ep.tile * 4 + q;
+            const int k = ep.k0 + j;
+#if defined(TCR_FS_ABLATE) && TCR_FS_ABLATE == 1
+            if (storm < ne && k < ns && ep.v[0] == 1.2345e300)
+#else
+            if (storm < ne && k < ns)
+#endif
+                store_fs<R>(fs + (storm * (int64_t)ns + k) * 4, amp * ep.v[0], amp * ep.v[1], amp * ep.v[2], amp * ep.v[3]);
+        }
+    };
+    double A[kFsMfmaKSteps];
+    int64_t tile = blockIdx.x;
+    if (tile < tiles) {
+#pragma unroll
+        for (int ks = 0; ks < kFsMfmaKSteps; ++ks) A[ks] = frag[tile * (kFsMfmaKSteps * 64) + ks * 64 + lane];
+    }
+    for (; tile < tiles; tile += gridDim.x) {
+        // next row tile's fragment while this one multiplies
+        double An[kFsMfmaKSteps];
+        const int64_t nxt = tile + gridDim.x;
+#pragma unroll
+        for (int ks = 0; ks < kFsMfmaKSteps; ++ks) An[ks] = (nxt < tiles) ? frag[nxt * (kFsMfmaKSteps * 64) + ks * 64 + lane] : 0.0;
+#pragma unroll
+        for (int t = 0; t < kFsMfmaColTiles; ++t) {
+            const int k0 = (wave * kFsMfmaColTiles + t) * 16;
+            if (k0 >= ns) break;                                // wave-uniform: this wave's last column tiles lie beyond the track
+            D4 acc = D4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < kFsMfmaKSteps; ++ks) {
+#if defined(TCR_FS_ABLATE) && TCR_FS_ABLATE == 2
+                acc[ks & 3] += A[ks] * B[t][ks];              // timing experiment: no matrix instructions (values wrong)
+#else
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ks], B[t][ks], acc, 0, 0, 0);
+#endif
+                epilogue_piece(ks);                              // of the previous tile
+                __builtin_amdgcn_sched_barrier(0);               // keep this interleaving
+            }
+            ep.v = acc; ep.tile = tile; ep.k0 = k0; ep.live = true;
+        }
+#pragma unroll
+        for (int ks = 0; ks < kFsMfmaKSteps; ++ks) A[ks] = An[ks];
+    }
+#pragma unroll
+    for (int piece = 0; piece < 8; ++piece) epilogue_piece(piece);
+}
+
 // ---------------------------------------------------------------------------
 // Dormand–Prince tableau exactly as SciPy spells it (rk.py:384-408)
 #define A10 (1. / 5)
@@ -258,6 +433,9 @@ constexpr int kWave = 64;
 #endif
 #ifndef TCR_INT_WPS_F32
 #define TCR_INT_WPS_F32 1  // ... and the fp32 instantiation: budgeted for 2 it spills 248 B per lane and is slower (1.38 vs 1.29 ms per step)
+#endif
+#ifndef TCR_INT_PIPELINE
+#define TCR_INT_PIPELINE 0   // 1: the next stage point's gathers are issued ahead of the intensity half (measured: +4 % time)
 #endif
 constexpr int kRunning = 99;
 template <typename R> constexpr int int_wps() { return sizeof(R) == 8 ? TCR_INT_WPS : TCR_INT_WPS_F32; }
@@ -322,6 +500,9 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
     R g = R(0.0);
     CornerCacheT<R> CC;
     cache_reset(CC);
+    RhsPipeT<R, AFFINE, SPLIT> PIPE;
+    bool pre = false;                       // the gathers of the point (e, et) are already in flight
+    double etn = 0;
 
     auto finalize = [&]() {
         a.n_valid[sid] = next_out;
@@ -359,6 +540,16 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
     // occupancy accounting lives in LDS (lane 0 only): the kernel has no register to spare
     __shared__ unsigned long long occ[4];
     if (lane == 0) { occ[0] = 0; occ[1] = 0; occ[2] = wall_clock64(); occ[3] = clock64(); }
+#ifdef TCR_INT_PHASE_CLOCKS
+    // experiment of DESIGN.md §9: shader clocks per phase of an evaluation slot, lane 0 of block 0 (perturbs the schedule)
+    __shared__ unsigned long long ph[8];
+    if (lane == 0) for (int i = 0; i < 8; ++i) ph[i] = 0;
+    unsigned long long ph_last = clock64();
+#define TCR_PHASE_CLK(i) do { if (TCR_INT_PHASE_CLOCKS == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = clock64(); \
+        if (lane == 0) { ph[i] += now_ - ph_last; if ((i) == 0) ph[5] += 1; } ph_last = now_; } while (0)
+#else
+#define TCR_PHASE_CLK(i) do { } while (0)
+#endif
     for (;;) {
         // ---- cycle boundary: refill idle lanes from the storm queue (wave-aggregated atomic)
         const unsigned long long want = __ballot(!active && !exhausted);
@@ -407,6 +598,9 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
                     h_bl = (R)a.h_bl[sid];
                     active = true;
                     cache_reset(CC);
+                    // the refill's loads complete here (vmcnt(0); expcnt / lgkmcnt untouched): otherwise their first use
+                    // — h_bl, in the intensity half — makes the compiler wait for the *prefetched* gathers issued since
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
                 }
             }
         }
@@ -445,33 +639,58 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
 #else
             const EvalKT<R> &Kq = K;
 #endif
-            if (live) r = rhs_eval_cached<R, AFFINE, SPLIT>(CC, Kq, wind, thermo, fs, h_bl, et, e[0], e[1], e[2], e[3]);
+            // Software pipeline over the stages of an attempt: the next stage *point* needs only this evaluation's
+            // d lon/dt and d lat/dt, so its gathers are issued as soon as those exist and the intensity half of this
+            // evaluation runs in their shadow.  Exposed round trips remain at the first slot of a cycle (the point
+            // depends on the step-size decision) and for fresh storms.
+            TCR_PHASE_CLK(0);
+            if (live && !pre) PIPE.issue(CC, Kq, wind, thermo, fs, et, e[0], e[1]);
+            TCR_PHASE_CLK(1);
+            R th[4] = {0, 0, 0, 0}, lb[2] = {0, 0};
+            TrackMidT<R> mid{};
+            if (live) PIPE.track(CC, Kq, et, e[0], e[1], e[2], r, mid, th, lb);
+            TCR_PHASE_CLK(2);
+            // rk_step (rk.py:62-70): K[s] = fun(...); next stage input dy = dot(K[:s].T, a[:s]) * h, one component at a time
+            R en[4] = {e[0], e[1], e[2], e[3]};
+            auto stage_input = [&](int i) {
+                R dy = R(0.0);
+                switch (slot) {
+                case 0: dy += KS(0, i) * R(A20); dy += KS(1, i) * R(A21); break;
+                case 1: dy += KS(0, i) * R(A30); dy += KS(1, i) * R(A31); dy += KS(2, i) * R(A32); break;
+                case 2: dy += KS(0, i) * R(A40); dy += KS(1, i) * R(A41); dy += KS(2, i) * R(A42); dy += KS(3, i) * R(A43); break;
+                case 3: dy += KS(0, i) * R(A50); dy += KS(1, i) * R(A51); dy += KS(2, i) * R(A52); dy += KS(3, i) * R(A53);
+                        dy += KS(4, i) * R(A54); break;
+                default:
+                    for (int j = 0; j < 6; ++j) dy += KS(j, i) * R(RK_B[j]);
+                    break;
+                }
+                if (slot < 4) en[i] = y[i] + dy * (R)h;
+                else { en[i] = y[i] + (R)h * dy; yn[i] = en[i]; }     // y_new (rk.py:68)
+            };
+            const bool stepping = live && !fresh;
+            const R v_e = e[2], m_e = e[3], lat_e = e[1];
+            pre = false;
+            if (stepping) { KS(slot + 1, 0) = r.d[0]; KS(slot + 1, 1) = r.d[1]; }
+            if (stepping && slot < 5) {
+                stage_input(0); stage_input(1);
+                etn = (slot < 4) ? t + RK_C[slot + 2] * h : t + h;
+                if (TCR_INT_PIPELINE) { PIPE.issue(CC, Kq, wind, thermo, fs, etn, en[0], en[1]); pre = true; }
+            }
+            TCR_PHASE_CLK(3);
+            if (live) rhs_intensity<R>(Kq, h_bl, lat_e, v_e, m_e, th, lb, mid, r);
+            TCR_PHASE_CLK(4);
             if (PROBE && live) {
                 const int ev = fresh ? slot : nfev;          // index of this evaluation in the storm's call order
                 if (ev < a.probe_cap) a.probe[(size_t)sid * a.probe_cap + ev] = (uint8_t)r.dec;
             }
-            if (live && !fresh) {
-                // rk_step (rk.py:62-70): K[s] = fun(...); next stage input dy = dot(K[:s].T, a[:s]) * h
+            if (stepping) {
                 ++nfev;
                 const int st = slot + 1;
-                for (int i = 0; i < 4; ++i) KS(st, i) = r.d[i];
+                KS(st, 2) = r.d[2]; KS(st, 3) = r.d[3];
                 if (slot < 5) {
-                    for (int i = 0; i < 4; ++i) {
-                        R dy = R(0.0);
-                        switch (slot) {
-                        case 0: dy += KS(0, i) * R(A20); dy += KS(1, i) * R(A21); break;
-                        case 1: dy += KS(0, i) * R(A30); dy += KS(1, i) * R(A31); dy += KS(2, i) * R(A32); break;
-                        case 2: dy += KS(0, i) * R(A40); dy += KS(1, i) * R(A41); dy += KS(2, i) * R(A42); dy += KS(3, i) * R(A43); break;
-                        case 3: dy += KS(0, i) * R(A50); dy += KS(1, i) * R(A51); dy += KS(2, i) * R(A52); dy += KS(3, i) * R(A53);
-                                dy += KS(4, i) * R(A54); break;
-                        default:
-                            for (int j = 0; j < 6; ++j) dy += KS(j, i) * R(RK_B[j]);
-                            break;
-                        }
-                        if (slot < 4) e[i] = y[i] + dy * (R)h;
-                        else { e[i] = y[i] + (R)h * dy; yn[i] = e[i]; }     // y_new (rk.py:68)
-                    }
-                    et = (slot < 4) ? t + RK_C[slot + 2] * h : t + h;
+                    stage_input(2); stage_input(3);
+                    for (int i = 0; i < 4; ++i) e[i] = en[i];
+                    et = etn;
                 } else {
                     // f_new is in K[6]: error estimate and step-size control (rk.py:147-165), in fp64
                     double er[4];
@@ -488,7 +707,11 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
                         if (rejected && fac > 1) fac = 1;
                         ha *= fac;
                         // step record for k_emit: doubles t_old, h, t_new, -; then R y_old[4], K[7][4]
+#ifdef TCR_ABLATE_STEP_STORES
+                        if (nacc < 0) {         // timing experiment only: no step records (post-processing reads garbage)
+#else
                         if (nacc < a.max_rk_steps) {
+#endif
                             double *rec = srec + (size_t)nacc * REC;
                             double2 *o = reinterpret_cast<double2 *>(rec);
                             o[0] = make_double2(t, h);
@@ -573,6 +796,11 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
         }
         fresh = false;
     }
+#ifdef TCR_INT_PHASE_CLOCKS
+    if (lane == 0 && blockIdx.x == 0 && a.pass == 0)
+        printf("phase clocks (block 0, pass 0): issue %llu track %llu stage+prefetch %llu intensity %llu bookkeeping %llu; slots %llu\n",
+               ph[1], ph[2], ph[3], ph[4], ph[0], ph[5]);
+#endif
     if (lane == 0) {       // occupancy accounting of this pass (tcr_integrate_pass_stats)
         unsigned long long *st = a.queue + 2 * kMaxPasses + 4 * a.pass;
         atomicAdd(st + 0, occ[0]);
