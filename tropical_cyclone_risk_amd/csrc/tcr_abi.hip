@@ -581,10 +581,17 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
             a.list = ctx->d_tc_idx; a.count = ctx->d_tc_count;
         }
         // k_dense, TC rows only: a bounded grid of waves walks the device-side list (one wave per storm otherwise)
-        const unsigned gx = out.tc_rows_only ? (unsigned)(n < 16384 ? n : 16384) : (unsigned)n;
+        const unsigned gx = out.tc_rows_only ? (unsigned)std::min<int64_t>(n, kEmitGridCap) : (unsigned)n;
         hipLaunchKernelGGL(k_dense<R>, dim3(gx), dim3(kWave), 0, st, a, ctx->d_sidx);
-        if (affine) hipLaunchKernelGGL((k_emit<R, true>), dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
-        else hipLaunchKernelGGL((k_emit<R, false>), dim3((unsigned)n, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
+        // TC rows only: a bounded grid walks the device-side list (all rows: one row of workgroups per storm)
+        const unsigned ex = out.tc_rows_only ? (unsigned)std::min<int64_t>(n, kEmitGridCap) : (unsigned)n;
+        if (out.tc_rows_only) {
+            if (affine) hipLaunchKernelGGL((k_emit<R, true, true>), dim3(ex, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
+            else hipLaunchKernelGGL((k_emit<R, false, true>), dim3(ex, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
+        } else {
+            if (affine) hipLaunchKernelGGL((k_emit<R, true, false>), dim3(ex, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
+            else hipLaunchKernelGGL((k_emit<R, false, false>), dim3(ex, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
+        }
         hipLaunchKernelGGL(k_flags<R>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, n, out.n_valid,
                            out.status, out.v, out.flags, out.pad_state, a.list, a.count, a.n_dev);
     }

@@ -632,7 +632,9 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
         for (int slot = 0; slot < 6; ++slot) {
             const bool live = active && !(fresh && slot >= 2);
             RhsT<R> r{};
-#ifdef TCR_OPAQUE_K
+#if defined(TCR_K_KERNARG)
+            const EvalKT<R> &Kq = a.K;           // experiment: constants through scalar loads from the kernel arguments
+#elif defined(TCR_OPAQUE_K)
             int koff = 0;
             asm volatile("" : "+s"(koff));      // opaque per iteration: the ~100 EvalK constants stay in LDS instead of being hoisted into registers
             const EvalKT<R> &Kq = *reinterpret_cast<const EvalKT<R> *>(reinterpret_cast<const char *>(&K) + koff);
@@ -851,6 +853,10 @@ constexpr int kBitAny15 = 1 << 8, kBitVmax = 1 << 9;     // scratch bits in flag
 #define TCR_POST_THREADS 128
 #endif
 constexpr int kPostThreads = TCR_POST_THREADS;
+#ifndef TCR_EMIT_GRID_CAP
+#define TCR_EMIT_GRID_CAP 8192
+#endif
+constexpr int64_t kEmitGridCap = TCR_EMIT_GRID_CAP;      // workgroup rows of k_emit / k_dense over the TC list
 constexpr int kEmitSlotCache = 32;      // field-slot wind pointers kept in LDS by k_emit
 #ifndef TCR_EMIT_WPS
 #define TCR_EMIT_WPS 3     // waves per SIMD k_emit is register-budgeted for (<= 168 VGPRs)
@@ -989,82 +995,98 @@ __device__ __forceinline__ void dense_at(const double *__restrict__ srec_storm, 
 // outside neighbour themselves), planes written; the rest of the row is NaN padding.  The gathers
 // make this kernel wait on memory ~60 % of the time, so the transcendental-heavy vmax math of
 // the same sample runs in its shadow (as a kernel of its own it cost 0.34 ms per 100k storms).
-template <typename R, bool AFFINE>
+template <typename R, bool AFFINE, bool LIST>
 __global__ __launch_bounds__(kPostThreads, TCR_EMIT_WPS) void k_emit(EArgsT<R> a, const uint16_t *__restrict__ sidx)
 {
-    __shared__ EvalKT<R> K;
+    __shared__ EvalKT<R> K_lds;
     __shared__ const R *s_wind[kEmitSlotCache];
     const tcr_params &P = a.P;
-    if (a.list && (int64_t)blockIdx.x >= *a.count) return;            // uniform per workgroup
-    if (!a.list && (int64_t)blockIdx.x >= n_eff(a.n, a.n_dev)) return;
-    const int64_t sid = a.list ? (int64_t)a.list[blockIdx.x] : (int64_t)blockIdx.x;
+    // Work items along x: every existing row, or (TC rows only) the device-side list walked by a bounded grid —
+    // a grid sized for the whole batch spent 40 us per 100 000 storms on workgroups that only read the count and left.
+    const int64_t n_items = a.list ? *a.count : n_eff(a.n, a.n_dev);
+    if ((int64_t)blockIdx.x >= n_items) return;                        // uniform per workgroup
     const int ns = P.n_steps;
     const int i = blockIdx.y * kPostThreads + threadIdx.x;
-    // the three per-storm / per-sample indices are independent loads: one round trip, not three
-    const int n = a.n_valid[sid];
-    const int slot_id = a.slot[sid];
-    const uint16_t *sidx_storm = sidx + (size_t)sid * ns;
-    const int my_step = (i < ns) ? sidx_storm[i] : 0;          // meaningful only if i < n
-    const size_t o = (size_t)sid * ns + i;
     const R nan = (R)__longlong_as_double(0x7ff8000000000000LL);
-    const bool live_block = (int)(blockIdx.y * kPostThreads) < n;
-    if (live_block) {
-        for (unsigned w = threadIdx.x; w < sizeof(EvalKT<R>) / 8; w += kPostThreads)       // any workgroup size
-            reinterpret_cast<uint64_t *>(&K)[w] = reinterpret_cast<const uint64_t *>(&a.K)[w];
-        if (threadIdx.x < kEmitSlotCache && (int)threadIdx.x < a.D.n_slots) s_wind[threadIdx.x] = slot_wind<R>(a.D.slots[threadIdx.x]);
-        __syncthreads();
-    }
-    typedef typename VecT<R, 4>::type V4;
-    const bool valid = i < n;
-    const double *srec_storm = a.srec + sid * (int64_t)a.max_rk_steps * step_rec_doubles<R>();
-    R ye[4] = {0, 0, 0, 0}, w[4] = {0, 0, 0, 0};
-    if (valid) {
-        const double te = ts_at(P, i);
-        dense_at<R, 4>(srec_storm, my_step, te, ye);
-        const R *wind = (slot_id < kEmitSlotCache) ? s_wind[slot_id] : slot_wind<R>(a.D.slots[slot_id]);
-        env_winds<R, AFFINE>(K, wind, a.fs + sid * ns * 4, ye[0], ye[1], te, w);
-        a.lon[o] = ye[0]; a.lat[o] = ye[1]; a.v[o] = ye[2]; a.m[o] = ye[3];
-        V4 wv; wv[0] = w[0]; wv[1] = w[1]; wv[2] = w[2]; wv[3] = w[3];
-        *reinterpret_cast<V4 *>(a.envw + o * 4) = wv;
-    }
-    // neighbours along the track: lanes +-1, except across the wave's edges
-    const int lane = threadIdx.x & 63;
-    R lom = __shfl_up(ye[0], 1), lam = __shfl_up(ye[1], 1);
-    R lop = __shfl_down(ye[0], 1), lap = __shfl_down(ye[1], 1);
-    if (valid && n > 1) {
-        if (lane == 0 && i > 0) {
-            R q[2];
-            dense_at<R, 2>(srec_storm, sidx_storm[i - 1], ts_at(P, i - 1), q);
-            lom = q[0]; lam = q[1];
+    for (unsigned w = threadIdx.x; w < sizeof(EvalKT<R>) / 8; w += kPostThreads)       // any workgroup size
+        reinterpret_cast<uint64_t *>(&K_lds)[w] = reinterpret_cast<const uint64_t *>(&a.K)[w];
+    if (threadIdx.x < kEmitSlotCache && (int)threadIdx.x < a.D.n_slots) s_wind[threadIdx.x] = slot_wind<R>(a.D.slots[threadIdx.x]);
+    __syncthreads();
+    // LIST: the bounded grid may have to take several list entries per workgroup; otherwise straight-line code
+    int64_t item = blockIdx.x;
+#pragma unroll 1
+    do {
+        // per-iteration opaque view of the constants: they stay in LDS instead of being hoisted into registers around the loop
+        int koff = 0;
+        asm volatile("" : "+s"(koff));
+        const EvalKT<R> &K = *reinterpret_cast<const EvalKT<R> *>(reinterpret_cast<const char *>(&K_lds) + koff);
+        const int64_t sid = a.list ? (int64_t)a.list[item] : item;
+        // the three per-storm / per-sample indices are independent loads: one round trip, not three
+        const int n = a.n_valid[sid];
+        const int slot_id = a.slot[sid];
+        const uint16_t *sidx_storm = sidx + (size_t)sid * ns;
+        const int my_step = (i < ns) ? sidx_storm[i] : 0;          // meaningful only if i < n
+        const size_t o = (size_t)sid * ns + i;
+        typedef typename VecT<R, 4>::type V4;
+        const bool valid = i < n;
+        const double *srec_storm = a.srec + sid * (int64_t)a.max_rk_steps * step_rec_doubles<R>();
+        R ye[4] = {0, 0, 0, 0}, w[4] = {0, 0, 0, 0};
+        if (valid) {
+            const double te = ts_at(P, i);
+    #if defined(TCR_EMIT_ABLATE) && (TCR_EMIT_ABLATE & 1)
+            ye[0] = R(-60) + R(0.05) * (R)i; ye[1] = R(15) + R(0.03) * (R)i; ye[2] = R(20); ye[3] = R(0.5) + R(1e-3) * (R)my_step;     // timing experiment: no record gather
+    #else
+            dense_at<R, 4>(srec_storm, my_step, te, ye);
+    #endif
+            const R *wind = (slot_id < kEmitSlotCache) ? s_wind[slot_id] : slot_wind<R>(a.D.slots[slot_id]);
+    #if defined(TCR_EMIT_ABLATE) && (TCR_EMIT_ABLATE & 2)
+            w[0] = ye[0] * R(0.1); w[1] = ye[1] * R(0.1); w[2] = R(1); w[3] = (R)(wind != nullptr);            // timing experiment: no wind / forcing gathers
+    #else
+            env_winds<R, AFFINE>(K, wind, a.fs + sid * ns * 4, ye[0], ye[1], te, w);
+    #endif
+            a.lon[o] = ye[0]; a.lat[o] = ye[1]; a.v[o] = ye[2]; a.m[o] = ye[3];
+            V4 wv; wv[0] = w[0]; wv[1] = w[1]; wv[2] = w[2]; wv[3] = w[3];
+            *reinterpret_cast<V4 *>(a.envw + o * 4) = wv;
         }
-        if (lane == 63 && i < n - 1) {
-            R q[2];
-            dense_at<R, 2>(srec_storm, sidx_storm[i + 1], ts_at(P, i + 1), q);
-            lop = q[0]; lap = q[1];
+        // neighbours along the track: lanes +-1, except across the wave's edges
+        const int lane = threadIdx.x & 63;
+        R lom = __shfl_up(ye[0], 1), lam = __shfl_up(ye[1], 1);
+        R lop = __shfl_down(ye[0], 1), lap = __shfl_down(ye[1], 1);
+        if (valid && n > 1) {
+            if (lane == 0 && i > 0) {
+                R q[2];
+                dense_at<R, 2>(srec_storm, sidx_storm[i - 1], ts_at(P, i - 1), q);
+                lom = q[0]; lam = q[1];
+            }
+            if (lane == 63 && i < n - 1) {
+                R q[2];
+                dense_at<R, 2>(srec_storm, sidx_storm[i + 1], ts_at(P, i + 1), q);
+                lop = q[0]; lap = q[1];
+            }
+            // linear extrapolation at both ends (sphere.py:66-69): the neighbour on the other side is
+            // sample 1 / n-2, i.e. lop / lom of this very lane
+            const R lop_in = lop, lap_in = lap, lom_in = lom, lam_in = lam;
+            if (i == 0) { lom = R(2) * ye[0] - lop_in; lam = R(2) * ye[1] - lap_in; }
+            if (i == n - 1) { lop = R(2) * ye[0] - lom_in; lap = R(2) * ye[1] - lam_in; }
+            const R vm = vmax_at<R>(P, ye[0], ye[1], ye[2], w[0] - w[2], w[1] - w[3], lom, lam, lop, lap);
+            a.vmax[o] = vm;
+            const bool hit_v = ye[2] >= (R)P.v_thresh, hit_vm = vm >= (R)P.vmax_thresh;
+            const int bits = (__ballot(hit_v) ? kBitAny15 : 0) | (__ballot(hit_vm) ? kBitVmax : 0);
+            if (bits && lane == (__ffsll((long long)__ballot(true)) - 1)) atomicOr(a.flags + sid, bits);
+        } else if (valid) {                                   // n == 1: no translation speed, vmax stays NaN
+            a.vmax[o] = nan;
+            if (ye[2] >= (R)P.v_thresh) atomicOr(a.flags + sid, kBitAny15);
+        } else {
+            // NaN padding, only where the row is not known to be padded already
+            int pad_to = a.pad_state ? a.pad_state[sid] : ns;
+            pad_to = (pad_to < 0 || pad_to > ns) ? ns : pad_to;
+            if (i < pad_to) {
+                a.lon[o] = nan; a.lat[o] = nan; a.v[o] = nan; a.m[o] = nan; a.vmax[o] = nan;
+                V4 nv; nv[0] = nan; nv[1] = nan; nv[2] = nan; nv[3] = nan;
+                *reinterpret_cast<V4 *>(a.envw + o * 4) = nv;
+            }
         }
-        // linear extrapolation at both ends (sphere.py:66-69): the neighbour on the other side is
-        // sample 1 / n-2, i.e. lop / lom of this very lane
-        const R lop_in = lop, lap_in = lap, lom_in = lom, lam_in = lam;
-        if (i == 0) { lom = R(2) * ye[0] - lop_in; lam = R(2) * ye[1] - lap_in; }
-        if (i == n - 1) { lop = R(2) * ye[0] - lom_in; lap = R(2) * ye[1] - lam_in; }
-        const R vm = vmax_at<R>(P, ye[0], ye[1], ye[2], w[0] - w[2], w[1] - w[3], lom, lam, lop, lap);
-        a.vmax[o] = vm;
-        const bool hit_v = ye[2] >= (R)P.v_thresh, hit_vm = vm >= (R)P.vmax_thresh;
-        const int bits = (__ballot(hit_v) ? kBitAny15 : 0) | (__ballot(hit_vm) ? kBitVmax : 0);
-        if (bits && lane == (__ffsll((long long)__ballot(true)) - 1)) atomicOr(a.flags + sid, bits);
-    } else if (valid) {                                   // n == 1: no translation speed, vmax stays NaN
-        a.vmax[o] = nan;
-        if (ye[2] >= (R)P.v_thresh) atomicOr(a.flags + sid, kBitAny15);
-    } else {
-        // NaN padding, only where the row is not known to be padded already
-        int pad_to = a.pad_state ? a.pad_state[sid] : ns;
-        pad_to = (pad_to < 0 || pad_to > ns) ? ns : pad_to;
-        if (i < pad_to) {
-            a.lon[o] = nan; a.lat[o] = nan; a.v[o] = nan; a.m[o] = nan; a.vmax[o] = nan;
-            V4 nv; nv[0] = nan; nv[1] = nan; nv[2] = nan; nv[3] = nan;
-            *reinterpret_cast<V4 *>(a.envw + o * 4) = nv;
-        }
-    }
+    } while (LIST && (item += gridDim.x) < n_items);
 }
 
 // k_screen: accept test 1 (util/compute.py:185-189) without producing a single row.  The reference
@@ -1101,66 +1123,98 @@ __global__ __launch_bounds__(kScreenThreads) void k_screen(EArgsT<R> a)
     const int j2d = clamp2d ? n - 1 : (int)floor(t2d / step_out);
     bool any15 = false;
     const double *vrec_storm = a.vrec + sid * (int64_t)a.max_rk_steps * kVRec;
-    for (int j = l; j < nst && n > 0; j += kScreenGroup) {
+    // One accepted step of the storm: the v row of Q = K^T P and the samples the step emits
+    struct StepV {
+        double t_old, h64;
+        R hh, y0, Q[4];
+        int i_lo, i_hi;
+    };
+    auto load_step = [&](int j) {
         // (values were stored widened to fp64; narrowing back gives the R values k_dense reads from the full record)
         const double2 *rj = reinterpret_cast<const double2 *>(vrec_storm + (size_t)j * kVRec);
         const double2 r0 = rj[0], r1 = rj[1], r2 = rj[2], r3 = rj[3], r4 = rj[4], r5 = rj[5];
-        const double t_old = r0.x, h64 = r0.y, t_new = r1.x;
-        const R hh = (R)h64, y0 = (R)r1.y;
+        StepV s;
+        s.t_old = r0.x; s.h64 = r0.y;
+        const double t_new = r1.x;
+        s.hh = (R)s.h64; s.y0 = (R)r1.y;
         const R kq[7] = {(R)r2.x, (R)r2.y, (R)r3.x, (R)r3.y, (R)r4.x, (R)r4.y, (R)r5.x};
-        R Q[4];
         for (int k = 0; k < 4; ++k) {
             R acc = R(0.0);
             for (int q = 0; q < 7; ++q) acc += kq[q] * R(RK_P[q][k]);
-            Q[k] = acc;
+            s.Q[k] = acc;
         }
-        const int i_lo = (j == 0) ? 0 : samples_upto(P, t_old);
-        int i_hi = samples_upto(P, t_new);
-        i_hi = i_hi < n ? i_hi : n;
-        // dense output of v at sample i, exactly as dense_at forms it: x = (t_i - t_old) / h
-        auto v_at = [&](int i) -> R {
-            const R x = (R)((ts_at(P, i) - t_old) / h64);
-            const R p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
-            R acc = R(0.0);
-            acc += Q[0] * p1; acc += Q[1] * p2; acc += Q[2] * p3; acc += Q[3] * p4;
-            return hh * acc + y0;
-        };
-        // `any(v >= v_thresh)`: this kernel is bound by fp64 issue and the division per sample is two thirds of the
-        // loop, so every sample is first judged with x = (t_i - t_old) * (1 / h) and Horner's form — within 1e-13 (fp32:
-        // 1e-5) of the exact value — and only a sample that lands within `band` of the threshold is evaluated exactly
-        // (a wave-uniform branch the compiler cannot turn into straight-line code): the decision is the exact one
-        const double rh = 1.0 / h64;
-        const R thr = (R)P.v_thresh, band = sizeof(R) == 8 ? R(1e-9) : R(2e-3);
-        for (int i = i_lo; i < i_hi; ++i) {
-            const R x = (R)((ts_at(P, i) - t_old) * rh);
-            const R v_f = hh * (x * (Q[0] + x * (Q[1] + x * (Q[2] + x * Q[3])))) + y0;
+        s.i_lo = (j == 0) ? 0 : samples_upto(P, s.t_old);
+        s.i_hi = samples_upto(P, t_new);
+        s.i_hi = s.i_hi < n ? s.i_hi : n;
+        return s;
+    };
+    // dense output of v at sample i, exactly as dense_at forms it: x = (t_i - t_old) / h
+    auto v_at = [&](const StepV &s, int i) -> R {
+        const R x = (R)((ts_at(P, i) - s.t_old) / s.h64);
+        const R p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
+        R acc = R(0.0);
+        acc += s.Q[0] * p1; acc += s.Q[1] * p2; acc += s.Q[2] * p3; acc += s.Q[3] * p4;
+        return s.hh * acc + s.y0;
+    };
+    // ---- phase 1: the 2-day test (three exact samples at most) — most storms fail it, and those need no more
+    auto caps = [&](const StepV &s) {
+        if (s.i_lo <= j2d && j2d < s.i_hi) cap[g][0] = v_at(s, j2d);
+        if (s.i_lo <= j2d + 1 && j2d + 1 < s.i_hi) cap[g][1] = v_at(s, j2d + 1);
+        if (s.i_lo <= n - 1 && n - 1 < s.i_hi) cap[g][2] = v_at(s, n - 1);
+    };
+#if defined(TCR_SCREEN_ABLATE) && TCR_SCREEN_ABLATE == 2
+    n = 0;
+#endif
+    const bool has0 = l < nst && n > 0;
+    StepV s0{};                                          // the lane's first step stays in registers for phase 2
+    if (has0) { s0 = load_step(l); caps(s0); }
+    for (int j = l + kScreenGroup; j < nst && n > 0; j += kScreenGroup) caps(load_step(j));
+    __syncthreads();
+    bool pass2d = false;
+    if (n > 0 && st != TCR_STATUS_GATED) {
+        double v2d;
+        if (clamp2d) v2d = (double)cap[g][2];
+        else v2d = interp_v2d<R>(cap[g][0], cap[g][1], ts_at(P, j2d), ts_at(P, j2d + 1), t2d);
+        pass2d = v2d >= P.v_2d_thresh;
+    }
+#if defined(TCR_SCREEN_ABLATE)
+    pass2d = false;
+#endif
+    // ---- phase 2: `any(v >= v_thresh)` over the hourly samples, only for the storms that passed.
+    // A step whose dense output cannot reach the threshold anywhere is skipped without looking at its samples:
+    // on x in [0, 1] every term Q_k x^(k+1) is at most max(Q_k, 0), so v <= y0 + |h| sum max(Q_k, 0) (h > 0 here); the
+    // margin (1e-3 m/s; fp32: 1e-2) is orders of magnitude above the rounding of either side.  A step that can
+    // reach it is walked until its first hit.  Each sample is first judged with x = (t_i - t_old) * (1 / h) and
+    // Horner's form — within 1e-13 (fp32: 1e-5) of the exact value — and only a sample that lands within `band` of the
+    // threshold is evaluated exactly as dense_at does (a wave-uniform branch the compiler cannot turn into
+    // straight-line code): the decision is the exact one in every case.
+    const R thr = (R)P.v_thresh, band = sizeof(R) == 8 ? R(1e-9) : R(2e-3), margin = sizeof(R) == 8 ? R(1e-3) : R(1e-2);
+    auto scan = [&](const StepV &s) {
+        const R z = R(0.0);
+        const R up = (s.Q[0] > z ? s.Q[0] : z) + (s.Q[1] > z ? s.Q[1] : z) + (s.Q[2] > z ? s.Q[2] : z) + (s.Q[3] > z ? s.Q[3] : z);
+        const R ub = s.y0 + fabs(s.hh) * up;
+        if (ub < thr - margin) return;                  // NaNs fall through to the walk
+        const double rh = 1.0 / s.h64;
+        for (int i = s.i_lo; i < s.i_hi && !any15; ++i) {
+            const R x = (R)((ts_at(P, i) - s.t_old) * rh);
+            const R v_f = s.hh * (x * (s.Q[0] + x * (s.Q[1] + x * (s.Q[2] + x * s.Q[3])))) + s.y0;
             bool hit = v_f >= thr + band;
             const bool amb = !hit && v_f >= thr - band;
             if (__ballot(amb)) {
                 asm volatile("" ::: "memory");
-                if (amb) hit = v_at(i) >= thr;
+                if (amb) hit = v_at(s, i) >= thr;
             }
             any15 = any15 || hit;
         }
-        // the samples np.interp(2 d, res.t, v) can read: exact
-        if (i_lo <= j2d && j2d < i_hi) cap[g][0] = v_at(j2d);
-        if (i_lo <= j2d + 1 && j2d + 1 < i_hi) cap[g][1] = v_at(j2d + 1);
-        if (i_lo <= n - 1 && n - 1 < i_hi) cap[g][2] = v_at(n - 1);
+    };
+    if (pass2d) {
+        if (has0) scan(s0);
+        for (int j = l + kScreenGroup; j < nst; j += kScreenGroup) scan(load_step(j));
     }
     int hit = any15 ? 1 : 0;
     for (int off = kScreenGroup / 2; off > 0; off >>= 1) hit |= __shfl_xor(hit, off);       // every lane takes part
     any15 = hit != 0;
-    __syncthreads();
-    if (on && l == 0) {
-        int fl = 0;
-        if (n > 0 && st != TCR_STATUS_GATED) {
-            double v2d;
-            if (clamp2d) v2d = (double)cap[g][2];
-            else v2d = interp_v2d<R>(cap[g][0], cap[g][1], ts_at(P, j2d), ts_at(P, j2d + 1), t2d);
-            if (any15 && v2d >= P.v_2d_thresh) fl = TCR_FLAG_IS_TC;
-        }
-        a.flags[sid] = fl;
-    }
+    if (on && l == 0) a.flags[sid] = (any15 && pass2d) ? TCR_FLAG_IS_TC : 0;
 }
 
 template <typename R>
