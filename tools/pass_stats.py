@@ -15,8 +15,9 @@ for _ in range(3):
 print('integrate %.3f ms' % eng.timing_last()['integrate_ms'])
 ps = eng.pass_stats()
 for i, p in enumerate(ps):
-    print('pass %2d: requests %7d parked %6d wave-cycles %6d lane-util %.3f wave-ms %8.1f us/cycle %5.1f shader %4.0f MHz' % (
+    uc = 1e3 * p['wave_ms'] / max(1, p['wave_cycles'])
+    print('pass %2d: requests %7d parked %6d wave-cycles %6d lane-util %.3f wave-ms %8.1f us/cycle %5.1f shader %4.0f MHz kclk/cycle %5.1f' % (
         i, p['requests'], p['parked'], p['wave_cycles'], p['lane_cycles'] / max(1, 64 * p['wave_cycles']), p['wave_ms'],
-        1e3 * p['wave_ms'] / max(1, p['wave_cycles']), p['shader_mhz']))
+        uc, p['shader_mhz'], uc * p['shader_mhz'] / 1e3))
 tc = sum(p['wave_cycles'] for p in ps); tl = sum(p['lane_cycles'] for p in ps); tm = sum(p['wave_ms'] for p in ps)
 print('total: wave-cycles %d lane-util %.3f wave-ms %.1f' % (tc, tl / (64.0 * tc), tm))

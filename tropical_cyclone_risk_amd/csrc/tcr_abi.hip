@@ -480,8 +480,8 @@ int launch_fourier(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const double *
             if (grow(ctx, &p, &ctx->pf_cap, (size_t)tiles * kFsMfmaKSteps * 64)) { ctx->d_pf = nullptr; return -1; }
             ctx->d_pf = reinterpret_cast<double2 *>(p);
             hipLaunchKernelGGL(k_phase_factors_frag, dim3((unsigned)tiles), dim3(256), 0, st, P, n, n_dev, phases, p);
-            const unsigned wgs = (unsigned)std::min<int64_t>(tiles, (int64_t)ctx->cu_count * kFsMfmaWgsPerCu);
-            hipLaunchKernelGGL(k_fourier_mfma<R>, dim3(wgs), dim3(64 * kFsMfmaWaves), 0, st, P, n, n_dev, ctx->fs_period, ctx->d_sc_table, p, fs);
+            const unsigned wgs = (unsigned)std::min<int64_t>(tiles, std::max<int64_t>(1, (int64_t)ctx->cu_count * kFsMfmaWgsPerCu / kFsMfmaColGroups));
+            hipLaunchKernelGGL(k_fourier_mfma<R>, dim3(wgs, kFsMfmaColGroups), dim3(64 * kFsMfmaWaves), 0, st, P, n, n_dev, ctx->fs_period, ctx->d_sc_table, p, fs);
         } else {
             hipLaunchKernelGGL(k_phase_factors, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, P, n, n_dev, phases, ctx->d_pf);
             hipLaunchKernelGGL(k_fourier_periodic<R>, dim3((unsigned)n), dim3(kFsThreads), lds, st, P, n, n_dev,

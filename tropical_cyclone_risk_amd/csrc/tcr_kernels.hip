@@ -223,9 +223,11 @@ __global__ __launch_bounds__(kFsThreads) void k_fourier_periodic(tcr_params P, i
 #ifndef TCR_FS_MFMA_WPS
 #define TCR_FS_MFMA_WPS 2
 #endif
-constexpr int kFsMfmaColTiles = TCR_FS_MFMA_TILES;          // column tiles per wave (6 / 4 / 3: four / six / eight waves per workgroup)
-constexpr int kFsMfmaWaves = 24 / kFsMfmaColTiles;
-constexpr int kFsMfmaWgsPerCu = TCR_FS_MFMA_WPS * 4 / kFsMfmaWaves > 0 ? TCR_FS_MFMA_WPS * 4 / kFsMfmaWaves : 1;
+constexpr int kFsMfmaColTiles = TCR_FS_MFMA_TILES;          // column tiles per wave (6 / 3 / 2: one / two / four workgroups along y share the samples)
+constexpr int kFsMfmaWaves = 4;                                       // waves per workgroup: one per SIMD
+constexpr int kFsMfmaColGroups = 24 / (kFsMfmaWaves * kFsMfmaColTiles);   // workgroups along y that together cover the 24 column tiles
+constexpr int kFsMfmaWgsPerCu = TCR_FS_MFMA_WPS;
+static_assert(kFsMfmaColGroups * kFsMfmaWaves * kFsMfmaColTiles == 24, "column tiles per wave must be 6, 3, 2 or 1");
 constexpr int kFsMfmaKSteps = 8;            // K = 32 >= 2 * n_series
 constexpr int kFsMfmaMaxSamples = 24 * 16;
 
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(64 * kFsMfmaWaves, TCR_FS_MFMA_WPS) void k_fourier_
     double B[kFsMfmaColTiles][kFsMfmaKSteps];
 #pragma unroll
     for (int t = 0; t < kFsMfmaColTiles; ++t) {
-        const int col = (wave * kFsMfmaColTiles + t) * 16 + (lane & 15);
+        const int col = ((blockIdx.y * kFsMfmaWaves + wave) * kFsMfmaColTiles + t) * 16 + (lane & 15);
 #pragma unroll
         for (int ks = 0; ks < kFsMfmaKSteps; ++ks) {
             const int k = (lane >> 4) + 4 * ks, h = k >> 1;
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(64 * kFsMfmaWaves, TCR_FS_MFMA_WPS) void k_fourier_
         for (int ks = 0; ks < kFsMfmaKSteps; ++ks) An[ks] = (nxt < tiles) ? frag[nxt * (kFsMfmaKSteps * 64) + ks * 64 + lane] : 0.0;
 #pragma unroll
         for (int t = 0; t < kFsMfmaColTiles; ++t) {
-            const int k0 = (wave * kFsMfmaColTiles + t) * 16;
+            const int k0 = ((blockIdx.y * kFsMfmaWaves + wave) * kFsMfmaColTiles + t) * 16;
             if (k0 >= ns) break;                                // wave-uniform: this wave's last column tiles lie beyond the track
             D4 acc = D4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
