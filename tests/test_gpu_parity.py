@@ -183,12 +183,12 @@ def _namelist_with(**over):
     return nl
 
 
-@pytest.mark.parametrize('dt_out,days,T_days', [(5400, 10, 20), (7000, 15, 20), (3600, 15, 17.3), (21600, 6, 20)])
+@pytest.mark.parametrize('dt_out,days,T_days', [(5400, 10, 20), (7000, 15, 20), (3600, 15, 17.3), (21600, 6, 20), (1800, 9, 20)])
 def test_other_output_grids(golden_env, built_lib, dt_out, days, T_days):
     """Non-default namelist time settings: n_steps != 361, output intervals that do not divide
     the track length (np.linspace step != dt_out, bam_track.py:54-55), and a Fourier period that
     is not a whole number of output intervals (direct k_fourier_direct path instead of the
-    periodic table)."""
+    periodic table); 1800 s x 9 d = 433 samples is beyond the matrix-core kernel's 384 (k_fourier_periodic)."""
     from oracle import c_oracle, scipy_port
     from tropical_cyclone_risk_amd import synthetic
     from tropical_cyclone_risk_amd.engine import TCEngine
@@ -332,6 +332,18 @@ def test_tc_rows_only_matches_all_rows(golden_env, built_lib):
         assert st[4] == is_tc.sum() and st[5] == a['n_valid'][is_tc].sum() and st[3] == a['accepted'].sum()
         assert st[0] == np.clip(a['n_valid'] - 1, 0, None).sum() and st[1] == a['nfev'].sum() and st[2] == a['n_valid'].sum()
         del full
+    # the bounded grids of k_dense / k_emit over the TC list: with 64 workgroup rows every workgroup takes ~30 list
+    # entries in turn; rows and flags must not depend on the grid
+    os.environ['TCR_EMIT_GRID_CAP'] = '64'
+    try:
+        tc2 = DevicePipeline(eng, 200_000, B, tc_rows_only=True)
+        tc2.seed_round(2002, 0); tc2.select_passed(B); tc2.integrate(B)
+        c = tc2.host_tracks()
+    finally:
+        del os.environ['TCR_EMIT_GRID_CAP']
+    assert np.array_equal(c['flags'], b['flags']) and c['is_tc'].sum() > 64 * 3
+    for k in keys:
+        assert np.array_equal(c[k][is_tc], b[k][is_tc], equal_nan=True), k
     eng.close()
 
 

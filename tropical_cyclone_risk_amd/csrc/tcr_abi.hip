@@ -581,10 +581,12 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
             a.list = ctx->d_tc_idx; a.count = ctx->d_tc_count;
         }
         // k_dense, TC rows only: a bounded grid of waves walks the device-side list (one wave per storm otherwise)
-        const unsigned gx = out.tc_rows_only ? (unsigned)std::min<int64_t>(n, kEmitGridCap) : (unsigned)n;
+        int64_t cap = kEmitGridCap;
+        if (const char *e = getenv("TCR_EMIT_GRID_CAP")) { const long v = atol(e); if (v > 0) cap = v; }     // tests: force several list entries per workgroup
+        const unsigned gx = out.tc_rows_only ? (unsigned)std::min<int64_t>(n, cap) : (unsigned)n;
         hipLaunchKernelGGL(k_dense<R>, dim3(gx), dim3(kWave), 0, st, a, ctx->d_sidx);
         // TC rows only: a bounded grid walks the device-side list (all rows: one row of workgroups per storm)
-        const unsigned ex = out.tc_rows_only ? (unsigned)std::min<int64_t>(n, kEmitGridCap) : (unsigned)n;
+        const unsigned ex = gx;
         if (out.tc_rows_only) {
             if (affine) hipLaunchKernelGGL((k_emit<R, true, true>), dim3(ex, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
             else hipLaunchKernelGGL((k_emit<R, false, true>), dim3(ex, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
