@@ -84,7 +84,7 @@ def test_rhs_vs_reference_golden(engines, name, slot):
     assert np.abs(envw - g['envw']).max() < 1e-12
     assert np.abs(alpha - g['alpha']).max() < 1e-13
     Fs = eng.fourier_table(g['phases'][None])[0]
-    assert np.abs(Fs - g["Fs"]).max() < 5e-14      # periodic-table evaluation, see k_fourier_periodic
+    assert np.abs(Fs - g["Fs"]).max() < 5e-14      # periodic-table evaluation on the matrix cores, see k_fourier_mfma
 
 
 @pytest.mark.parametrize('basin,n,seed', [('NA', 4000, 77), ('GL', 2000, 78), ('SI', 1000, 79)])
