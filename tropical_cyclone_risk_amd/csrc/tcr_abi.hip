@@ -591,8 +591,17 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
         // TC rows only: a bounded grid walks the device-side list (all rows: one row of workgroups per storm)
         const unsigned ex = gx;
         if (out.tc_rows_only) {
-            if (affine) hipLaunchKernelGGL((k_emit<R, true, true>), dim3(ex, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
-            else hipLaunchKernelGGL((k_emit<R, false, true>), dim3(ex, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
+            // list entries [0, ex): one per workgroup row, straight-line kernel; entries beyond the bounded grid (none
+            // unless more than `cap` storms pass accept test 1): a small grid that loops
+            if (affine) hipLaunchKernelGGL((k_emit<R, true, false>), dim3(ex, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
+            else hipLaunchKernelGGL((k_emit<R, false, false>), dim3(ex, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
+            if ((int64_t)ex < n) {
+                a.item_base = ex;
+                const unsigned ov = (unsigned)std::min<int64_t>(n - ex, 256);
+                if (affine) hipLaunchKernelGGL((k_emit<R, true, true>), dim3(ov, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
+                else hipLaunchKernelGGL((k_emit<R, false, true>), dim3(ov, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
+                a.item_base = 0;
+            }
         } else {
             if (affine) hipLaunchKernelGGL((k_emit<R, true, false>), dim3(ex, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
             else hipLaunchKernelGGL((k_emit<R, false, false>), dim3(ex, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);

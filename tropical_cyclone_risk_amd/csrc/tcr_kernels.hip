@@ -846,6 +846,7 @@ struct EArgsT {
     // found to pass accept test 1 — instead of over every storm of the batch (list == NULL)
     const int32_t *list;
     const int64_t *count;
+    int64_t item_base;           // k_emit's overflow launch: first list entry it handles
     EvalKT<R> K;                 // built on the host; k_emit's small workgroups copy it to LDS
 };
 using EArgs = EArgsT<double>;
@@ -1006,7 +1007,7 @@ __global__ __launch_bounds__(kPostThreads, TCR_EMIT_WPS) void k_emit(EArgsT<R> a
     // Work items along x: every existing row, or (TC rows only) the device-side list walked by a bounded grid —
     // a grid sized for the whole batch spent 40 us per 100 000 storms on workgroups that only read the count and left.
     const int64_t n_items = a.list ? *a.count : n_eff(a.n, a.n_dev);
-    if ((int64_t)blockIdx.x >= n_items) return;                        // uniform per workgroup
+    if ((int64_t)blockIdx.x + (LIST ? a.item_base : 0) >= n_items) return;       // uniform per workgroup
     const int ns = P.n_steps;
     const int i = blockIdx.y * kPostThreads + threadIdx.x;
     const R nan = (R)__longlong_as_double(0x7ff8000000000000LL);
@@ -1014,8 +1015,9 @@ __global__ __launch_bounds__(kPostThreads, TCR_EMIT_WPS) void k_emit(EArgsT<R> a
         reinterpret_cast<uint64_t *>(&K_lds)[w] = reinterpret_cast<const uint64_t *>(&a.K)[w];
     if (threadIdx.x < kEmitSlotCache && (int)threadIdx.x < a.D.n_slots) s_wind[threadIdx.x] = slot_wind<R>(a.D.slots[threadIdx.x]);
     __syncthreads();
-    // LIST: the bounded grid may have to take several list entries per workgroup; otherwise straight-line code
-    int64_t item = blockIdx.x;
+    // LIST: this launch walks list entries item_base + blockIdx.x, + gridDim.x, ... (the overflow launch behind a bounded
+    // grid); otherwise one entry per workgroup and straight-line code (90 instead of 130 VGPRs: 5 instead of 3 waves per SIMD)
+    int64_t item = blockIdx.x + (LIST ? a.item_base : 0);
 #pragma unroll 1
     do {
         // per-iteration opaque view of the constants: they stay in LDS instead of being hoisted into registers around the loop
