@@ -62,7 +62,7 @@ struct KArgsT {
 using KArgs = KArgsT<double>;
 constexpr int kVRec = 12;
 constexpr int kMaxPasses = 16;
-constexpr int kParkRec = 16;     // doubles per parked storm: t, h, t_new, ha, g, y[4], f[4], 6 x int32
+constexpr int kParkRec = 18;     // doubles per parked storm: t, h, t_new, ha, g, y[4], f[4], 6 x int32, h_bl, field slot
 
 // ---------------------------------------------------------------------------
 // gen_f (track/bam_track.py:23-31), direct form: one thread per (storm, sample),
@@ -440,6 +440,7 @@ constexpr int kWave = 64;
 #define TCR_INT_PIPELINE 0   // 1: the next stage point's gathers are issued ahead of the intensity half (measured: +4 % time)
 #endif
 constexpr int kRunning = 99;
+constexpr int kIntSlotCache = 32;     // field-slot pointers kept in LDS by k_integrate
 template <typename R> constexpr int int_wps() { return sizeof(R) == 8 ? TCR_INT_WPS : TCR_INT_WPS_F32; }
 // Register cap of the integrator (build knob for the experiment in DESIGN.md §9): amdgpu_num_vgpr(N) makes the kernel
 // allocate 256 + (2N - 256) registers of the SIMD's 512, so that the small kernels of the batches other streams have in
@@ -472,6 +473,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
     // Kl[(stage*4 + component)*64 + lane]
     __shared__ R Kl[7 * 4 * kWave];
     __shared__ EvalKT<R> K;
+    __shared__ const R *s_wind[kIntSlotCache], *s_thermo[kIntSlotCache];     // month slot -> field planes: a refill reads LDS, not HBM
     const tcr_params &P = a.P;
     const DevFields &D = a.D;
     const int lane = threadIdx.x;
@@ -480,6 +482,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
     unsigned long long *const q_head = a.queue + a.pass;
     for (unsigned w = lane; w < sizeof(EvalKT<R>) / 8; w += kWave)
         reinterpret_cast<uint64_t *>(&K)[w] = reinterpret_cast<const uint64_t *>(&a.K)[w];
+    if (lane < kIntSlotCache && lane < D.n_slots) { const DevSlot S = D.slots[lane]; s_wind[lane] = slot_wind<R>(S); s_thermo[lane] = slot_thermo<R>(S); }
     __syncthreads();
     const int ns = P.n_steps;
     const double tb = P.total_time;
@@ -495,6 +498,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
     const R *fs = nullptr;
     double *srec = nullptr;
     R h_bl = R(0.0);
+    int cur_slot = 0;                       // the storm's field slot (travels in the park record)
     R y[4] = {0, 0, 0, 0}, f[4] = {0, 0, 0, 0}, yn[4] = {0, 0, 0, 0};
     R e[4] = {0, 0, 0, 0};                  // evaluation point: lon, lat, v, m
     double et = 0;                          // ... and its time
@@ -565,9 +569,16 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
                 if (item >= n_items) {
                     exhausted = true;
                 } else {
+                    // Everything a lane needs to take a storm arrives in ONE round trip behind the queue's: the six
+                    // per-storm inputs (or the park record, which carries h_bl and the field slot as well), then the
+                    // slot's planes from LDS.  (As five dependent trips — inputs, slot, h_bl, slot table — the refill
+                    // cost every cycle of the first pass, which always has a lane to refill, 3-4 of its 42 us.)
+                    int slot_id;
                     if (a.pass == 0) {
                         sid = item;
-                        y[0] = (R)a.lon0[sid]; y[1] = (R)a.lat0[sid]; y[2] = (R)a.v0[sid]; y[3] = (R)a.m0[sid];
+                        const double lo0 = a.lon0[sid], la0 = a.lat0[sid], vv0 = a.v0[sid], mm0 = a.m0[sid], hb0 = a.h_bl[sid];
+                        slot_id = a.slot[sid];
+                        y[0] = (R)lo0; y[1] = (R)la0; y[2] = (R)vv0; y[3] = (R)mm0; h_bl = (R)hb0;
                         status = kRunning; nfev = 0; nacc = 0; nrej = 0; next_out = 0;
                         t = 0.0;
                         et = 0.0; e[0] = y[0]; e[1] = y[1]; e[2] = y[2]; e[3] = y[3];
@@ -575,7 +586,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
                     } else {
                         // restore a parked storm: the state between two attempts of _step_impl
                         const double2 *r = reinterpret_cast<const double2 *>(a.park_in + (size_t)item * kParkRec);
-                        const double2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7];
+                        const double2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7], r8 = r[8];
                         t = r0.x; h = r0.y; t_new = r1.x; ha = r1.y; g = (R)r2.x;
                         y[0] = (R)r2.y; y[1] = (R)r3.x; y[2] = (R)r3.y; y[3] = (R)r4.x;
                         f[0] = (R)r4.y; f[1] = (R)r5.x; f[2] = (R)r5.y; f[3] = (R)r6.x;
@@ -583,6 +594,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
                         const long long c0 = __double_as_longlong(r7.x), c1 = __double_as_longlong(r7.y);
                         nfev = (int)(c0 & 0xffffffffll); nacc = (int)(c0 >> 32);
                         nrej = (int)(c1 & 0x7fffffffll); rejected = (c1 >> 31) & 1; next_out = (int)(c1 >> 32);
+                        h_bl = (R)r8.x; slot_id = (int)__double_as_longlong(r8.y);
                         status = kRunning;
                         // stage-2 input exactly as attempt_setup left it
                         for (int i = 0; i < 4; ++i) {
@@ -593,11 +605,11 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
                         et = t + RK_C[1] * h;
                         fresh = false;
                     }
-                    const DevSlot S = D.slots[a.slot[sid]];
-                    wind = slot_wind<R>(S); thermo = slot_thermo<R>(S);
+                    if (slot_id < kIntSlotCache) { wind = s_wind[slot_id]; thermo = s_thermo[slot_id]; }
+                    else { const DevSlot S = D.slots[slot_id]; wind = slot_wind<R>(S); thermo = slot_thermo<R>(S); }
+                    cur_slot = slot_id;
                     fs = a.fs + sid * ns * 4;
                     srec = a.srec + sid * (long long)a.max_rk_steps * REC;
-                    h_bl = (R)a.h_bl[sid];
                     active = true;
                     cache_reset(CC);
                     // the refill's loads complete here (vmcnt(0); expcnt / lgkmcnt untouched): otherwise their first use
@@ -623,6 +635,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
                 o[5] = make_double2((double)f[1], (double)f[2]);
                 o[6] = make_double2((double)f[3], __longlong_as_double(sid));
                 o[7] = make_double2(__longlong_as_double(c0), __longlong_as_double(c1));
+                o[8] = make_double2((double)h_bl, __longlong_as_double((long long)cur_slot));
             }
             break;
         }
