@@ -305,6 +305,11 @@ __global__ __launch_bounds__(64 * kFsMfmaWaves, TCR_FS_MFMA_WPS) void k_fourier_
     double *const stg = stage[wave];
     auto epilogue_piece = [&](int piece) {
         if (!ep.live) return;                                   // wave-uniform
+#if defined(TCR_FS_ABLATE) && (TCR_FS_ABLATE & 8)
+        // timing experiment: the store pattern alone (no scaling, no LDS staging; table contents wrong)
+        if (sizeof(R) == 8 && piece != 5 && piece != 6) return;
+        if (sizeof(R) == 8) { ep.d0 = make_double2(ep.v[0], ep.v[1]); ep.d1 = make_double2(ep.v[2], ep.v[3]); }
+#endif
         if (sizeof(R) == 8) {
             switch (piece) {
             case 0: ep.v[0] = amp * ep.v[0]; ep.v[1] = amp * ep.v[1]; ep.v[2] = amp * ep.v[2]; ep.v[3] = amp * ep.v[3]; break;
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(64 * kFsMfmaWaves, TCR_FS_MFMA_WPS) void k_fourier_
                 const int64_t storm = ep.tile * 4 + 2 * i + (lane >> 5);
                 const int k = ep.k0 + ((lane & 31) >> 1);
                 const double2 d = i ? ep.d1 : ep.d0;
-#if defined(TCR_FS_ABLATE) && TCR_FS_ABLATE == 1
+#if defined(TCR_FS_ABLATE) && (TCR_FS_ABLATE & 1)
                 if (storm < ne && k < ns && d.x == 1.2345e300)    // timing experiment: no stores
 #else
                 if (storm < ne && k < ns)
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(64 * kFsMfmaWaves, TCR_FS_MFMA_WPS) void k_fourier_
         } else if (piece == 5) {
             const int64_t storm = ep.tile * 4 + q;
             const int k = ep.k0 + j;
-#if defined(TCR_FS_ABLATE) && TCR_FS_ABLATE == 1
+#if defined(TCR_FS_ABLATE) && (TCR_FS_ABLATE & 1)
             if (storm < ne && k < ns && ep.v[0] == 1.2345e300)
 #else
             if (storm < ne && k < ns)
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(64 * kFsMfmaWaves, TCR_FS_MFMA_WPS) void k_fourier_
             D4 acc = D4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int ks = 0; ks < kFsMfmaKSteps; ++ks) {
-#if defined(TCR_FS_ABLATE) && TCR_FS_ABLATE == 2
+#if defined(TCR_FS_ABLATE) && (TCR_FS_ABLATE & 2)
                 acc[ks & 3] += A[ks] * B[t][ks];              // timing experiment: no matrix instructions (values wrong)
 #else
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ks], B[t][ks], acc, 0, 0, 0);
