@@ -18,7 +18,9 @@ Only tests/ and __graft_entry__.smoke() import this.
 """
 import numpy as np
 
-TOL_ALL = 1e-6        # every sample of every decision-identical storm
+TOL_ALL = 1e-6        # every sample of every decision-identical storm (ensembles of up to a few thousand storms; the
+                      # tail grows with the ensemble exactly as the oracle's own response to a one-ulp input change does:
+                      # profiles/r02_parity_study.json)
 TOL_99 = 1e-8         # 99 % of those storms (max over the storm's samples)
 TOL_95 = 1e-9         # 95 % of those storms
 # samples before the first differing decision: the same tiers, over the storms that have such a prefix
@@ -55,13 +57,15 @@ def _storm_maxdiff(a, b):
 
 
 def check_tracks(tag, got, want, dec_got, dec_want, t0_want, t_s, counters=('status', 'n_valid', 'nfev'),
-                 flags=('is_tc', 'accepted'), names=('traj', 'envw', 'vmax'), verbose=True):
+                 flags=('is_tc', 'accepted'), names=('traj', 'envw', 'vmax'), verbose=True, tol_all=TOL_ALL):
     """Assert pointwise / prefix parity of `got` against `want` (dicts of arrays: traj [n,4,ns],
     envw [n,ns,4], vmax [n,ns], status, n_valid, nfev, is_tc, accepted ...).
 
     dec_*: [n, cap] decision probes (bit0 `land == 1`, bit1 PI != 0, bit2 land within 1e-12 of 1; 0xff
     = not evaluated); t0_want [n, cap]: start time of the step attempt of each evaluation of `want`.
-    Returns a summary dict (counts of storms per class, exposure among accepted storms)."""
+    Returns a summary dict (counts of storms per class, exposure among accepted storms).
+    tol_all: the bound on every sample (TOL_ALL; the large-ensemble study passes its own, see
+    tests/test_gpu_parity.py::test_parity_study_at_scale)."""
     n = len(want['n_valid'])
     ns = len(t_s)
     k = first_divergence(dec_got, dec_want)
@@ -85,7 +89,7 @@ def check_tracks(tag, got, want, dec_got, dec_want, t0_want, t_s, counters=('sta
         if verbose:
             print('%s %-5s identical decisions: max %.3g  p99 %.3g  p95 %.3g   (n=%d)'
                   % (tag, name, worst[name], np.percentile(d, 99) if d.size else 0, np.percentile(d, 95) if d.size else 0, d.size))
-        assert worst[name] <= TOL_ALL, (tag, name, worst[name])
+        assert worst[name] <= tol_all, (tag, name, worst[name])
         if d.size >= 100:
             assert np.percentile(d, 99) <= TOL_99, (tag, name)
         if d.size >= 20:
@@ -117,7 +121,7 @@ def check_tracks(tag, got, want, dec_got, dec_want, t0_want, t_s, counters=('sta
             d = np.abs(np.nan_to_num(a) - np.nan_to_num(b)).max()
             pref_worst = max(pref_worst, float(d))
             pref_max.append(float(d))
-            assert d <= TOL_ALL, (tag, name, 'prefix of storm %d (first differing decision at evaluation %d, '
+            assert d <= tol_all, (tag, name, 'prefix of storm %d (first differing decision at evaluation %d, '
                                   't = %.0f s, %d samples)' % (i, k[i], t0, n_pref), d)
         pref_samples += n_pref
     if pref_max:
