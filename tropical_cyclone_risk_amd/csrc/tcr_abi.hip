@@ -97,6 +97,8 @@ struct tcr_ctx {
     size_t pf_cap = 0;
     int fs_period = 0;                          // 0: direct Fourier kernel
     int cu_count = 256;
+    int64_t *d_seg_sids = nullptr;    // storm ids of the park list the table's second segment is written for
+    size_t seg_sids_cap = 0;
     float *d_stat32 = nullptr;                  // fp32 copy of the land / bathymetry planes
     bool stat32_stale = true;
     int32_t *d_tc_idx = nullptr;                // storms that passed accept test 1 (k_screen -> compaction), tc_rows_only
@@ -285,6 +287,18 @@ int park_threshold(const tcr_ctx *ctx, unsigned waves, int wps)
     return waves >= (unsigned)ctx->cu_count * 4u ? 16 : 0;
 }
 
+// TCR_TABLE_SEGMENTS=0: the whole forcing table for every storm before the chain
+bool table_segments_enabled()
+{
+    if (const char *e = getenv("TCR_TABLE_SEGMENTS")) return atol(e) != 0;
+    return true;
+}
+// np.linspace(0, total_time, n_steps)[i] as the kernels form it (ts_at)
+double ts_host(const tcr_params &P, int i)
+{
+    return (i == P.n_steps - 1) ? P.total_time : (double)i * (P.total_time / (double)(P.n_steps - 1));
+}
+
 constexpr size_t kQueueWords = 6 * kMaxPasses;     // heads, parked counts, 4 occupancy counters per pass
 unsigned park_final_waves()               // a pass this small runs to the end
 {
@@ -312,15 +326,18 @@ struct DevBuf {
     }
 };
 
+// per timed call: [0] start, [1] table (first segment) written, [2] integration chain done, [3] post-processing done,
+// [4], [5] around the table's second segment inside the chain (recorded back to back when there is none)
+constexpr size_t kEvPerCall = 6;
 int timing_events(tcr_ctx *ctx, hipEvent_t **quad)
 {
-    if (ctx->ev_used + 4 > ctx->ev_pool.size()) {
+    if (ctx->ev_used + kEvPerCall > ctx->ev_pool.size()) {
         const size_t old = ctx->ev_pool.size();
         ctx->ev_pool.resize(old + 64, nullptr);
         for (size_t i = old; i < ctx->ev_pool.size(); ++i) HIPCHK(ctx, hipEventCreate(&ctx->ev_pool[i]));
     }
     *quad = &ctx->ev_pool[ctx->ev_used];
-    ctx->ev_used += 4;
+    ctx->ev_used += kEvPerCall;
     return 0;
 }
 
@@ -464,8 +481,20 @@ TracksT<R> tracks_of(const T *o)
     return t;
 }
 
+// The forcing table can be written in two segments of 12 column tiles (192 samples) each: the first for every storm before
+// the chain starts, the second only for the storms the first integration pass parks.
+constexpr int kFsSegSamples = kFsMfmaWaves * kFsMfmaColTiles * 16;
+enum FsPart { kFsAll = -1, kFsFirst = 0, kFsRest = 1 };
+bool fourier_on_matrix_cores(const tcr_ctx *ctx)
+{
+    const tcr_params &P = ctx->prm;
+    return TCR_FS_MFMA && ctx->fs_period > 0 && 2 * P.n_series <= 4 * kFsMfmaKSteps && P.n_steps <= kFsMfmaMaxSamples;
+}
+
+// part = kFsRest: rows are the storms of the park list `park` (count on the device, at most n)
 template <typename R>
-int launch_fourier(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const double *phases, R *fs, hipStream_t st)
+int launch_fourier(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const double *phases, R *fs, hipStream_t st,
+                   FsPart part = kFsAll, const double *park = nullptr, const unsigned long long *park_count = nullptr)
 {
     const tcr_params &P = ctx->prm;
     if (ctx->fs_period > 0) {
@@ -476,15 +505,29 @@ int launch_fourier(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const double *
             if (grow(ctx, &p, &ctx->pf_cap, (size_t)nf * 2)) { ctx->d_pf = nullptr; return -1; }
             ctx->d_pf = reinterpret_cast<double2 *>(p);
         }
-        if (TCR_FS_MFMA && 2 * P.n_series <= 4 * kFsMfmaKSteps && P.n_steps <= kFsMfmaMaxSamples) {
+        if (fourier_on_matrix_cores(ctx)) {
             // matrix-core form: phase factors in MFMA fragment order (4 KB per 4 storms <= the 3.84 KB of d_pf's layout + padding)
             const int64_t tiles = (n + 3) / 4;
             double *p = reinterpret_cast<double *>(ctx->d_pf);
             if (grow(ctx, &p, &ctx->pf_cap, (size_t)tiles * kFsMfmaKSteps * 64)) { ctx->d_pf = nullptr; return -1; }
             ctx->d_pf = reinterpret_cast<double2 *>(p);
-            hipLaunchKernelGGL(k_phase_factors_frag, dim3((unsigned)tiles), dim3(256), 0, st, P, n, n_dev, phases, p);
-            const unsigned wgs = (unsigned)std::min<int64_t>(tiles, std::max<int64_t>(1, (int64_t)ctx->cu_count * kFsMfmaWgsPerCu / kFsMfmaColGroups));
-            hipLaunchKernelGGL(k_fourier_mfma<R>, dim3(wgs, kFsMfmaColGroups), dim3(64 * kFsMfmaWaves), 0, st, P, n, n_dev, ctx->fs_period, ctx->d_sc_table, p, fs);
+            const int64_t *list = nullptr;
+            if (part == kFsRest) {
+                double *q = reinterpret_cast<double *>(ctx->d_seg_sids);
+                if (grow(ctx, &q, &ctx->seg_sids_cap, (size_t)n)) { ctx->d_seg_sids = nullptr; return -1; }
+                ctx->d_seg_sids = reinterpret_cast<int64_t *>(q);
+                hipLaunchKernelGGL(k_park_sids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, park, park_count, n, ctx->d_seg_sids);
+                list = ctx->d_seg_sids;
+            }
+            hipLaunchKernelGGL(k_phase_factors_frag, dim3((unsigned)tiles), dim3(256), 0, st, P, n, n_dev, phases, p, list, park_count);
+            const int groups = part == kFsAll ? kFsMfmaColGroups : 1;
+            const unsigned wgs = (unsigned)std::min<int64_t>(tiles, std::max<int64_t>(1, (int64_t)ctx->cu_count * kFsMfmaWgsPerCu * (4 / kFsMfmaWaves) / groups));
+            if (part == kFsRest)
+                hipLaunchKernelGGL((k_fourier_mfma<R, true>), dim3(wgs, groups), dim3(64 * kFsMfmaWaves), 0, st, P, n, n_dev, ctx->fs_period,
+                                   ctx->d_sc_table, p, fs, 1, list, park_count);
+            else
+                hipLaunchKernelGGL((k_fourier_mfma<R, false>), dim3(wgs, groups), dim3(64 * kFsMfmaWaves), 0, st, P, n, n_dev, ctx->fs_period,
+                                   ctx->d_sc_table, p, fs, 0, list, park_count);
         } else {
             hipLaunchKernelGGL(k_phase_factors, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, P, n, n_dev, phases, ctx->d_pf);
             hipLaunchKernelGGL(k_fourier_periodic<R>, dim3((unsigned)n), dim3(kFsThreads), lds, st, P, n, n_dev,
@@ -528,7 +571,16 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
     hipEvent_t *ev = nullptr;
     if (ctx->timing && timing_events(ctx, &ev)) return -1;
     if (ev) HIPCHK(ctx, hipEventRecord(ev[0], st));
-    if (launch_fourier<R>(ctx, n, in->n_dev, in->phases, fs, st)) return -1;
+    // Chain of launches with tail compaction (k_integrate): a pass parks the storms of waves that
+    // fall under `thr` live lanes, the next pass needs at most waves*(thr-1)/64 waves for them.
+    const int wps = std::is_same<R, double>::value ? TCR_INT_WPS : TCR_INT_WPS_F32;
+    unsigned waves = integrate_waves(ctx, n, wps);
+    const int thr = park_threshold(ctx, waves, wps);
+    // With a chain, the forcing table is written in two segments: samples [0, 192) for every storm now, the rest after the
+    // first pass and only for the storms that pass parks — the pass parks a storm (its lane takes the next one) as soon as
+    // its next attempt could read beyond the first segment.  58 % of the storms never get there.
+    const bool segmented = kFsMfmaColGroups == 2 && thr > 0 && fourier_on_matrix_cores(ctx) && (int)P.n_steps > kFsSegSamples + 16 && table_segments_enabled();
+    if (launch_fourier<R>(ctx, n, in->n_dev, in->phases, fs, st, segmented ? kFsFirst : kFsAll)) return -1;
     if (ev) HIPCHK(ctx, hipEventRecord(ev[1], st));
     {
         KArgsT<R> a{};
@@ -539,26 +591,36 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
         a.n_accept = out.n_accept; a.n_reject = out.n_reject;
         a.queue = ctx->d_queue;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, kQueueWords * sizeof(unsigned long long), st));
-        // Chain of launches with tail compaction (k_integrate): a pass parks the storms of waves that
-        // fall under `thr` live lanes, the next pass needs at most waves*(thr-1)/64 waves for them.
-        const int wps = std::is_same<R, double>::value ? TCR_INT_WPS : TCR_INT_WPS_F32;
-        unsigned waves = integrate_waves(ctx, n, wps);
-        const int thr = park_threshold(ctx, waves, wps);
         const unsigned final_waves = park_final_waves();
-        if (thr > 0 && grow(ctx, &ctx->d_park[0], &ctx->park_cap[0], (size_t)waves * kWave * kParkRec)) return -1;
-        if (thr > 0 && grow(ctx, &ctx->d_park[1], &ctx->park_cap[1], (size_t)waves * kWave * kParkRec)) return -1;
+        // (a segmented first pass can park any number of its storms)
+        const size_t park_items = segmented ? (size_t)n : (size_t)waves * kWave;
+        if (thr > 0 && grow(ctx, &ctx->d_park[0], &ctx->park_cap[0], park_items * kParkRec)) return -1;
+        if (thr > 0 && grow(ctx, &ctx->d_park[1], &ctx->park_cap[1], park_items * kParkRec)) return -1;
+        const bool probe = std::is_same<R, double>::value && ctx->d_probe;
+        if (probe) { a.probe = ctx->d_probe; a.probe_cap = ctx->probe_cap; }
+        bool seg_events = false;
         for (int pass = 0; pass < kMaxPasses; ++pass) {
             const bool last = thr <= 0 || waves <= final_waves || pass == kMaxPasses - 1;
             a.pass = pass;
             a.threshold = last ? 0 : thr;
             a.park_in = ctx->d_park[(pass + 1) & 1];
             a.park_out = ctx->d_park[pass & 1];
-            const bool probe = std::is_same<R, double>::value && ctx->d_probe;
-            if (probe) { a.probe = ctx->d_probe; a.probe_cap = ctx->probe_cap; }
+            // the stage times of an attempt lie in [t, t_new] and the table lookup at t reads samples up to ceil(t / dt) + 1
+            a.t_limit = (segmented && pass == 0) ? ts_host(P, kFsSegSamples - 2) : 1e300;
             launch_integrate(a, affine, probe, ctx->split_static, waves, st);
             if (last) break;
+            if (segmented && pass == 0) {
+                // the rest of the table, for the storms that are still alive (park list of pass 0, count on the device);
+                // pass 1 may have as many storms as pass 0 had, so it keeps pass 0's waves
+                if (ev) HIPCHK(ctx, hipEventRecord(ev[4], st));
+                if (launch_fourier<R>(ctx, n, in->n_dev, in->phases, fs, st, kFsRest, ctx->d_park[0], ctx->d_queue + kMaxPasses)) return -1;
+                if (ev) HIPCHK(ctx, hipEventRecord(ev[5], st));
+                seg_events = true;
+                continue;
+            }
             waves = (unsigned)(((size_t)waves * (size_t)(thr - 1) + kWave - 1) / kWave);
         }
+        if (ev && !seg_events) { HIPCHK(ctx, hipEventRecord(ev[4], st)); HIPCHK(ctx, hipEventRecord(ev[5], st)); }
     }
     if (ev) HIPCHK(ctx, hipEventRecord(ev[2], st));
     {
@@ -665,7 +727,7 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_mask_bits);
     (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_srec); (void)hipFree(ctx->d_vrec);
     for (auto &ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
-    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_tab);
+    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_seg_sids); (void)hipFree(ctx->d_tab);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -815,35 +877,39 @@ int tcr_timing_enable(tcr_ctx *ctx, int on)
     return 0;
 }
 
+// ms[0] forcing table (both segments), ms[1] integration chain without the table's second segment, ms[2] post-processing
+static int timing_of_call(tcr_ctx *ctx, hipEvent_t *q, double ms[3])
+{
+    float f[3] = {0.f, 0.f, 0.f}, seg = 0.f;
+    for (int i = 0; i < 3; ++i) HIPCHK(ctx, hipEventElapsedTime(&f[i], q[i], q[i + 1]));
+    HIPCHK(ctx, hipEventElapsedTime(&seg, q[4], q[5]));
+    ms[0] = f[0] + seg; ms[1] = f[1] - seg; ms[2] = f[2];
+    return 0;
+}
+
 int tcr_timing_sum(tcr_ctx *ctx, double ms[3], int64_t *n_calls)
 {
     if (!ctx || !ms) return -1;
     ms[0] = ms[1] = ms[2] = 0.0;
-    const size_t calls = ctx->ev_used / 4;
+    const size_t calls = ctx->ev_used / kEvPerCall;
     if (n_calls) *n_calls = (int64_t)calls;
     if (!calls) return fail(ctx, "no timed launch recorded (tcr_timing_enable + tcr_integrate_*)");
     HIPCHK(ctx, hipEventSynchronize(ctx->ev_pool[ctx->ev_used - 1]));
-    for (size_t c = 0; c < calls; ++c)
-        for (int i = 0; i < 3; ++i) {
-            float f = 0.f;
-            HIPCHK(ctx, hipEventElapsedTime(&f, ctx->ev_pool[c * 4 + i], ctx->ev_pool[c * 4 + i + 1]));
-            ms[i] += f;
-        }
+    for (size_t c = 0; c < calls; ++c) {
+        double one[3];
+        if (timing_of_call(ctx, &ctx->ev_pool[c * kEvPerCall], one)) return -1;
+        for (int i = 0; i < 3; ++i) ms[i] += one[i];
+    }
     return 0;
 }
 
 int tcr_timing_last(tcr_ctx *ctx, double ms[3])
 {
     if (!ctx || !ms) return -1;
-    if (ctx->ev_used < 4) return fail(ctx, "no timed launch recorded (tcr_timing_enable + tcr_integrate_*)");
-    hipEvent_t *q = &ctx->ev_pool[ctx->ev_used - 4];
-    HIPCHK(ctx, hipEventSynchronize(q[3]));
-    for (int i = 0; i < 3; ++i) {
-        float f = 0.f;
-        HIPCHK(ctx, hipEventElapsedTime(&f, q[i], q[i + 1]));
-        ms[i] = f;
-    }
-    return 0;
+    if (ctx->ev_used < kEvPerCall) return fail(ctx, "no timed launch recorded (tcr_timing_enable + tcr_integrate_*)");
+    hipEvent_t *q = &ctx->ev_pool[ctx->ev_used - kEvPerCall];
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev_pool[ctx->ev_used - 1]));
+    return timing_of_call(ctx, q, ms);
 }
 
 int tcr_integrate_pass_stats(tcr_ctx *ctx, int64_t *out, int max_passes)
@@ -1084,7 +1150,7 @@ int wind_stats_dev_impl(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, const
     if (ctx->timing && timing_events(ctx, &ev)) return -1;
     if (ev) { HIPCHK(ctx, hipEventRecord(ev[0], st)); HIPCHK(ctx, hipEventRecord(ev[1], st)); }
     hipLaunchKernelGGL(k_wind_stats<T>, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, st, a);
-    if (ev) { HIPCHK(ctx, hipEventRecord(ev[2], st)); HIPCHK(ctx, hipEventRecord(ev[3], st)); }
+    if (ev) { HIPCHK(ctx, hipEventRecord(ev[2], st)); HIPCHK(ctx, hipEventRecord(ev[3], st)); HIPCHK(ctx, hipEventRecord(ev[4], st)); HIPCHK(ctx, hipEventRecord(ev[5], st)); }
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }

@@ -50,6 +50,8 @@ struct KArgsT {
     int threshold;               // park the wave's storms and exit once fewer lanes than this are live (0: run to the end)
     const double *park_in;       // [.. ][kParkRec] list written by the previous pass
     double *park_out;            // list this pass writes
+    double t_limit;              // a storm whose next attempt ends beyond this time is parked for the next pass (the forcing table
+                                 // behind it is written only for the storms that get there); huge: no limit
     // decision probe (PROBE instantiation only, tcr_integrate_probe_host): probe[storm][probe_cap], one byte
     // per evaluation of fun in call order (Rhs::dec), so tests can find the first `land == 1` decision
     // that lands differently from the oracle's (oracle/parity.py)
@@ -224,7 +226,10 @@ __global__ __launch_bounds__(kFsThreads) void k_fourier_periodic(tcr_params P, i
 #define TCR_FS_MFMA_WPS 2
 #endif
 constexpr int kFsMfmaColTiles = TCR_FS_MFMA_TILES;          // column tiles per wave (6 / 3 / 2: one / two / four workgroups along y share the samples)
-constexpr int kFsMfmaWaves = 4;                                       // waves per workgroup: one per SIMD
+#ifndef TCR_FS_MFMA_WAVES
+#define TCR_FS_MFMA_WAVES 2
+#endif
+constexpr int kFsMfmaWaves = TCR_FS_MFMA_WAVES;                       // waves per workgroup (2: two column groups of 12 tiles = the table's two segments; 4: one group)
 constexpr int kFsMfmaColGroups = 24 / (kFsMfmaWaves * kFsMfmaColTiles);   // workgroups along y that together cover the 24 column tiles
 constexpr int kFsMfmaWgsPerCu = TCR_FS_MFMA_WPS;
 static_assert(kFsMfmaColGroups * kFsMfmaWaves * kFsMfmaColTiles == 24, "column tiles per wave must be 6, 3, 2 or 1");
@@ -233,20 +238,24 @@ constexpr int kFsMfmaMaxSamples = 24 * 16;
 
 // A fragments: [row tile of 4 storms][k step][lane]; lane l supplies A[i = l & 15][k = (l >> 4) + 4 * kstep],
 // i = series * 4 + storm_in_tile, k = 2 * harmonic + (0: weight * cos 2 pi x, 1: weight * sin 2 pi x); zero padding.
+// list != NULL: row r of the product is storm list[r], r < *list_count (the second segment of the table, written only for
+// the storms the first integration pass parked); otherwise row r is storm r.
 __global__ __launch_bounds__(256) void k_phase_factors_frag(tcr_params P, int64_t n, const int64_t *__restrict__ n_dev,
-                                                            const double *__restrict__ phases, double *__restrict__ frag)
+                                                            const double *__restrict__ phases, double *__restrict__ frag,
+                                                            const int64_t *__restrict__ list, const unsigned long long *__restrict__ list_count)
 {
     const int N = P.n_series;
-    const int64_t ne = n_eff(n, n_dev);
+    const int64_t ne = list ? (int64_t)*list_count : n_eff(n, n_dev);
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // (tile, kstep, lane) pairs: one thread writes k and k + 1
     const int64_t tiles = (ne + 3) / 4;
     if (gid >= tiles * 16 * 16) return;
     const int64_t tile = gid / 256;
     const int r = (int)(gid - tile * 256), h = r >> 4, i = r & 15;             // harmonic 0..15, row 0..15
     const int s = i >> 2;
-    const int64_t storm = tile * 4 + (i & 3);
+    const int64_t row = tile * 4 + (i & 3);
     double cb = 0.0, sb = 0.0;
-    if (h < N && storm < ne) {
+    if (h < N && row < ne) {
+        const int64_t storm = list ? list[row] : row;
         const double x = phases[storm * 4 * N + s * N + h];                     // phases are [storm][series][harmonic]
         const double wgt = P.fs_wgt[h];
         sb = wgt * sinpi(2.0 * x); cb = wgt * cospi(2.0 * x);
@@ -257,22 +266,32 @@ __global__ __launch_bounds__(256) void k_phase_factors_frag(tcr_params P, int64_
     o[((k & 3) + 1) * 16] = sb;
 }
 
-template <typename R>
+// storm ids of a park list (k_integrate's records), for the list mode of the table kernels
+__global__ __launch_bounds__(256) void k_park_sids(const double *__restrict__ park, const unsigned long long *__restrict__ count,
+                                                   int64_t cap, int64_t *__restrict__ sids)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)*count < cap ? (int64_t)*count : cap;
+    if (i < n) sids[i] = __double_as_longlong(park[i * kParkRec + 13]);
+}
+
+template <typename R, bool LIST>
 __global__ __launch_bounds__(64 * kFsMfmaWaves, TCR_FS_MFMA_WPS) void k_fourier_mfma(tcr_params P, int64_t n, const int64_t *__restrict__ n_dev,
                                                          int period, const double2 *__restrict__ sc_table,
-                                                         const double *__restrict__ frag, R *__restrict__ fs)
+                                                         const double *__restrict__ frag, R *__restrict__ fs, int group0,
+                                                         const int64_t *__restrict__ list, const unsigned long long *__restrict__ list_count)
 {
     typedef double D4 __attribute__((ext_vector_type(4)));
     __shared__ double stage[kFsMfmaWaves][4 * 16 * 4];     // per wave: one output tile, [storm][sample][series]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int N = P.n_series, ns = P.n_steps;
-    const int64_t ne = n_eff(n, n_dev);
+    const int64_t ne = LIST ? (int64_t)*list_count : n_eff(n, n_dev);      // rows of the product (LIST: row r is storm list[r])
     const int64_t tiles = (ne + 3) / 4;
     // B fragments of this wave's column tiles: lane l supplies B[k = (l >> 4) + 4 * kstep][sample = tile * 16 + (l & 15)]
     double B[kFsMfmaColTiles][kFsMfmaKSteps];
 #pragma unroll
     for (int t = 0; t < kFsMfmaColTiles; ++t) {
-        const int col = ((blockIdx.y * kFsMfmaWaves + wave) * kFsMfmaColTiles + t) * 16 + (lane & 15);
+        const int col = (((blockIdx.y + group0) * kFsMfmaWaves + wave) * kFsMfmaColTiles + t) * 16 + (lane & 15);
 #pragma unroll
         for (int ks = 0; ks < kFsMfmaKSteps; ++ks) {
             const int k = (lane >> 4) + 4 * ks, h = k >> 1;
@@ -298,10 +317,11 @@ __global__ __launch_bounds__(64 * kFsMfmaWaves, TCR_FS_MFMA_WPS) void k_fourier_
         D4 v;
         double2 d0, d1;
         int64_t tile;
+        int64_t s0, s1;          // storms behind the rows this lane stores (fp64: rows 2 i + (lane >> 5) of the tile; fp32: row lane >> 4)
         int k0;
         bool live;
     } ep;
-    ep.live = false; ep.tile = 0; ep.k0 = 0; ep.v = D4{0, 0, 0, 0}; ep.d0 = ep.d1 = make_double2(0, 0);
+    ep.live = false; ep.tile = 0; ep.k0 = 0; ep.s0 = ep.s1 = 0; ep.v = D4{0, 0, 0, 0}; ep.d0 = ep.d1 = make_double2(0, 0);
     double *const stg = stage[wave];
     auto epilogue_piece = [&](int piece) {
         if (!ep.live) return;                                   // wave-uniform
@@ -321,13 +341,14 @@ __global__ __launch_bounds__(64 * kFsMfmaWaves, TCR_FS_MFMA_WPS) void k_fourier_
             case 4: __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); break;
             case 5: case 6: {
                 const int i = piece - 5;
-                const int64_t storm = ep.tile * 4 + 2 * i + (lane >> 5);
+                const int64_t row = ep.tile * 4 + 2 * i + (lane >> 5);
+                const int64_t storm = i ? ep.s1 : ep.s0;
                 const int k = ep.k0 + ((lane & 31) >> 1);
                 const double2 d = i ? ep.d1 : ep.d0;
 #if defined(TCR_FS_ABLATE) && (TCR_FS_ABLATE & 1)
-                if (storm < ne && k < ns && d.x == 1.2345e300)    // timing experiment: no stores
+                if (row < ne && k < ns && d.x == 1.2345e300)    // timing experiment: no stores
 #else
-                if (storm < ne && k < ns)
+                if (row < ne && k < ns)
 #endif
                     *reinterpret_cast<double2 *>(reinterpret_cast<double *>(fs) + (storm * (int64_t)ns + ep.k0) * 4 + (lane & 31) * 2) = d;
                 break;
@@ -335,12 +356,13 @@ __global__ __launch_bounds__(64 * kFsMfmaWaves, TCR_FS_MFMA_WPS) void k_fourier_
             default: break;
             }
         } else if (piece == 5) {
-            const int64_t storm = ep.tile * 4 + q;
+            const int64_t row = ep.tile * 4 + q;
+            const int64_t storm = ep.s0;
             const int k = ep.k0 + j;
 #if defined(TCR_FS_ABLATE) && (TCR_FS_ABLATE & 1)
-            if (storm < ne && k < ns && ep.v[0] == 1.2345e300)
+            if (row < ne && k < ns && ep.v[0] == 1.2345e300)
 #else
-            if (storm < ne && k < ns)
+            if (row < ne && k < ns)
 #endif
                 store_fs<R>(fs + (storm * (int64_t)ns + k) * 4, amp * ep.v[0], amp * ep.v[1], amp * ep.v[2], amp * ep.v[3]);
         }
@@ -352,6 +374,11 @@ __global__ __launch_bounds__(64 * kFsMfmaWaves, TCR_FS_MFMA_WPS) void k_fourier_
         for (int ks = 0; ks < kFsMfmaKSteps; ++ks) A[ks] = frag[tile * (kFsMfmaKSteps * 64) + ks * 64 + lane];
     }
     for (; tile < tiles; tile += gridDim.x) {
+        // the storms behind this row tile's rows (LIST: loaded here, with the fragment loads, long before the stores need
+        // them — a load next to the stores would put a vmcnt(0), i.e. the stores' whole write latency, in front of each)
+        const int64_t r0 = tile * 4 + (sizeof(R) == 8 ? (lane >> 5) : q), r1 = r0 + 2;
+        int64_t cs0 = r0, cs1 = r1;
+        if (LIST) { cs0 = list[r0 < ne ? r0 : ne - 1]; cs1 = list[r1 < ne ? r1 : ne - 1]; }
         // next row tile's fragment while this one multiplies
         double An[kFsMfmaKSteps];
         const int64_t nxt = tile + gridDim.x;
@@ -359,7 +386,7 @@ __global__ __launch_bounds__(64 * kFsMfmaWaves, TCR_FS_MFMA_WPS) void k_fourier_
         for (int ks = 0; ks < kFsMfmaKSteps; ++ks) An[ks] = (nxt < tiles) ? frag[nxt * (kFsMfmaKSteps * 64) + ks * 64 + lane] : 0.0;
 #pragma unroll
         for (int t = 0; t < kFsMfmaColTiles; ++t) {
-            const int k0 = ((blockIdx.y * kFsMfmaWaves + wave) * kFsMfmaColTiles + t) * 16;
+            const int k0 = (((blockIdx.y + group0) * kFsMfmaWaves + wave) * kFsMfmaColTiles + t) * 16;
             if (k0 >= ns) break;                                // wave-uniform: this wave's last column tiles lie beyond the track
             D4 acc = D4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -372,7 +399,7 @@ __global__ __launch_bounds__(64 * kFsMfmaWaves, TCR_FS_MFMA_WPS) void k_fourier_
                 epilogue_piece(ks);                              // of the previous tile
                 __builtin_amdgcn_sched_barrier(0);               // keep this interleaving
             }
-            ep.v = acc; ep.tile = tile; ep.k0 = k0; ep.live = true;
+            ep.v = acc; ep.tile = tile; ep.k0 = k0; ep.s0 = cs0; ep.s1 = cs1; ep.live = true;
         }
 #pragma unroll
         for (int ks = 0; ks < kFsMfmaKSteps; ++ks) A[ks] = An[ks];
@@ -548,6 +575,25 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
         attempt_setup();
     };
 
+    // park the storms of the lanes in `mask` (each between two attempts of _step_impl) for the next pass
+    auto park = [&](unsigned long long mask) {
+        const int leader = __ffsll((long long)mask) - 1;
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(a.queue + kMaxPasses + a.pass, (unsigned long long)__popcll(mask));
+        base = __shfl(base, leader);
+        if ((mask >> lane) & 1ull) {
+            const size_t item = (size_t)(base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull)));
+            double2 *o = reinterpret_cast<double2 *>(a.park_out + item * kParkRec);
+            const long long c0 = (long long)(unsigned)nfev | ((long long)nacc << 32);
+            const long long c1 = (long long)(unsigned)nrej | ((long long)(rejected ? 1 : 0) << 31) | ((long long)next_out << 32);
+            o[0] = make_double2(t, h); o[1] = make_double2(t_new, ha); o[2] = make_double2((double)g, (double)y[0]);
+            o[3] = make_double2((double)y[1], (double)y[2]); o[4] = make_double2((double)y[3], (double)f[0]);
+            o[5] = make_double2((double)f[1], (double)f[2]);
+            o[6] = make_double2((double)f[3], __longlong_as_double(sid));
+            o[7] = make_double2(__longlong_as_double(c0), __longlong_as_double(c1));
+            o[8] = make_double2((double)h_bl, __longlong_as_double((long long)cur_slot));
+        }
+    };
     // occupancy accounting lives in LDS (lane 0 only): the kernel has no register to spare
     __shared__ unsigned long long occ[4];
     if (lane == 0) { occ[0] = 0; occ[1] = 0; occ[2] = wall_clock64(); occ[3] = clock64(); }
@@ -562,7 +608,13 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
 #define TCR_PHASE_CLK(i) do { } while (0)
 #endif
     for (;;) {
-        // ---- cycle boundary: refill idle lanes from the storm queue (wave-aggregated atomic)
+        // ---- cycle boundary.  First launch of a chain with a segmented forcing table: a storm whose next attempt would read
+        // the table beyond the part written so far leaves for the next pass (its lane takes a new storm right away)
+        {
+            const unsigned long long late = __ballot(active && t_new > a.t_limit);
+            if (late) { park(late); if ((late >> lane) & 1ull) active = false; }
+        }
+        // ---- refill idle lanes from the storm queue (wave-aggregated atomic)
         const unsigned long long want = __ballot(!active && !exhausted);
         if (want) {
             const int leader = __ffsll((long long)want) - 1;
@@ -626,22 +678,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
         const unsigned long long live_mask = __ballot(active);
         if (a.threshold > 0 && live_mask && !__ballot(fresh) && __popcll(live_mask) < a.threshold) {
             // queue empty (every idle lane tried it) and the wave is mostly idle: park and exit
-            const int leader = __ffsll((long long)live_mask) - 1;
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(a.queue + kMaxPasses + a.pass, (unsigned long long)__popcll(live_mask));
-            base = __shfl(base, leader);
-            if (active) {
-                const size_t item = (size_t)(base + (unsigned long long)__popcll(live_mask & ((1ull << lane) - 1ull)));
-                double2 *o = reinterpret_cast<double2 *>(a.park_out + item * kParkRec);
-                const long long c0 = (long long)(unsigned)nfev | ((long long)nacc << 32);
-                const long long c1 = (long long)(unsigned)nrej | ((long long)(rejected ? 1 : 0) << 31) | ((long long)next_out << 32);
-                o[0] = make_double2(t, h); o[1] = make_double2(t_new, ha); o[2] = make_double2((double)g, (double)y[0]);
-                o[3] = make_double2((double)y[1], (double)y[2]); o[4] = make_double2((double)y[3], (double)f[0]);
-                o[5] = make_double2((double)f[1], (double)f[2]);
-                o[6] = make_double2((double)f[3], __longlong_as_double(sid));
-                o[7] = make_double2(__longlong_as_double(c0), __longlong_as_double(c1));
-                o[8] = make_double2((double)h_bl, __longlong_as_double((long long)cur_slot));
-            }
+            park(live_mask);
             break;
         }
         if (!live_mask) break;
