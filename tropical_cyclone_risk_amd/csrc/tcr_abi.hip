@@ -281,10 +281,10 @@ int park_threshold(const tcr_ctx *ctx, unsigned waves, int wps)
         return v <= 0 ? 0 : (v > 63 ? 63 : (int)v);
     }
     (void)wps;
-    // 16: measured on 100 000-storm steps (4 streams) — threshold 12 / 16 / 24 / 32 / 48 give 1.51 / 1.48 / 1.47 / 1.50 / 1.59 ms per
-    // step and chains of 2.16 / 2.13 / 2.23 / 2.31 / 2.49 ms (4 / 5 / 6 / 8 / 16 passes): a higher threshold buys lane
-    // utilisation (0.72 ... 0.95) with pass barriers, and below 24 the barriers cost more than the idle lanes
-    return waves >= (unsigned)ctx->cu_count * 4u ? 16 : 0;
+    // 12: measured on 100 000-storm steps (4 streams, segmented forcing table) — threshold 8 / 12 / 16 / 24 give 1.41 / 1.39 / 1.39 /
+    // 1.38 ms per step and chains of 2.20 / 2.14-2.20 / 2.20-2.24 / 2.31-2.34 ms (5 / 5 / 6 / 7 passes): a higher threshold buys lane
+    // utilisation (0.69 ... 0.83) with pass barriers; 12 has the shortest chain at (within noise) the best step time
+    return waves >= (unsigned)ctx->cu_count * 4u ? 12 : 0;
 }
 
 // TCR_TABLE_SEGMENTS=0: the whole forcing table for every storm before the chain
