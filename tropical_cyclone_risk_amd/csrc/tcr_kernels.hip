@@ -206,9 +206,10 @@ __global__ __launch_bounds__(kFsThreads) void k_fourier_periodic(tcr_params P, i
 //   fs[storm][sample][series] = amp * sum_h ( S[(h+1) k mod period] * cb[storm][h][series] + C[...] * sb[storm][h][series] )
 //
 // is Out[(series, storm), sample] = A[(series, storm), 2N] x B[2N, sample] with A the storms' phase factors and B the
-// one-period table laid out per (harmonic, sample) — the same B for every storm.  A workgroup of four waves owns all
-// samples (wave w: column tiles 6w .. 6w+5 of 16 samples; 24 tiles = 384 samples), keeps its B fragments in registers
-// for its whole life (96 VGPRs) and walks row tiles of 4 storms x 4 series: 8 coalesced loads of the A fragment
+// one-period table laid out per (harmonic, sample) — the same B for every storm.  A workgroup of two waves owns a column
+// group of 12 tiles = 192 samples (wave w: tiles 6w .. 6w+5 of the group; two groups = 384 samples; group0 selects the
+// first group of a launch, so a launch writes the whole table or one of its two segments), keeps its B fragments in
+// registers for its whole life (96 VGPRs) and walks row tiles of 4 storms x 4 series: 8 coalesced loads of the A fragment
 // (written in fragment order by k_phase_factors_frag), 8 x v_mfma_f64_16x16x4_f64 per column tile on six independent
 // accumulator chains, and — rows ordered series-major — a lane ends up with the four series of one (storm, sample) in
 // its four accumulator registers: one 32-byte store per lane, 512 contiguous bytes per storm and instruction.
