@@ -210,7 +210,8 @@ def test_other_output_grids(golden_env, built_lib, dt_out, days, T_days):
 def test_full_size_ensemble_properties(golden_env, built_lib):
     """BASELINE's full size (100 000 storms, GL, device-seeded) through size-independent properties:
       * launch-shape invariance: the same batch integrated with a different number of persistent
-        waves (different storm-to-lane assignment and queue order) is bitwise identical;
+        waves (different storm-to-lane assignment and queue order; no chain of passes, no table segments) and with the
+        forcing table written in one piece is bitwise identical;
       * batch-composition invariance: a storm integrated inside the 100k batch equals the same
         storm integrated in a small batch, bitwise;
       * structure: NaN padding exactly beyond n_valid, accepted => is_tc, sample 0 == the seed;
@@ -237,6 +238,18 @@ def test_full_size_ensemble_properties(golden_env, built_lib):
         assert np.array_equal(a[k], b[k], equal_nan=True), k
     for k in ('n_valid', 'status', 'flags', 'nfev', 'n_accept', 'n_reject'):
         assert np.array_equal(a[k], b[k]), k
+    # the forcing table in one piece (every storm, before the chain) instead of two segments (the second only for the
+    # storms the first pass parks): same chain of passes otherwise, bitwise the same result
+    os.environ['TCR_TABLE_SEGMENTS'] = '0'
+    try:
+        pipe.integrate(B)
+        c = pipe.host_tracks()
+    finally:
+        del os.environ['TCR_TABLE_SEGMENTS']
+    for k in ('lon', 'lat', 'v', 'm', 'vmax', 'envw'):
+        assert np.array_equal(a[k], c[k], equal_nan=True), k
+    for k in ('n_valid', 'status', 'flags', 'nfev', 'n_accept', 'n_reject'):
+        assert np.array_equal(a[k], c[k]), k
     # structure
     ns = eng.n_steps
     idx = np.arange(ns)[None, :]
