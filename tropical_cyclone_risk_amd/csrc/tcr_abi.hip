@@ -519,7 +519,7 @@ int launch_fourier(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const double *
                 hipLaunchKernelGGL(k_park_sids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, park, park_count, n, ctx->d_seg_sids);
                 list = ctx->d_seg_sids;
             }
-            hipLaunchKernelGGL(k_phase_factors_frag, dim3((unsigned)tiles), dim3(256), 0, st, P, n, n_dev, phases, p, list, park_count);
+            hipLaunchKernelGGL(k_phase_factors_frag, dim3((unsigned)std::min<int64_t>(tiles, 8192)), dim3(256), 0, st, P, n, n_dev, phases, p, list, park_count);
             const int groups = part == kFsAll ? kFsMfmaColGroups : 1;
             const unsigned wgs = (unsigned)std::min<int64_t>(tiles, std::max<int64_t>(1, (int64_t)ctx->cu_count * kFsMfmaWgsPerCu * (4 / kFsMfmaWaves) / groups));
             if (part == kFsRest)

@@ -247,24 +247,24 @@ __global__ __launch_bounds__(256) void k_phase_factors_frag(tcr_params P, int64_
 {
     const int N = P.n_series;
     const int64_t ne = list ? (int64_t)*list_count : n_eff(n, n_dev);
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // (tile, kstep, lane) pairs: one thread writes k and k + 1
     const int64_t tiles = (ne + 3) / 4;
-    if (gid >= tiles * 16 * 16) return;
-    const int64_t tile = gid / 256;
-    const int r = (int)(gid - tile * 256), h = r >> 4, i = r & 15;             // harmonic 0..15, row 0..15
+    const int r = threadIdx.x, h = r >> 4, i = r & 15;                          // harmonic 0..15, row 0..15 of the tile
     const int s = i >> 2;
-    const int64_t row = tile * 4 + (i & 3);
-    double cb = 0.0, sb = 0.0;
-    if (h < N && row < ne) {
-        const int64_t storm = list ? list[row] : row;
-        const double x = phases[storm * 4 * N + s * N + h];                     // phases are [storm][series][harmonic]
-        const double wgt = P.fs_wgt[h];
-        sb = wgt * sinpi(2.0 * x); cb = wgt * cospi(2.0 * x);
+    // a workgroup per row tile; the grid is bounded (the row count may live on the device only), so it walks
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t row = tile * 4 + (i & 3);
+        double cb = 0.0, sb = 0.0;
+        if (h < N && row < ne) {
+            const int64_t storm = list ? list[row] : row;
+            const double x = phases[storm * 4 * N + s * N + h];                 // phases are [storm][series][harmonic]
+            const double wgt = P.fs_wgt[h];
+            sb = wgt * sinpi(2.0 * x); cb = wgt * cospi(2.0 * x);
+        }
+        const int k = 2 * h;                                                    // k & 3 is 0 or 2: k and k + 1 share a k step
+        double *o = frag + tile * (kFsMfmaKSteps * 64) + (k >> 2) * 64 + i;
+        o[(k & 3) * 16] = cb;
+        o[((k & 3) + 1) * 16] = sb;
     }
-    const int k = 2 * h;                                                        // k & 3 is 0 or 2: k and k + 1 share a k step
-    double *o = frag + tile * (kFsMfmaKSteps * 64) + (k >> 2) * 64 + i;
-    o[(k & 3) * 16] = cb;
-    o[((k & 3) + 1) * 16] = sb;
 }
 
 // storm ids of a park list (k_integrate's records), for the list mode of the table kernels
