@@ -23,7 +23,7 @@
  *                     util/sphere.py:15-30,58-83
  *
  * Parity pin: tests/test_oracle_golden.py checks this file against
- * tests/golden/*.npz, which hold outputs of the reference's own code.
+ * the .npz fixtures under tests/golden, which hold outputs of the reference's own code.
  * Build: oracle/Makefile (gcc -O2 -ffp-contract=off; no -ffast-math).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
