@@ -97,6 +97,8 @@ struct tcr_ctx {
     size_t pf_cap = 0;
     int fs_period = 0;                          // 0: direct Fourier kernel
     int cu_count = 256;
+    uint8_t *d_screen_skip = nullptr; // storms the integrator found to fail the 2-day test (TC rows only)
+    size_t screen_skip_cap = 0;
     int64_t *d_seg_sids = nullptr;    // storm ids of the park list the table's second segment is written for
     size_t seg_sids_cap = 0;
     float *d_stat32 = nullptr;                  // fp32 copy of the land / bathymetry planes
@@ -287,6 +289,12 @@ int park_threshold(const tcr_ctx *ctx, unsigned waves, int wps)
     return waves >= (unsigned)ctx->cu_count * 4u ? 12 : 0;
 }
 
+// TCR_PRUNE=0: no in-flight 2-day test (every storm writes all its step records, k_screen looks at every storm)
+bool prune_enabled()
+{
+    if (const char *e = getenv("TCR_PRUNE")) return atol(e) != 0;
+    return true;
+}
 // TCR_TABLE_SEGMENTS=0: the whole forcing table for every storm before the chain
 bool table_segments_enabled()
 {
@@ -580,6 +588,18 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
     // first pass and only for the storms that pass parks — the pass parks a storm (its lane takes the next one) as soon as
     // its next attempt could read beyond the first segment.  58 % of the storms never get there.
     const bool segmented = kFsMfmaColGroups == 2 && thr > 0 && fourier_on_matrix_cores(ctx) && (int)P.n_steps > kFsSegSamples + 16 && table_segments_enabled();
+    // TC rows only: the 2-day half of accept test 1 is decided in flight when 2 d is an output sample (KArgsT::prune_sample)
+    int prune_sample = -1;
+    if (out.tc_rows_only && prune_enabled()) {
+        const double t2d = 2 * 86400.0, step_out = P.total_time / (double)(P.n_steps - 1);
+        const int j = (int)floor(t2d / step_out);
+        if (j >= 1 && j < P.n_steps - 1 && ts_host(P, j) == t2d) {
+            prune_sample = j;
+            double *q = reinterpret_cast<double *>(ctx->d_screen_skip);
+            if (grow(ctx, &q, &ctx->screen_skip_cap, ((size_t)n + 7) / 8)) { ctx->d_screen_skip = nullptr; return -1; }
+            ctx->d_screen_skip = reinterpret_cast<uint8_t *>(q);
+        }
+    }
     if (launch_fourier<R>(ctx, n, in->n_dev, in->phases, fs, st, segmented ? kFsFirst : kFsAll)) return -1;
     if (ev) HIPCHK(ctx, hipEventRecord(ev[1], st));
     {
@@ -590,6 +610,8 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
         a.n_valid = out.n_valid; a.status = out.status; a.nfev = out.nfev;
         a.n_accept = out.n_accept; a.n_reject = out.n_reject;
         a.queue = ctx->d_queue;
+        a.prune_sample = prune_sample;
+        a.screen_skip = prune_sample >= 0 ? ctx->d_screen_skip : nullptr;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, kQueueWords * sizeof(unsigned long long), st));
         const unsigned final_waves = park_final_waves();
         // (a segmented first pass can park any number of its storms)
@@ -630,6 +652,7 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
         a.lon = out.lon; a.lat = out.lat; a.v = out.v; a.m = out.m; a.vmax = out.vmax;
         a.envw = out.envw; a.flags = out.flags; a.pad_state = out.pad_state;
         a.K = EK;
+        a.screen_skip = prune_sample >= 0 ? ctx->d_screen_skip : nullptr;
         const unsigned chunks = (unsigned)((ns + kPostThreads - 1) / kPostThreads);
         if (out.tc_rows_only) {
             // Only what the reference does (compute.py:185-204): accept test 1 from the v series alone, then env
@@ -727,7 +750,7 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_mask_bits);
     (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_srec); (void)hipFree(ctx->d_vrec);
     for (auto &ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
-    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_seg_sids); (void)hipFree(ctx->d_tab);
+    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_seg_sids); (void)hipFree(ctx->d_screen_skip); (void)hipFree(ctx->d_tab);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;

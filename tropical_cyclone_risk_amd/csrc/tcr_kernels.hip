@@ -60,6 +60,12 @@ struct KArgsT {
     // what accept test 1 needs of an accepted step, packed: t_old, h, t_new, v_old, K[0..6][v], - (12 doubles, 96 B);
     // k_screen reads these instead of pulling the whole 288-byte records of every storm through the cache
     double *vrec;                // [n][max_rk_steps][kVRec]
+    // TC-rows-only mode: accept test 1 is `any(v >= 15) and v(2 d) >= 6.5`, and when 2 d is an output sample (sample
+    // prune_sample, -1: off) v(2 d) is that sample's v.  The step that emits it evaluates it — with dense_at's arithmetic — and a
+    // storm that fails is marked in screen_skip[storm]: it cannot become a TC, so k_screen skips it and the integrator stops
+    // writing its step records (nothing downstream reads them).
+    int prune_sample;
+    uint8_t *screen_skip;        // [n]: written for every storm when it ends (1: failed the 2-day test in flight)
 };
 using KArgs = KArgsT<double>;
 constexpr int kVRec = 12;
@@ -532,6 +538,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
     double *srec = nullptr;
     R h_bl = R(0.0);
     int cur_slot = 0;                       // the storm's field slot (travels in the park record)
+    bool doomed = false;                    // failed the 2-day test already (prune_sample): no more records
     R y[4] = {0, 0, 0, 0}, f[4] = {0, 0, 0, 0}, yn[4] = {0, 0, 0, 0};
     R e[4] = {0, 0, 0, 0};                  // evaluation point: lon, lat, v, m
     double et = 0;                          // ... and its time
@@ -549,6 +556,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
         a.nfev[sid] = (status == TCR_STATUS_GATED) ? 0 : nfev;
         a.n_accept[sid] = nacc;
         a.n_reject[sid] = nrej;
+        if (a.screen_skip) a.screen_skip[sid] = doomed ? 1 : 0;
         active = false;
     };
     // one attempt of _step_impl's while-loop: clip to t_bound, stage-2 input (rk.py:137-146, 62-66)
@@ -586,7 +594,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
             const size_t item = (size_t)(base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull)));
             double2 *o = reinterpret_cast<double2 *>(a.park_out + item * kParkRec);
             const long long c0 = (long long)(unsigned)nfev | ((long long)nacc << 32);
-            const long long c1 = (long long)(unsigned)nrej | ((long long)(rejected ? 1 : 0) << 31) | ((long long)next_out << 32);
+            const long long c1 = (long long)(unsigned)nrej | ((long long)(doomed ? 1 : 0) << 30) | ((long long)(rejected ? 1 : 0) << 31) | ((long long)next_out << 32);
             o[0] = make_double2(t, h); o[1] = make_double2(t_new, ha); o[2] = make_double2((double)g, (double)y[0]);
             o[3] = make_double2((double)y[1], (double)y[2]); o[4] = make_double2((double)y[3], (double)f[0]);
             o[5] = make_double2((double)f[1], (double)f[2]);
@@ -637,7 +645,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
                         const double lo0 = a.lon0[sid], la0 = a.lat0[sid], vv0 = a.v0[sid], mm0 = a.m0[sid], hb0 = a.h_bl[sid];
                         slot_id = a.slot[sid];
                         y[0] = (R)lo0; y[1] = (R)la0; y[2] = (R)vv0; y[3] = (R)mm0; h_bl = (R)hb0;
-                        status = kRunning; nfev = 0; nacc = 0; nrej = 0; next_out = 0;
+                        status = kRunning; nfev = 0; nacc = 0; nrej = 0; next_out = 0; doomed = false;
                         t = 0.0;
                         et = 0.0; e[0] = y[0]; e[1] = y[1]; e[2] = y[2]; e[3] = y[3];
                         fresh = true;
@@ -651,7 +659,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
                         sid = __double_as_longlong(r6.y);
                         const long long c0 = __double_as_longlong(r7.x), c1 = __double_as_longlong(r7.y);
                         nfev = (int)(c0 & 0xffffffffll); nacc = (int)(c0 >> 32);
-                        nrej = (int)(c1 & 0x7fffffffll); rejected = (c1 >> 31) & 1; next_out = (int)(c1 >> 32);
+                        nrej = (int)(c1 & 0x3fffffffll); doomed = (c1 >> 30) & 1; rejected = (c1 >> 31) & 1; next_out = (int)(c1 >> 32);
                         h_bl = (R)r8.x; slot_id = (int)__double_as_longlong(r8.y);
                         status = kRunning;
                         // stage-2 input exactly as attempt_setup left it
@@ -770,7 +778,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
 #ifdef TCR_ABLATE_STEP_STORES
                         if (nacc < 0) {         // timing experiment only: no step records (post-processing reads garbage)
 #else
-                        if (nacc < a.max_rk_steps) {
+                        if (nacc < a.max_rk_steps && !doomed) {
 #endif
                             double *rec = srec + (size_t)nacc * REC;
                             double2 *o = reinterpret_cast<double2 *>(rec);
@@ -794,6 +802,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
                         ++nacc;
                         const double t_old = t;
                         t = t_new;
+                        const R v_old = y[2];
                         for (int i = 0; i < 4; ++i) { y[i] = yn[i]; f[i] = r.d[i]; }
                         h_abs = ha;
                         if (t - tb >= 0) status = TCR_STATUS_FINISHED;
@@ -804,7 +813,24 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
                         if (g == R(0.0)) { status = TCR_STATUS_EVENT; t_emit = t_old; }
                         else if (g_new == R(0.0)) status = TCR_STATUS_EVENT;
                         g = g_new;
+                        const int first_out = next_out;
                         next_out = samples_upto(P, t_emit);         // t_eval emission count (ivp.py:706-723)
+                        if (a.prune_sample >= 0 && !doomed && first_out <= a.prune_sample && a.prune_sample < next_out) {
+                            // this step emits the 2-day sample: its v exactly as dense_at / k_screen form it (row 2 of
+                            // Q = K^T P, x = (t_i - t_old) / h), and accept test 1's second half on it
+                            R Qv[4];
+                            for (int k = 0; k < 4; ++k) {
+                                R acc = R(0.0);
+                                for (int q = 0; q < 7; ++q) acc += KS(q, 2) * R(RK_P[q][k]);
+                                Qv[k] = acc;
+                            }
+                            const R x = (R)((ts_at(P, a.prune_sample) - t_old) / h);
+                            const R p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
+                            R acc = R(0.0);
+                            acc += Qv[0] * p1; acc += Qv[1] * p2; acc += Qv[2] * p3; acc += Qv[3] * p4;
+                            const R v2d = (R)h * acc + v_old;
+                            doomed = !((double)v2d >= P.v_2d_thresh);
+                        }
                         if (status == kRunning && nacc >= a.max_rk_steps) status = TCR_STATUS_STEP_OVERFLOW;
                         if (status != kRunning) finalize();
                         else begin_step();
@@ -903,6 +929,7 @@ struct EArgsT {
     const int32_t *list;
     const int64_t *count;
     int64_t item_base;           // k_emit's overflow launch: first list entry it handles
+    const uint8_t *screen_skip;  // k_screen: storms the integrator already found to fail the 2-day test (KArgsT::screen_skip; NULL: none)
     EvalKT<R> K;                 // built on the host; k_emit's small workgroups copy it to LDS
 };
 using EArgs = EArgsT<double>;
@@ -1175,6 +1202,7 @@ __global__ __launch_bounds__(kScreenThreads) void k_screen(EArgsT<R> a)
     if (exists) {
         n = a.n_valid[sid]; nst = a.n_accept[sid]; st = a.status[sid];
         nst = nst < a.max_rk_steps ? nst : a.max_rk_steps;
+        if (a.screen_skip && a.screen_skip[sid]) n = 0;        // not a TC whatever else happened; its records stop at day 2
     }
     // np.interp(2 d, res.t, v): which samples it reads (compute.py:186-188; same as k_flags)
     const double step_out = P.total_time / (double)(ns - 1);
