@@ -174,7 +174,12 @@ int tcr_masks_upload(tcr_ctx *ctx, const tcr_grid *mg, const uint8_t *run_mask,
  * accept test 1 (:185-189), env-wind recompute (:201-202), axi_to_max_wind
  * (:203-204), accept test 2 (:205) — for a whole batch.  Host buffers. */
 int tcr_integrate_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out);
-/* same with device buffers, asynchronous on `stream` */
+/* same with device buffers, asynchronous on `stream`.
+ * Results do not depend on how the library schedules a batch; the schedule can be steered through the environment for
+ * experiments and tests (read at every call): TCR_WAVES (persistent integrator waves), TCR_PARK (tail-compaction
+ * threshold, 0 = one launch), TCR_PARK_FINAL, TCR_TABLE_SEGMENTS=0 (forcing table in one piece instead of a second
+ * segment written only for the storms the first integration pass parks), TCR_PRUNE=0 (tc_rows_only: no in-flight
+ * 2-day test), TCR_EMIT_GRID_CAP (workgroup rows walking the list of storms that pass accept test 1). */
 int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in_dev, const tcr_tracks *out_dev, void *stream);
 
 /* The fp32 variant of the same path (BASELINE config 5; the reference itself is fp64 throughout, so this is a
