@@ -815,16 +815,23 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
                         g = g_new;
                         const int first_out = next_out;
                         next_out = samples_upto(P, t_emit);         // t_eval emission count (ivp.py:706-723)
-                        if (a.prune_sample >= 0 && !doomed && first_out <= a.prune_sample && a.prune_sample < next_out) {
-                            // this step emits the 2-day sample: its v exactly as dense_at / k_screen form it (row 2 of
-                            // Q = K^T P, x = (t_i - t_old) / h), and accept test 1's second half on it
+                        // the sample np.interp(2 d, res.t, v) reads: the 2-day sample itself, or — the track ends before
+                        // it — the last one emitted (np.interp clamps), if this final step is the one that emits it
+                        int s2d = -1;
+                        if (a.prune_sample >= 0 && !doomed) {
+                            if (first_out <= a.prune_sample && a.prune_sample < next_out) s2d = a.prune_sample;
+                            else if (status != kRunning && next_out <= a.prune_sample && first_out < next_out) s2d = next_out - 1;
+                        }
+                        if (s2d >= 0) {
+                            // its v exactly as dense_at / k_screen form it (row 2 of Q = K^T P, x = (t_i - t_old) / h), and
+                            // accept test 1's second half on it
                             R Qv[4];
                             for (int k = 0; k < 4; ++k) {
                                 R acc = R(0.0);
                                 for (int q = 0; q < 7; ++q) acc += KS(q, 2) * R(RK_P[q][k]);
                                 Qv[k] = acc;
                             }
-                            const R x = (R)((ts_at(P, a.prune_sample) - t_old) / h);
+                            const R x = (R)((ts_at(P, s2d) - t_old) / h);
                             const R p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
                             R acc = R(0.0);
                             acc += Qv[0] * p1; acc += Qv[1] * p2; acc += Qv[2] * p3; acc += Qv[3] * p4;
