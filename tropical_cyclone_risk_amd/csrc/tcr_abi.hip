@@ -99,6 +99,9 @@ struct tcr_ctx {
     int cu_count = 256;
     uint8_t *d_screen_skip = nullptr; // storms the integrator found to fail the 2-day test (TC rows only)
     size_t screen_skip_cap = 0;
+    int32_t *d_und_list = nullptr;    // ... and the storms accept test 1 is still open for (k_screen's work list)
+    size_t und_list_cap = 0;
+    unsigned long long *d_und_count = nullptr;
     int64_t *d_seg_sids = nullptr;    // storm ids of the park list the table's second segment is written for
     size_t seg_sids_cap = 0;
     float *d_stat32 = nullptr;                  // fp32 copy of the land / bathymetry planes
@@ -598,6 +601,10 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
             double *q = reinterpret_cast<double *>(ctx->d_screen_skip);
             if (grow(ctx, &q, &ctx->screen_skip_cap, ((size_t)n + 7) / 8)) { ctx->d_screen_skip = nullptr; return -1; }
             ctx->d_screen_skip = reinterpret_cast<uint8_t *>(q);
+            double *u = reinterpret_cast<double *>(ctx->d_und_list);
+            if (grow(ctx, &u, &ctx->und_list_cap, ((size_t)n + 1) / 2 + 1)) { ctx->d_und_list = nullptr; return -1; }
+            ctx->d_und_list = reinterpret_cast<int32_t *>(u);
+            if (!ctx->d_und_count && dev_alloc(ctx, &ctx->d_und_count, (size_t)1)) return -1;
         }
     }
     if (launch_fourier<R>(ctx, n, in->n_dev, in->phases, fs, st, segmented ? kFsFirst : kFsAll)) return -1;
@@ -612,6 +619,12 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
         a.queue = ctx->d_queue;
         a.prune_sample = prune_sample;
         a.screen_skip = prune_sample >= 0 ? ctx->d_screen_skip : nullptr;
+        if (prune_sample >= 0) {
+            // storms still open for accept test 1 when they end: the list k_screen works through (flags of the others stay 0)
+            a.und_list = ctx->d_und_list; a.und_count = ctx->d_und_count;
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_und_count, 0, sizeof(unsigned long long), st));
+            HIPCHK(ctx, hipMemsetAsync(out.flags, 0, sizeof(int32_t) * (size_t)n, st));
+        }
         HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, kQueueWords * sizeof(unsigned long long), st));
         const unsigned final_waves = park_final_waves();
         // (a segmented first pass can park any number of its storms)
@@ -653,6 +666,7 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
         a.envw = out.envw; a.flags = out.flags; a.pad_state = out.pad_state;
         a.K = EK;
         a.screen_skip = prune_sample >= 0 ? ctx->d_screen_skip : nullptr;
+        if (prune_sample >= 0) { a.und_list = ctx->d_und_list; a.und_count = ctx->d_und_count; }
         const unsigned chunks = (unsigned)((ns + kPostThreads - 1) / kPostThreads);
         if (out.tc_rows_only) {
             // Only what the reference does (compute.py:185-204): accept test 1 from the v series alone, then env
@@ -750,7 +764,7 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_mask_bits);
     (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_srec); (void)hipFree(ctx->d_vrec);
     for (auto &ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
-    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_seg_sids); (void)hipFree(ctx->d_screen_skip); (void)hipFree(ctx->d_tab);
+    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_seg_sids); (void)hipFree(ctx->d_screen_skip); (void)hipFree(ctx->d_und_list); (void)hipFree(ctx->d_und_count); (void)hipFree(ctx->d_tab);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;

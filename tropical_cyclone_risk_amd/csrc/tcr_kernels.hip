@@ -66,6 +66,8 @@ struct KArgsT {
     // writing its step records (nothing downstream reads them).
     int prune_sample;
     uint8_t *screen_skip;        // [n]: written for every storm when it ends (1: failed the 2-day test in flight)
+    int32_t *und_list;           // storms accept test 1 is still open for when they end (neither gated nor failed in flight), any order
+    unsigned long long *und_count;
 };
 using KArgs = KArgsT<double>;
 constexpr int kVRec = 12;
@@ -557,6 +559,8 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
         a.n_accept[sid] = nacc;
         a.n_reject[sid] = nrej;
         if (a.screen_skip) a.screen_skip[sid] = doomed ? 1 : 0;
+        if (a.und_list && !doomed && status != TCR_STATUS_GATED && next_out > 0)
+            a.und_list[atomicAdd(a.und_count, 1ull)] = (int32_t)sid;            // k_screen works through this list only
         active = false;
     };
     // one attempt of _step_impl's while-loop: clip to t_bound, stage-2 input (rk.py:137-146, 62-66)
@@ -937,6 +941,8 @@ struct EArgsT {
     const int64_t *count;
     int64_t item_base;           // k_emit's overflow launch: first list entry it handles
     const uint8_t *screen_skip;  // k_screen: storms the integrator already found to fail the 2-day test (KArgsT::screen_skip; NULL: none)
+    const int32_t *und_list;     // k_screen: if set, only these storms are looked at (KArgsT::und_list); flags[] was zeroed beforehand
+    const unsigned long long *und_count;
     EvalKT<R> K;                 // built on the host; k_emit's small workgroups copy it to LDS
 };
 using EArgs = EArgsT<double>;
@@ -1201,9 +1207,12 @@ __global__ __launch_bounds__(kScreenThreads) void k_screen(EArgsT<R> a)
     __shared__ R cap[kScreenStorms][3];      // v at sample j2d, j2d + 1, n - 1
     const tcr_params &P = a.P;
     const int g = threadIdx.x / kScreenGroup, l = threadIdx.x % kScreenGroup;
-    const int64_t sid = (int64_t)blockIdx.x * kScreenStorms + g;
-    const bool on = sid < a.n;                       // writes a flag
-    const bool exists = sid < n_eff(a.n, a.n_dev);   // has a storm behind it
+    const int64_t item = (int64_t)blockIdx.x * kScreenStorms + g;
+    if (a.und_list && (int64_t)blockIdx.x * kScreenStorms >= (int64_t)*a.und_count) return;      // uniform per workgroup
+    const bool listed = a.und_list && item < (int64_t)*a.und_count;
+    const int64_t sid = a.und_list ? (listed ? (int64_t)a.und_list[item] : 0) : item;
+    const bool on = a.und_list ? listed : sid < a.n;                       // writes a flag
+    const bool exists = a.und_list ? listed : sid < n_eff(a.n, a.n_dev);   // has a storm behind it
     const int ns = P.n_steps;
     int n = 0, nst = 0, st = TCR_STATUS_GATED;
     if (exists) {
