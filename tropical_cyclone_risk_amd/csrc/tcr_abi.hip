@@ -678,14 +678,8 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
                 if (dev_alloc(ctx, &ctx->d_tc_idx, (size_t)n)) return -1;
                 ctx->tc_idx_cap = (size_t)n;
             }
-            if (a.und_list) {
-                // k_screen appends the storms that pass to the list itself (k_dense / k_emit / k_flags write by storm id: order is free)
-                static_assert(sizeof(*ctx->d_tc_count) == sizeof(unsigned long long), "count word");
-                a.tc_out = ctx->d_tc_idx; a.tc_out_count = reinterpret_cast<unsigned long long *>(ctx->d_tc_count);
-                HIPCHK(ctx, hipMemsetAsync(ctx->d_tc_count, 0, sizeof(unsigned long long), st));
-            }
             hipLaunchKernelGGL(k_screen<R>, dim3((unsigned)((n + kScreenStorms - 1) / kScreenStorms)), dim3(kScreenThreads), 0, st, a);
-            if (!a.und_list && tcr_compact_dev(ctx, n, out.flags, TCR_FLAG_IS_TC, n, ctx->d_tc_idx, ctx->d_tc_count, st)) return -1;
+            if (tcr_compact_dev(ctx, n, out.flags, TCR_FLAG_IS_TC, n, ctx->d_tc_idx, ctx->d_tc_count, st)) return -1;
             a.list = ctx->d_tc_idx; a.count = ctx->d_tc_count;
         }
         // k_dense, TC rows only: a bounded grid of waves walks the device-side list (one wave per storm otherwise)

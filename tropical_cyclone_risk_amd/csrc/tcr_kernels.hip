@@ -943,8 +943,6 @@ struct EArgsT {
     const uint8_t *screen_skip;  // k_screen: storms the integrator already found to fail the 2-day test (KArgsT::screen_skip; NULL: none)
     const int32_t *und_list;     // k_screen: if set, only these storms are looked at (KArgsT::und_list); flags[] was zeroed beforehand
     const unsigned long long *und_count;
-    int32_t *tc_out;             // k_screen in list mode: the storms that pass accept test 1 are appended here (any order) ...
-    unsigned long long *tc_out_count;    // ... instead of being compacted out of flags[] afterwards
     EvalKT<R> K;                 // built on the host; k_emit's small workgroups copy it to LDS
 };
 using EArgs = EArgsT<double>;
@@ -1320,11 +1318,7 @@ __global__ __launch_bounds__(kScreenThreads) void k_screen(EArgsT<R> a)
     int hit = any15 ? 1 : 0;
     for (int off = kScreenGroup / 2; off > 0; off >>= 1) hit |= __shfl_xor(hit, off);       // every lane takes part
     any15 = hit != 0;
-    if (on && l == 0) {
-        const bool tc = any15 && pass2d;
-        a.flags[sid] = tc ? TCR_FLAG_IS_TC : 0;
-        if (tc && a.tc_out) a.tc_out[atomicAdd(a.tc_out_count, 1ull)] = (int32_t)sid;
-    }
+    if (on && l == 0) a.flags[sid] = (any15 && pass2d) ? TCR_FLAG_IS_TC : 0;
 }
 
 template <typename R>
