@@ -168,7 +168,10 @@ class Ensemble:
                 self.cmes[int(mo)] = CMonthEnv(self.env, self.basin, int(mo) - 1, self.bounds)
                 self.envs[int(mo) - 1] = C.pointer(self.cmes[int(mo)].c)
 
-    def run(self, storms, post=True, probe=False):
+    def run(self, storms, post=True, probe=False, force=None):
+        """force: [n, cap] uint8 decision probes of another implementation (decision-forced replay, see
+        tc_oracle.c orc_storm.force): rounding-sensitive `land == 1` evaluations take that side's decision.
+        Adds 'overridden' and 'hard_mismatch' [n] to the result."""
         p = self.p
         n = len(storms['lon'])
         ns = p.n_steps
@@ -181,14 +184,22 @@ class Ensemble:
         counters = np.zeros((n, 5), np.int32); flags = np.zeros((n, 2), np.int32)
         dec = np.full((n, PROBE_CAP), 0xff, np.uint8) if probe else None
         dec_t0 = np.full((n, PROBE_CAP), np.nan) if probe else None
-        lib().orc_run_ensemble_probe(self.envs, C.byref(p), C.c_int(n), _dp(lon0), _dp(lat0), _dp(v0), _dp(m0),
-                                     _dp(h_bl), _ip(months), _dp(ph), _dp(traj), _dp(envw), _dp(vmax),
-                                     _ip(n_valid), _ip(status), _ip(counters), _ip(flags), C.c_int(1 if post else 0),
-                                     dec.ctypes.data_as(C.c_void_p) if probe else None,
-                                     dec_t0.ctypes.data_as(C.c_void_p) if probe else None, C.c_int(PROBE_CAP))
+        finfo = np.zeros((n, 2), np.int32)
+        if force is not None:
+            force = np.ascontiguousarray(force, dtype=np.uint8)
+            assert force.ndim == 2 and force.shape[0] == n
+        lib().orc_run_ensemble_forced(self.envs, C.byref(p), C.c_int(n), _dp(lon0), _dp(lat0), _dp(v0), _dp(m0),
+                                      _dp(h_bl), _ip(months), _dp(ph), _dp(traj), _dp(envw), _dp(vmax),
+                                      _ip(n_valid), _ip(status), _ip(counters), _ip(flags), C.c_int(1 if post else 0),
+                                      dec.ctypes.data_as(C.c_void_p) if probe else None,
+                                      dec_t0.ctypes.data_as(C.c_void_p) if probe else None, C.c_int(PROBE_CAP),
+                                      force.ctypes.data_as(C.c_void_p) if force is not None else None,
+                                      C.c_int(force.shape[1] if force is not None else 0), _ip(finfo))
         if not post:
             envw[:] = np.nan; vmax[:] = np.nan
         extra = dict(dec=dec, dec_t0=dec_t0) if probe else {}
+        if force is not None:
+            extra.update(overridden=finfo[:, 0].copy(), hard_mismatch=finfo[:, 1].copy())
         return dict(traj=traj, envw=envw, vmax=vmax, n_valid=n_valid, status=status, **extra,
                     nfev=counters[:, 0].copy(), n_accept=counters[:, 1].copy(),
                     n_reject=counters[:, 2].copy(), anomaly=counters[:, 3].copy(),
@@ -196,8 +207,19 @@ class Ensemble:
                     is_tc=flags[:, 0].astype(bool), accepted=flags[:, 1].astype(bool))
 
 
-def run_ensemble(env, basin, storms, prm=None, post=True, bounds=None, probe=False):
+def run_ensemble(env, basin, storms, prm=None, post=True, bounds=None, probe=False, force=None):
     """Same contract as scipy_port.run_ensemble, plus per-storm step counters.  probe=True adds
     'dec' [n, PROBE_CAP] uint8 (per RHS evaluation: bit0 `land == 1`, bit1 PI != 0, bit2 land within
     1e-12 of 1; 0xff = not evaluated) and 'dec_t0' (start time of the step attempt of that evaluation)."""
-    return Ensemble(env, basin, prm, bounds).run(storms, post=post, probe=probe)
+    return Ensemble(env, basin, prm, bounds).run(storms, post=post, probe=probe, force=force)
+
+
+def replayer(env, basin, storms, prm=None, bounds=None, ensemble=None):
+    """Callback for parity.check_tracks: `replay(idx, dec_force)` re-runs storms `idx` with the other
+    implementation's decision sequence forced at the rounding-sensitive evaluations."""
+    ens = ensemble or Ensemble(env, basin, prm, bounds)
+
+    def replay(idx, dec_force):
+        sub = {k: np.asarray(v)[idx] for k, v in storms.items()}
+        return ens.run(sub, post=True, probe=True, force=dec_force)
+    return replay

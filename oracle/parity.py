@@ -1,30 +1,42 @@
-"""ORACLE-side checker (test infrastructure): pointwise / prefix parity of a batch of tracks.
+"""ORACLE-side checker (test infrastructure): pointwise parity of a batch of tracks, with a
+decision-forced replay for the storms whose `land == 1` decisions differ.
 
 The reference's over-land test ``f_land.ev(lon, lat) == 1`` (intensity/coupled_fast.py:35-38) runs
 on a bilinear sum whose weights add up to 1 only within rounding, so in the interior of land it is
 True or False with the last bits of lon/lat ("flicker").  Where the interpolated PI is non-zero the
 RHS then jumps between PI and 0, and two implementations whose trajectories differ by 1e-13 stop
 agreeing at the first evaluation where the decision lands differently — by an amount bounded only
-by the integrator's own rtol.  Instead of waving such storms through, every implementation records
-the decision of every RHS evaluation (the "decision probe"), and this checker asserts
+by the integrator's own rtol.  Every implementation therefore records the decision of every RHS
+evaluation (the "decision probe": bit 0 `land == 1`, bit 1 PI != 0, bit 2 land within 1e-12 of 1), and
+this checker asserts
 
   * storms whose decision sequences agree: identical discrete results (status, n_valid, nfev, accept
     flags, step counters when given) and the stated fp64 tolerance on every sample;
-  * storms whose sequences differ at evaluation k: everything emitted before the step attempt that
-    contains evaluation k — i.e. every hourly sample up to that attempt's start time — agrees to the
-    same tolerance tiers, and both tracks are at least that long.  Nothing is skipped.
+  * storms whose sequences differ at evaluation k:
+      - the differing evaluation itself is rounding-sensitive (bit 2 on either side AT evaluation k) —
+        a differing decision anywhere else is a bug (coastline indexing, wrong cell) and fails;
+      - everything emitted before the step attempt that contains evaluation k agrees (prefix check);
+      - **decision-forced replay**: the C oracle is run again taking the other side's decision at every
+        rounding-sensitive evaluation (tc_oracle.c, orc_run_ensemble_forced; pinned to the reference's own
+        code by tests/golden/forced_*.npz).  Both sides then walk the same branch sequence, so the WHOLE
+        track is held to the same discrete equalities and the same pointwise tiers as the storms above;
+        the replay must leave no differing decision and report no hard mismatch.
+    No storm is skipped and none is only partly checked.
 
 Only tests/ and __graft_entry__.smoke() import this.
 """
 import numpy as np
 
-TOL_ALL = 1e-6        # every sample of every decision-identical storm (ensembles of up to a few thousand storms; the
-                      # tail grows with the ensemble exactly as the oracle's own response to a one-ulp input change does:
-                      # profiles/r02_parity_study.json)
-TOL_99 = 1e-8         # 99 % of those storms (max over the storm's samples)
-TOL_95 = 1e-9         # 95 % of those storms
-# samples before the first differing decision: the same tiers, over the storms that have such a prefix
-# (all <= TOL_ALL; 99 % <= TOL_99 and 95 % <= TOL_95 when there are enough of them, else all <= TOL_99)
+# Tiers on max |got - want| over a storm's hourly lon / lat / v / m / env winds / vmax, about 10x what was measured on
+# 20 000 storms per basin (profiles/r02_parity_study.json: p95 0.8-1.7e-12, p99 2-7e-11; the intensity equation
+# amplifies a perturbation while a storm intensifies, so the far tail grows with the ensemble exactly as the oracle's
+# own response to a one-ulp input change does — the study test bounds p99.9 / max by 10x that twin instead of TOL_ALL)
+TOL_ALL = 1e-6        # every sample of every storm (ensembles of up to a few thousand storms)
+TOL_99 = 1e-9         # 99 % of the storms: at most n // 100 + 1 storms above it
+TOL_95 = 2e-11        # 95 % of the storms: at most n // 20 + 2 storms above it
+# vmax (wind/tc_wind.py:6-21) contains the translation speed, a centred difference of hourly positions
+# (util/sphere.py:58-83): a derivative of the track, so its tiers are 5x the track's
+TIER_SCALE = {'vmax': 5.0}
 NOT_EVAL = 0xff
 
 
@@ -56,46 +68,53 @@ def _storm_maxdiff(a, b):
     return d.max(axis=1) if d.size else np.zeros(n)
 
 
+def _subset(d, idx, keys):
+    return {k: np.asarray(d[k])[idx] for k in keys if k in d}
+
+
 def check_tracks(tag, got, want, dec_got, dec_want, t0_want, t_s, counters=('status', 'n_valid', 'nfev'),
-                 flags=('is_tc', 'accepted'), names=('traj', 'envw', 'vmax'), verbose=True, tol_all=TOL_ALL):
-    """Assert pointwise / prefix parity of `got` against `want` (dicts of arrays: traj [n,4,ns],
-    envw [n,ns,4], vmax [n,ns], status, n_valid, nfev, is_tc, accepted ...).
+                 flags=('is_tc', 'accepted'), names=('traj', 'envw', 'vmax'), verbose=True, tol_all=TOL_ALL,
+                 replay=None, replay_as='want', tol_99=TOL_99, tol_95=TOL_95):
+    """Assert parity of `got` against `want` (dicts of arrays: traj [n,4,ns], envw [n,ns,4], vmax [n,ns],
+    status, n_valid, nfev, is_tc, accepted ...) — every storm pointwise over its whole track.
 
     dec_*: [n, cap] decision probes (bit0 `land == 1`, bit1 PI != 0, bit2 land within 1e-12 of 1; 0xff
     = not evaluated); t0_want [n, cap]: start time of the step attempt of each evaluation of `want`.
-    Returns a summary dict (counts of storms per class, exposure among accepted storms).
+
+    replay(idx, dec_force) -> result dict of the C oracle for storms `idx` with `dec_force` [len(idx), cap]
+    taken at the rounding-sensitive evaluations (c_oracle.replayer).  replay_as says which side the oracle plays:
+      'want' (GPU vs oracle): forced with got's decisions, `got[idx]` is compared with the replay;
+      'got'  (oracle vs a reference fixture): forced with want's decisions, the replay is compared with `want[idx]`.
+    Without `replay` the storms with a differing decision are only prefix-checked and the summary says so
+    (`unreplayed`); every caller in tests/ and smoke() passes one.
+    Returns a summary dict (counts of storms per class, exposure among accepted storms, worst differences).
     tol_all: the bound on every sample (TOL_ALL; the large-ensemble study passes its own, see
     tests/test_gpu_parity.py::test_parity_study_at_scale)."""
     n = len(want['n_valid'])
-    ns = len(t_s)
+    dec_got, dec_want = np.asarray(dec_got), np.asarray(dec_want)
     k = first_divergence(dec_got, dec_want)
-    len_g = (np.asarray(dec_got) != NOT_EVAL).sum(axis=1)
-    len_w = (np.asarray(dec_want) != NOT_EVAL).sum(axis=1)
+    len_g = (dec_got != NOT_EVAL).sum(axis=1)
+    len_w = (dec_want != NOT_EVAL).sum(axis=1)
     agree = k < 0
-    cap = min(np.asarray(dec_got).shape[1], np.asarray(dec_want).shape[1])
+    cap = min(dec_got.shape[1], dec_want.shape[1])
     # no differing decision => the same evaluations were made (beyond the probe's capacity the
     # discrete results below still pin it)
     same_len = (len_g == len_w) | (np.minimum(len_g, len_w) >= cap)
     assert same_len[agree].all(), (tag, 'evaluation count differs without a differing land decision',
                                    np.nonzero(agree & ~same_len)[0][:8])
-    # ---- decision-identical storms: full pointwise parity
+    div = np.nonzero(~agree)[0]
+    # ---- a differing decision may only occur AT an evaluation that is rounding-sensitive (bit 2 on either side, at
+    #      evaluation k itself): anything else is a wrong land decision, not flicker
+    if len(div):
+        at_k = dec_got[div, k[div]] | dec_want[div, k[div]]
+        bad = div[(at_k & 4) == 0]
+        assert bad.size == 0, (tag, 'land decision differs at an evaluation that is not within 1e-12 of land == 1',
+                               [(int(i), int(k[i])) for i in bad[:8]])
+    # ---- decision-identical storms: discrete results
     for key in tuple(counters) + tuple(flags):
         bad = agree & (np.asarray(got[key]) != np.asarray(want[key]))
         assert not bad.any(), (tag, key, np.nonzero(bad)[0][:8])
-    worst = {}
-    for name in names:
-        d = _storm_maxdiff(np.asarray(got[name])[agree], np.asarray(want[name])[agree])
-        worst[name] = float(d.max()) if d.size else 0.0
-        if verbose:
-            print('%s %-5s identical decisions: max %.3g  p99 %.3g  p95 %.3g   (n=%d)'
-                  % (tag, name, worst[name], np.percentile(d, 99) if d.size else 0, np.percentile(d, 95) if d.size else 0, d.size))
-        assert worst[name] <= tol_all, (tag, name, worst[name])
-        if d.size >= 100:
-            assert np.percentile(d, 99) <= TOL_99, (tag, name)
-        if d.size >= 20:
-            assert np.percentile(d, 95) <= TOL_95, (tag, name)
-    # ---- storms with a differing decision: prefix parity up to the attempt that contains it
-    div = np.nonzero(~agree)[0]
+    # ---- storms with a differing decision: prefix parity against `want` up to the attempt that contains it
     pref_worst, pref_samples, pref_max = 0.0, 0, []
     for i in div:
         t0 = float(np.asarray(t0_want)[i, k[i]])
@@ -124,27 +143,56 @@ def check_tracks(tag, got, want, dec_got, dec_want, t0_want, t_s, counters=('sta
             assert d <= tol_all, (tag, name, 'prefix of storm %d (first differing decision at evaluation %d, '
                                   't = %.0f s, %d samples)' % (i, k[i], t0, n_pref), d)
         pref_samples += n_pref
-    if pref_max:
-        pm = np.array(pref_max)
-        if pm.size >= 300:
-            assert np.percentile(pm, 99) <= TOL_99, (tag, 'prefix p99', np.percentile(pm, 99))
-        if pm.size >= 60:
-            assert np.percentile(pm, 95) <= TOL_95, (tag, 'prefix p95', np.percentile(pm, 95))
-        else:
-            assert pm.max() <= TOL_99, (tag, 'prefix max', pm.max())
-    exposed = ((np.asarray(dec_want) != NOT_EVAL) & ((np.asarray(dec_want) & 6) == 6)).any(axis=1)
+    # ---- ... and the decision-forced replay: the whole track of every such storm, pointwise
+    keys = tuple(counters) + tuple(flags) + tuple(names)
+    overridden = hard = 0
+    per_storm = {name: np.full(n, np.nan) for name in names}
+    for name in names:
+        per_storm[name][agree] = _storm_maxdiff(np.asarray(got[name])[agree], np.asarray(want[name])[agree])
+    replayed = 0
+    if replay is not None and len(div):
+        src_dec = dec_got if replay_as == 'want' else dec_want
+        alt = replay(div, np.ascontiguousarray(src_dec[div]))
+        hard = int(np.asarray(alt['hard_mismatch']).sum())
+        overridden = int(np.asarray(alt['overridden']).sum())
+        assert hard == 0, (tag, 'forced replay: decisions differ at evaluations that are not rounding-sensitive',
+                           div[np.asarray(alt['hard_mismatch']) > 0][:8])
+        left = first_divergence(np.asarray(alt['dec']), src_dec[div])
+        assert (left < 0).all(), (tag, 'forced replay still differs in a land decision', div[left >= 0][:8], left[left >= 0][:8])
+        a, b = (_subset(got, div, keys), alt) if replay_as == 'want' else (alt, _subset(want, div, keys))
+        for key in tuple(counters) + tuple(flags):
+            bad = np.asarray(a[key]) != np.asarray(b[key])
+            assert not bad.any(), (tag, key, 'after forced replay', div[bad][:8])
+        for name in names:
+            per_storm[name][div] = _storm_maxdiff(np.asarray(a[name]), np.asarray(b[name]))
+        replayed = len(div)
+    worst = {}
+    for name in names:
+        d = per_storm[name][~np.isnan(per_storm[name])]
+        worst[name] = float(d.max()) if d.size else 0.0
+        if verbose:
+            print('%s %-5s pointwise over whole tracks: max %.3g  p99 %.3g  p95 %.3g   (n=%d, %d of them replayed)'
+                  % (tag, name, worst[name], np.percentile(d, 99) if d.size else 0, np.percentile(d, 95) if d.size else 0,
+                     d.size, replayed))
+        assert worst[name] <= tol_all, (tag, name, worst[name], int(np.nanargmax(per_storm[name])))
+        # the tiers as counts, at every ensemble size: at most 1 % (+1) of the storms above tol_99, 5 % (+2) above tol_95
+        # (the additive slack only matters for the small curated golden sets, which over-sample intense storms)
+        sc = TIER_SCALE.get(name, 1.0)
+        assert (d > sc * tol_99).sum() <= d.size // 100 + 1, (tag, name, 'p99 tier', int((d > sc * tol_99).sum()), d.size)
+        assert (d > sc * tol_95).sum() <= d.size // 20 + 2, (tag, name, 'p95 tier', int((d > sc * tol_95).sum()), d.size)
+    exposed = ((dec_want != NOT_EVAL) & ((dec_want & 6) == 6)).any(axis=1)
     acc = np.asarray(want['accepted'], bool)
-    out = dict(n=n, identical=int(agree.sum()), diverged=int(len(div)), exposed=int(exposed.sum()),
+    out = dict(n=n, identical=int(agree.sum()), diverged=int(len(div)), replayed=int(replayed),
+               unreplayed=int(len(div) - replayed), pointwise=int(agree.sum() + replayed),
+               overridden=overridden, hard_mismatch=hard, exposed=int(exposed.sum()),
                exposed_identical=int((exposed & agree).sum()), accepted=int(acc.sum()),
                accepted_exposed=int((acc & exposed).sum()), accepted_diverged=int((acc & ~agree).sum()),
-               prefix_samples=int(pref_samples), prefix_worst=pref_worst, worst=worst)
-    # a differing decision can only come from an evaluation the probe marks as rounding-sensitive
-    assert (exposed | agree).all(), (tag, 'decision differs at a point that is not within 1e-12 of land == 1',
-                                     np.nonzero(~exposed & ~agree)[0][:8])
+               prefix_samples=int(pref_samples), prefix_worst=pref_worst, worst=worst, per_storm=per_storm)
     if verbose:
-        print('%s: %d storms — %d decision-identical (pointwise), %d diverged (prefix-checked, %d samples, worst %.3g); '
-              '%d flicker-exposed of which %d pointwise; accepted %d, of which exposed %d (%.0f %%), diverged %d'
-              % (tag, n, out['identical'], out['diverged'], pref_samples, pref_worst, out['exposed'],
-                 out['exposed_identical'], out['accepted'], out['accepted_exposed'],
+        print('%s: %d storms — %d decision-identical + %d decision-forced replays = %d pointwise over the whole track '
+              '(%d forced decisions, %d unforced mismatches), %d only prefix-checked; prefixes: %d samples, worst %.3g; '
+              '%d flicker-exposed of which %d decision-identical; accepted %d, of which exposed %d (%.0f %%), diverged %d'
+              % (tag, n, out['identical'], replayed, out['pointwise'], overridden, hard, out['unreplayed'], pref_samples,
+                 pref_worst, out['exposed'], out['exposed_identical'], out['accepted'], out['accepted_exposed'],
                  100.0 * out['accepted_exposed'] / max(1, out['accepted']), out['accepted_diverged']))
     return out

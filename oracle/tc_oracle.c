@@ -230,6 +230,17 @@ typedef struct {
     double *dec_t0;
     int dec_cap;
     double t_attempt;
+    /* decision-forced replay (parity checker only, may be NULL): force[k] is another implementation's
+     * probe byte for evaluation k (0xff = none).  Where this oracle's own land value is within 1e-12
+     * of 1 — the reference's `== 1` (coupled_fast.py:35-38) is then decided by rounding — the over-land
+     * decision of evaluation k is taken from force[k] bit 0 instead of the oracle's own comparison, so that
+     * the two implementations walk the same branch sequence and the whole track is comparable pointwise.
+     * Anywhere else the oracle keeps its own decision; if the other side's differs there and the
+     * interpolated PI is non-zero (the decision matters) that is a hard mismatch and is counted. */
+    const unsigned char *force;
+    int force_cap;
+    long n_overridden;      /* evaluations whose decision was taken from `force` and differed from the own one */
+    long n_hard;            /* differing decisions at evaluations that are NOT rounding-sensitive */
 } orc_storm;
 
 static void steering(const orc_params *p, double v, double *c)
@@ -247,9 +258,25 @@ static void steering(const orc_params *p, double v, double *c)
 
 static double sgn(double x) { return (x > 0) - (x < 0) + (x != x ? x : 0.0); }
 
-static double vpot_here(const orc_env *e, double lon, double lat)
+/* `_get_over_land` (coupled_fast.py:35-38) for RHS evaluation `k` of storm `s` (the gate and f0 are both
+ * evaluation 0 and read the same point).  Without a forced sequence this is the plain `== 1`. */
+static int over_land(orc_storm *s, long k, double lon, double lat, int count)
 {
-    if (orc_bilinear(&e->hg, e->land, lon, lat) == 1.0) return 0.0;
+    const orc_env *e = s->e;
+    double l = orc_bilinear(&e->hg, e->land, lon, lat);
+    int own = (l == 1.0);
+    if (!s->force || k >= s->force_cap || s->force[k] == 0xff) return own;
+    int other = s->force[k] & 1;
+    if (other == own) return own;
+    if (fabs(l - 1.0) <= 1e-12) { if (count) s->n_overridden++; return other; }
+    if (count && orc_bilinear(&e->tg, e->vpot, lon, lat) != 0.0) s->n_hard++;
+    return own;
+}
+
+static double vpot_given(const orc_env *e, int land, double lon, double lat)
+{
+    /* _get_current_vpot (coupled_fast.py:54-58) */
+    if (land) return 0.0;
     return orc_bilinear(&e->tg, e->vpot, lon, lat);
 }
 
@@ -267,12 +294,12 @@ static int flicker_exposed(const orc_env *e, double lon, double lat)
     return orc_bilinear(&e->tg, e->vpot, lon, lat) != 0.0;
 }
 
-static double ocean_alpha(const orc_storm *s, double lon, double lat, const double *vb, double v)
+static double ocean_alpha(const orc_storm *s, int land, double lon, double lat, const double *vb, double v)
 {
     const orc_env *e = s->e;
     double h_m = orc_bilinear(&e->tg, e->mld, lon, lat);
     double gam = orc_bilinear(&e->tg, e->strat, lon, lat);
-    double vp = vpot_here(e, lon, lat);
+    double vp = vpot_given(e, land, lon, lat);      /* _calc_alpha looks PI up again: the same decision */
     double uT = sqrt(vb[0] * vb[0] + vb[1] * vb[1]);
     double bathy = orc_bilinear(&e->bg, e->bathy, lon, lat);
     if (bathy >= 0 || -h_m <= bathy || gam == 0) return 1.0;
@@ -290,10 +317,11 @@ void orc_rhs(orc_storm *s, double t, const double *y, double *dy, double *w_out)
     double lon = y[0], lat = y[1], v = y[2], m = y[3];
     double c[2], vb[2], w[NW];
     s->flicker += flicker_exposed(e, lon, lat);
+    int land = over_land(s, s->nfev - 1, lon, lat, 1);
     if (s->dec && s->nfev - 1 < s->dec_cap) {
         double l = orc_bilinear(&e->hg, e->land, lon, lat);
-        int d = (l == 1.0 ? 1 : 0) | (orc_bilinear(&e->tg, e->vpot, lon, lat) != 0.0 ? 2 : 0) |
-                (fabs(l - 1.0) <= 1e-12 ? 4 : 0);
+        int d = (land ? 1 : 0) | (orc_bilinear(&e->tg, e->vpot, lon, lat) != 0.0 ? 2 : 0) |
+                (fabs(l - 1.0) <= 1e-12 ? 4 : 0) | ((land != (l == 1.0)) ? 8 : 0);   /* bit 3: decision was forced */
         s->dec[s->nfev - 1] = (unsigned char)d;
         if (s->dec_t0) s->dec_t0[s->nfev - 1] = s->t_attempt;
     }
@@ -308,8 +336,8 @@ void orc_rhs(orc_storm *s, double t, const double *y, double *dy, double *w_out)
     }
     dy[0] = vb[0] / p->earth_R * 180. / PI_ / cos(lat * PI_ / 180.);
     dy[1] = vb[1] / p->earth_R * 180. / PI_;
-    double vp = vpot_here(e, lon, lat);
-    double al = ocean_alpha(s, lon, lat, vb, v);
+    double vp = vpot_given(e, land, lon, lat);
+    double al = ocean_alpha(s, land, lon, lat, vb, v);
     double beta = 1 - p->epsilon - p->kappa;
     double gamma = p->epsilon + al * p->kappa;
     double m3 = pow(m, 3.0);
@@ -328,7 +356,7 @@ void orc_rhs_points(const orc_env *e, const orc_params *p, const double *Fs, dou
                     const double *t, const double *lon, const double *lat, const double *v,
                     const double *m, double *dydt, double *envw, double *alpha)
 {
-    orc_storm s = { e, p, Fs, h_bl, 0, 0, NULL, NULL, 0, 0.0 };
+    orc_storm s = { e, p, Fs, h_bl, 0, 0, NULL, NULL, 0, 0.0, NULL, 0, 0, 0 };
     for (int i = 0; i < n; i++) {
         double y[4] = { lon[i], lat[i], v[i], m[i] };
         orc_rhs(&s, t[i], y, dydt + 4 * i, NULL);
@@ -341,7 +369,7 @@ void orc_rhs_points(const orc_env *e, const orc_params *p, const double *Fs, dou
             vb[0] = (w[0] * c[0] + w[2] * c[1]) + p->u_beta * cl;
             vb[1] = (w[1] * c[0] + w[3] * c[1]) + (sgn(lat[i]) * p->v_beta) * cl;
         }
-        alpha[i] = ocean_alpha(&s, lon[i], lat[i], vb, v[i]);
+        alpha[i] = ocean_alpha(&s, over_land(&s, 0, lon[i], lat[i], 0), lon[i], lat[i], vb, v[i]);
     }
 }
 
@@ -390,14 +418,15 @@ static double event_fn(const orc_env *e, const double *y)
  *          anomaly (dense output at the step end disagrees with y_new about the event),
  *          [4]=RHS evaluations exposed to the `land == 1` rounding flicker (diagnostic).
  */
-int orc_integrate_probe(const orc_env *e, const orc_params *p, double lon0, double lat0, double v0,
-                        double m0, double h_bl, const double *phases, double *traj, int *n_valid,
-                        int *counters, double *Fs_out, unsigned char *dec, double *dec_t0, int dec_cap)
+static int integrate_impl(const orc_env *e, const orc_params *p, double lon0, double lat0, double v0,
+                          double m0, double h_bl, const double *phases, double *traj, int *n_valid,
+                          int *counters, double *Fs_out, unsigned char *dec, double *dec_t0, int dec_cap,
+                          const unsigned char *force, int force_cap, int *forced_info)
 {
     int ns = p->n_steps;
     double *Fs = Fs_out ? Fs_out : (double *)malloc(sizeof(double) * NW * ns);
     orc_fourier_table(p, phases, Fs);
-    orc_storm s = { e, p, Fs, h_bl, 0, 0, dec, dec_t0, dec_cap, 0.0 };
+    orc_storm s = { e, p, Fs, h_bl, 0, 0, dec, dec_t0, dec_cap, 0.0, force, force_cap, 0, 0 };
     int status;
     long nacc = 0, nrej = 0, anomaly = 0;
     *n_valid = 0;
@@ -409,14 +438,16 @@ int orc_integrate_probe(const orc_env *e, const orc_params *p, double lon0, doub
         orc_env_winds(e, p, Fs, lon0, lat0, 0.0, w);
         double du = w[0] - w[2], dv = w[1] - w[3];
         double S = sqrt(du * du + dv * dv);
-        double vp = vpot_here(e, lon0, lat0);
+        int land = over_land(&s, 0, lon0, lat0, 0);      /* counted once, by f0, unless the storm is gated */
+        double vp = vpot_given(e, land, lon0, lat0);
         double chi = orc_bilinear(&e->tg, e->chi, lon0, lat0);
         if (dec && dec_cap > 0) {       /* the gate reads the same `land == 1` decision f0 will read */
             double l = orc_bilinear(&e->hg, e->land, lon0, lat0);
-            dec[0] = (unsigned char)((l == 1.0 ? 1 : 0) | (orc_bilinear(&e->tg, e->vpot, lon0, lat0) != 0.0 ? 2 : 0) |
-                                     (fabs(l - 1.0) <= 1e-12 ? 4 : 0));
+            dec[0] = (unsigned char)((land ? 1 : 0) | (orc_bilinear(&e->tg, e->vpot, lon0, lat0) != 0.0 ? 2 : 0) |
+                                     (fabs(l - 1.0) <= 1e-12 ? 4 : 0) | ((land != (l == 1.0)) ? 8 : 0));
             if (dec_t0) dec_t0[0] = 0.0;
         }
+        if (vp > 0 && S * chi / vp >= 1) over_land(&s, 0, lon0, lat0, 1);
         if (vp > 0 && S * chi / vp >= 1) { status = -1; goto done; }
     }
     {
@@ -542,8 +573,17 @@ int orc_integrate_probe(const orc_env *e, const orc_params *p, double lon0, doub
 done:
     if (counters) { counters[0] = (int)s.nfev; counters[1] = (int)nacc; counters[2] = (int)nrej; counters[3] = (int)anomaly; counters[4] = (int)s.flicker; }
     if (status == -1) { if (counters) counters[0] = 0; }
+    if (forced_info) { forced_info[0] = (int)s.n_overridden; forced_info[1] = (int)s.n_hard; }
     if (!Fs_out) free(Fs);
     return status;
+}
+
+int orc_integrate_probe(const orc_env *e, const orc_params *p, double lon0, double lat0, double v0,
+                        double m0, double h_bl, const double *phases, double *traj, int *n_valid,
+                        int *counters, double *Fs_out, unsigned char *dec, double *dec_t0, int dec_cap)
+{
+    return integrate_impl(e, p, lon0, lat0, v0, m0, h_bl, phases, traj, n_valid, counters, Fs_out,
+                          dec, dec_t0, dec_cap, NULL, 0, NULL);
 }
 
 int orc_integrate(const orc_env *e, const orc_params *p, double lon0, double lat0, double v0,
@@ -620,6 +660,35 @@ void orc_post(const orc_env *e, const orc_params *p, const double *Fs, int statu
 }
 
 /* Whole ensemble, storm-major outputs.  env_of_month[12] may contain NULLs for unused months. */
+/* dec_force [n][force_cap] (or NULL): another implementation's decision probes, see orc_storm.force;
+ * forced_info [n][2] (or NULL): per storm {decisions taken from dec_force that differed from the oracle's own,
+ * differing decisions at evaluations that are not rounding-sensitive (hard mismatches; must be 0)}. */
+void orc_run_ensemble_forced(const orc_env *const *env_of_month, const orc_params *p, int n,
+                             const double *lon0, const double *lat0, const double *v0, const double *m0,
+                             const double *h_bl, const int *month, const double *phases,
+                             double *traj, double *envw, double *vmax, int *n_valid, int *status,
+                             int *counters, int *flags, int do_post,
+                             unsigned char *dec /* [n][dec_cap] or NULL */, double *dec_t0, int dec_cap,
+                             const unsigned char *dec_force, int force_cap, int *forced_info)
+{
+    int ns = p->n_steps;
+    double *Fs = (double *)malloc(sizeof(double) * NW * ns);
+    for (int i = 0; i < n; i++) {
+        const orc_env *e = env_of_month[month[i] - 1];
+        double *tr = traj + (size_t)i * 4 * ns;
+        status[i] = integrate_impl(e, p, lon0[i], lat0[i], v0[i], m0[i], h_bl[i],
+                                   phases + (size_t)i * NW * p->n_series, tr, n_valid + i,
+                                   counters + 5 * i, Fs, dec ? dec + (size_t)i * dec_cap : NULL,
+                                   dec_t0 ? dec_t0 + (size_t)i * dec_cap : NULL, dec_cap,
+                                   dec_force ? dec_force + (size_t)i * force_cap : NULL, force_cap,
+                                   forced_info ? forced_info + 2 * i : NULL);
+        if (do_post)
+            orc_post(e, p, Fs, status[i], n_valid[i], tr, envw + (size_t)i * ns * 4,
+                     vmax + (size_t)i * ns, flags + 2 * i);
+    }
+    free(Fs);
+}
+
 void orc_run_ensemble_probe(const orc_env *const *env_of_month, const orc_params *p, int n,
                             const double *lon0, const double *lat0, const double *v0, const double *m0,
                             const double *h_bl, const int *month, const double *phases,
@@ -627,20 +696,8 @@ void orc_run_ensemble_probe(const orc_env *const *env_of_month, const orc_params
                             int *counters, int *flags, int do_post,
                             unsigned char *dec /* [n][dec_cap] or NULL */, double *dec_t0, int dec_cap)
 {
-    int ns = p->n_steps;
-    double *Fs = (double *)malloc(sizeof(double) * NW * ns);
-    for (int i = 0; i < n; i++) {
-        const orc_env *e = env_of_month[month[i] - 1];
-        double *tr = traj + (size_t)i * 4 * ns;
-        status[i] = orc_integrate_probe(e, p, lon0[i], lat0[i], v0[i], m0[i], h_bl[i],
-                                        phases + (size_t)i * NW * p->n_series, tr, n_valid + i,
-                                        counters + 5 * i, Fs, dec ? dec + (size_t)i * dec_cap : NULL,
-                                        dec_t0 ? dec_t0 + (size_t)i * dec_cap : NULL, dec_cap);
-        if (do_post)
-            orc_post(e, p, Fs, status[i], n_valid[i], tr, envw + (size_t)i * ns * 4,
-                     vmax + (size_t)i * ns, flags + 2 * i);
-    }
-    free(Fs);
+    orc_run_ensemble_forced(env_of_month, p, n, lon0, lat0, v0, m0, h_bl, month, phases, traj, envw, vmax,
+                            n_valid, status, counters, flags, do_post, dec, dec_t0, dec_cap, NULL, 0, NULL);
 }
 
 void orc_run_ensemble(const orc_env *const *env_of_month, const orc_params *p, int n,

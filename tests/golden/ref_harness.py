@@ -114,12 +114,28 @@ class InjectedRandom:
         np.random.rand = self._orig
 
 
-def gen_track(ref, f, lon, lat, v0, m0, h_bl, phases):
+def gen_track(ref, f, lon, lat, v0, m0, h_bl, phases, script=None):
     """Run the reference gen_track with injected Fourier phases.
 
     Returns dict(status, n, t, y[4,n], nfev) with status -1 for a gated seed.
+
+    script (optional, used only for the forced-replay fixtures): callable(eval_index, own_decision) ->
+    decision.  When given, the reference's `_get_over_land` is replaced — on this instance only — by its
+    own test wherever the land value is NOT within 1e-12 of 1, and by `script(k, own)` where it is (the
+    decision is then a matter of rounding, coupled_fast.py:35-38); k is the index of the dydt call being
+    served (0 for the gate, which reads the same point as the first call).  The recorded bit 0 is the
+    decision the reference's code actually used.
     """
     f.h_bl = h_bl
+    cur = [0]
+    if script is not None:
+        def scripted_over_land(clon, clat):
+            l = float(f.f_land.ev(clon, clat).flatten()[0])
+            own = (l == 1)
+            if abs(l - 1.0) <= 1e-12:
+                return bool(script(cur[0], own))
+            return own
+        f._get_over_land = scripted_over_land
     # Decision probe: the reference's over-land test `f_land.ev(lon, lat) == 1` (coupled_fast.py:35-38)
     # is decided by rounding in the interior of land, so the parity tests compare trajectories up to the
     # first RHS evaluation where that decision lands differently.  Record, per call of the reference's
@@ -130,6 +146,7 @@ def gen_track(ref, f, lon, lat, v0, m0, h_bl, phases):
     orig = f.dydt
 
     def probed(t, y):
+        cur[0] = len(rec_d)
         l = float(f.f_land.ev(y[0], y[1]).item())
         d = (1 if f._get_over_land(y[0], y[1]) else 0) | (2 if float(f.f_vpot.ev(y[0], y[1]).item()) != 0.0 else 0) | \
             (4 if abs(l - 1.0) <= 1e-12 else 0)
@@ -142,11 +159,16 @@ def gen_track(ref, f, lon, lat, v0, m0, h_bl, phases):
     finally:
         del f.dydt
     if res is None:
+        cur[0] = 0
         l = float(f.f_land.ev(lon, lat).item())
         d = (1 if f._get_over_land(lon, lat) else 0) | (2 if float(f.f_vpot.ev(lon, lat).item()) != 0.0 else 0) | \
             (4 if abs(l - 1.0) <= 1e-12 else 0)
+        if script is not None:
+            del f._get_over_land
         return dict(status=-1, n=0, t=np.zeros(0), y=np.zeros((4, 0)), nfev=0,
                     dec=np.array([d], np.uint8), dec_t0=np.zeros(1))
+    if script is not None:
+        del f._get_over_land
     assert len(rec_d) == res.nfev
     return dict(status=int(res.status), n=int(res.t.size), t=res.t, y=res.y,
                 nfev=int(res.nfev), dec=np.array(rec_d, np.uint8), dec_t0=attempt_starts(np.array(rec_t)))

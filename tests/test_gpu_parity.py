@@ -33,18 +33,20 @@ def _storms(g):
                 month=g['month'], phases=g['phases'])
 
 
-def _check(tag, got, want, t_s, counters=('status', 'n_valid', 'nfev')):
+def _check(tag, got, want, t_s, replay, counters=('status', 'n_valid', 'nfev'), **tiers):
     """got: engine.integrate(..., probe_cap=PROBE_CAP); want: c_oracle.run_ensemble(..., probe=True) or a
-    golden fixture (decisions of the reference itself, ragged)."""
+    golden fixture (decisions of the reference itself, ragged); replay: c_oracle.replayer(env, basin, storms) — storms
+    whose `land == 1` decisions differ are re-run on the C oracle with the GPU's decisions forced at the
+    rounding-sensitive evaluations and then held, over their whole track, to the same bar as all the others."""
     from oracle import parity
     if 'dec_off' in want:
         dec_w = parity.ragged_to_padded(want['dec'], want['dec_off'], PROBE_CAP)
         t0_w = parity.ragged_to_padded(want['dec_t0'], want['dec_off'], PROBE_CAP, fill=np.nan, dtype=np.float64)
     else:
         dec_w, t0_w = want['dec'], want['dec_t0']
-    s = parity.check_tracks(tag, got, want, got['dec'], dec_w, t0_w, t_s, counters=counters)
-    # every exposed storm was checked pointwise or by prefix — none skipped
-    assert s['identical'] + s['diverged'] == s['n']
+    s = parity.check_tracks(tag, got, want, got['dec'], dec_w, t0_w, t_s, counters=counters, replay=replay, **tiers)
+    # every storm was checked pointwise over its whole track — none skipped, none only prefix-checked
+    assert s['pointwise'] == s['n'] and s['unreplayed'] == 0 and s['hard_mismatch'] == 0
     return s
 
 
@@ -68,7 +70,9 @@ def test_tracks_vs_reference_golden(engines, golden_env, basin):
     g = np.load(os.path.join(GOLDEN, 'tracks_%s.npz' % basin))
     eng = engines(basin)
     out = eng.integrate(_storms(g), probe_cap=PROBE_CAP)
-    s = _check('golden-' + basin, out, g, eng.t_s)
+    # the golden sets are curated, not random: 27 % of the NA tracks are accepted storms (5.7 % in a seeded ensemble) — the
+    # long-lived intensifying ones that amplify a last-bit difference — so the 95 % tier is 1e-10 here instead of 2e-11
+    s = _check('golden-' + basin, out, g, eng.t_s, c_oracle.replayer(golden_env, basin, _storms(g)), tol_95=1e-10)
     # the golden sets hold 10 (NA), 5 (AU), 3 (GL) flicker-exposed tracks; each is pointwise- or prefix-checked
     assert s['exposed'] == {'NA': 10, 'AU': 5, 'GL': 3}[basin]
     assert s['exposed'] == int((c_oracle.run_ensemble(golden_env, basin, _storms(g), post=False)['flicker'] > 0).sum())
@@ -96,7 +100,8 @@ def test_ensemble_vs_c_oracle(engines, golden_env, basin, n, seed):
     eng = engines(basin)
     got = eng.integrate(storms, probe_cap=PROBE_CAP)
     ref = c_oracle.run_ensemble(golden_env, basin, storms, probe=True)
-    s = _check('oracle-' + basin, got, ref, eng.t_s, counters=('status', 'n_valid', 'nfev', 'n_accept', 'n_reject'))
+    s = _check('oracle-' + basin, got, ref, eng.t_s, c_oracle.replayer(golden_env, basin, storms),
+               counters=('status', 'n_valid', 'nfev', 'n_accept', 'n_reject'))
     assert s['accepted'] > 20 and s['accepted_exposed'] > 0      # accepted storms make landfall: the exposed ones are in the sample
     # the probe instantiation of the integrator is the production arithmetic
     plain = eng.integrate(storms)
@@ -136,7 +141,8 @@ def test_two_grid_and_nonuniform_fields(built_lib, shape, basin):
     t_s = eng.t_s
     eng.close()
     ref = c_oracle.run_ensemble(env, basin, storms, probe=True)
-    _check('%s-%s' % (shape, basin), got, ref, t_s, counters=('status', 'n_valid', 'nfev', 'n_accept', 'n_reject'))
+    _check('%s-%s' % (shape, basin), got, ref, t_s, c_oracle.replayer(env, basin, storms),
+           counters=('status', 'n_valid', 'nfev', 'n_accept', 'n_reject'))
 
 
 def test_independent_land_and_bathymetry_grids(built_lib):
@@ -166,7 +172,8 @@ def test_independent_land_and_bathymetry_grids(built_lib):
     o_dydt, o_envw, o_alpha = c_oracle.rhs_points(cme, Fs, 1800.0, t, lon, lat, v, m)
     assert (np.abs(dydt - o_dydt) / np.abs(o_dydt).max(axis=0)).max() < 1e-12 and np.abs(alpha - o_alpha).max() < 1e-12
     ref = c_oracle.run_ensemble(env, 'WP', storms, probe=True)
-    _check('split-static-WP', got, ref, t_s, counters=('status', 'n_valid', 'nfev', 'n_accept', 'n_reject'))
+    _check('split-static-WP', got, ref, t_s, c_oracle.replayer(env, 'WP', storms),
+           counters=('status', 'n_valid', 'nfev', 'n_accept', 'n_reject'))
     # and it matters: the same storms on the shared 0.25-degree bathymetry give different tracks
     env1 = synthetic.make_env('era5', seed=11)
     ref1 = c_oracle.run_ensemble(env1, 'WP', storms)
@@ -204,7 +211,7 @@ def test_other_output_grids(golden_env, built_lib, dt_out, days, T_days):
     ref = c_oracle.run_ensemble(golden_env, 'NA', storms, prm=prm, probe=True)
     for i in range(3):
         assert np.abs(Fs[i] - c_oracle.fourier_table(storms['phases'][i], prm)).max() < 5e-14
-    _check('dt%d-%dd' % (dt_out, days), got, ref, t_s)
+    _check('dt%d-%dd' % (dt_out, days), got, ref, t_s, c_oracle.replayer(golden_env, 'NA', storms, prm=prm))
 
 
 def test_full_size_ensemble_properties(golden_env, built_lib):
@@ -274,7 +281,7 @@ def test_full_size_ensemble_properties(golden_env, built_lib):
     eng.close()
     ref = c_oracle.run_ensemble(golden_env, 'GL', storms, probe=True)
     print('full size: %d storm-steps, %.1f %% accepted' % (np.clip(a['n_valid'] - 1, 0, None).sum(), 100 * a['accepted'].mean()))
-    _check('full-size-sample', small, ref, t_s)
+    _check('full-size-sample', small, ref, t_s, c_oracle.replayer(golden_env, 'GL', storms))
 
 
 def test_pad_state_reuse_is_bit_identical(golden_env, built_lib):
@@ -458,13 +465,14 @@ def test_wind_stats_kernel_vs_oracle(built_lib):
 
 @pytest.mark.skipif(not os.environ.get('TCR_PARITY_STUDY'), reason='opt-in: TCR_PARITY_STUDY=<storms per basin> writes gpurun_out/parity_study.json')
 def test_parity_study_at_scale(golden_env, built_lib):
-    """The parity tiers of this file on a large random ensemble per basin (profiles/r02_parity_study.json): every storm
-    pointwise- or prefix-checked against the C oracle, none skipped.  The intensity equation amplifies perturbations
+    """The parity tiers of this file on a large random ensemble per basin (profiles/r03_parity_study.json): every storm
+    checked pointwise over its whole track against the C oracle — decision-identical storms directly, the others after
+    the decision-forced replay; none skipped.  The intensity equation amplifies perturbations
     (an e-folding of hours while a storm intensifies), so over 20 000 fifteen-day tracks a last-bit difference of the
     device's libm grows to 1e-5 in a handful of storms — the same storms, and the same amounts, by which the ORACLE
-    moves when one of its inputs (v0) is changed by one ulp.  Asserted per basin, on decision-identical storms
+    moves when one of its inputs (v0) is changed by one ulp.  Asserted per basin, on ALL storms
     (per-storm maximum over lon / lat / v / m):
-      * p95 <= 1e-9, p99 <= 1e-8 (the tiers of the other tests);
+      * the p95 / p99 tiers of oracle/parity.py (2e-11 / 1e-9), as counts;
       * p99.9 and the maximum: no more than 10x the oracle's own p99.9 / maximum response to the one-ulp change
         (or 1e-6, whichever is larger)."""
     import json
@@ -473,7 +481,8 @@ def test_parity_study_at_scale(golden_env, built_lib):
     from tropical_cyclone_risk_amd.engine import TCEngine
     n = int(os.environ['TCR_PARITY_STUDY'])
     out = {'storms_per_basin': n,
-           'd_gpu': 'per storm max |GPU - C oracle| over lon, lat, v, m of the hourly samples (decision-identical storms)',
+           'd_gpu': 'per storm max |GPU - C oracle| over lon, lat, v, m of the hourly samples, ALL storms (the ones with a '
+                    'differing land == 1 decision against the decision-forced replay; d_gpu_replayed_storms = those alone)',
            'd_ulp': 'the same between the C oracle and the C oracle with v0 -> nextafter(v0) (same decision sequence and counters)'}
 
     def md(a, b):
@@ -490,16 +499,18 @@ def test_parity_study_at_scale(golden_env, built_lib):
         pert['v0'] = np.nextafter(storms['v0'], np.inf)
         ref2 = c_oracle.run_ensemble(golden_env, basin, pert, probe=True)
         from oracle import parity as P
-        s = P.check_tracks('study-' + basin, got, ref, got['dec'], ref['dec'], ref['dec_t0'], t_s, tol_all=np.inf)
-        assert s['identical'] + s['diverged'] == s['n']
+        s = P.check_tracks('study-' + basin, got, ref, got['dec'], ref['dec'], ref['dec_t0'], t_s, tol_all=np.inf,
+                           replay=c_oracle.replayer(golden_env, basin, storms))
+        assert s['pointwise'] == s['n'] and s['unreplayed'] == 0 and s['hard_mismatch'] == 0
         agree = P.first_divergence(got['dec'], ref['dec']) < 0
         twin = (P.first_divergence(ref2['dec'], ref['dec']) < 0) & (ref2['nfev'] == ref['nfev']) & (ref2['n_valid'] == ref['n_valid'])
-        d, u = md(got['traj'], ref['traj'])[agree], md(ref2['traj'], ref['traj'])[twin]
+        d, u = s['per_storm']['traj'], md(ref2['traj'], ref['traj'])[twin]
         q = lambda x: dict(zip(('p50', 'p95', 'p99', 'p99.9', 'max'), (float(v) for v in np.percentile(x, [50, 95, 99, 99.9, 100]))))
-        qd, qu = q(d), q(u)
-        assert qd['p95'] <= 1e-9 and qd['p99'] <= 1e-8, (basin, qd)
+        qd, qu, qr = q(d), q(u), q(d[~agree]) if (~agree).any() else None
+        qo = {name: q(s['per_storm'][name]) for name in ('envw', 'vmax')}
         assert qd['p99.9'] <= max(1e-6, 10 * qu['p99.9']) and qd['max'] <= max(1e-6, 10 * qu['max']), (basin, qd, qu)
         out[basin] = dict(summary={k: v for k, v in s.items() if not isinstance(v, dict)}, worst=s['worst'], d_gpu=qd, d_ulp=qu,
+                          d_gpu_replayed_storms=qr, d_gpu_envw=qo['envw'], d_gpu_vmax=qo['vmax'],
                           storms_over_1e9=int((d > 1e-9).sum()), oracle_twins_over_1e9=int((u > 1e-9).sum()),
                           accepted=int(ref['accepted'].sum()), is_tc=int(ref['is_tc'].sum()))
         print(basin, 'd_gpu', qd, 'd_ulp', qu)

@@ -57,7 +57,10 @@ def test_c_oracle_vs_reference(golden_env, basin):
     dec_ref = parity.ragged_to_padded(g['dec'], g['dec_off'], CO.PROBE_CAP)
     t0_ref = parity.ragged_to_padded(g['dec_t0'], g['dec_off'], CO.PROBE_CAP, fill=np.nan, dtype=np.float64)
     t_s = np.linspace(0, 15 * 86400.0, 361)
-    s = parity.check_tracks('c-oracle-' + basin, o, g, o['dec'], dec_ref, t0_ref, t_s)
+    # (all 85 golden tracks happen to be decision-identical; tests/golden/forced_*.npz hold the ones that are not)
+    s = parity.check_tracks('c-oracle-' + basin, o, g, o['dec'], dec_ref, t0_ref, t_s,
+                            replay=CO.replayer(golden_env, basin, _storms(g)), replay_as='got')
+    assert s['pointwise'] == s['n'] and s['unreplayed'] == 0
     assert s['exposed'] == int((o['flicker'] > 0).sum())         # the two exposure diagnostics agree
     # attempt start times reconstructed from the reference's evaluation times == the restatement's own record
     same = s['identical'] == len(g['n_valid'])
@@ -67,6 +70,58 @@ def test_c_oracle_vs_reference(golden_env, basin):
     tags = ','.join(g['tags'])
     for needed in ('full', 'dissipated', 'basin_exit', 'gated', 'v0_le_4', 'land', 'shelf'):
         assert needed in tags, needed       # the branches SURVEY §4 lists are all exercised
+
+
+@pytest.mark.parametrize('basin', ['NA', 'AU'])
+def test_forced_replay_reproduces_reference(golden_env, basin):
+    """Pin of the decision-forced replay (tc_oracle.c orc_run_ensemble_forced) — the mechanism every parity
+    test uses to check storms whose `land == 1` decisions differ over their WHOLE track.  The fixture
+    (tests/golden/make_golden_forced.py) holds reference tracks the C oracle does NOT reproduce on its own:
+    'natural' = the reference's rounding took another branch than the oracle's; 'scripted' = the reference run
+    with a fixed pseudo-random decision at every rounding-sensitive evaluation (its `_get_over_land` patched on
+    the instance, everything else its own code).  Forced with the decisions the reference recorded, the oracle
+    must reproduce status / n_valid / nfev / accept flags exactly and every sample to the pointwise tiers."""
+    from oracle import c_oracle as CO, parity
+    g = np.load(os.path.join(GOLDEN, 'forced_%s.npz' % basin))
+    assert str(g['meta_scipy']) == '1.15.3'
+    storms = _storms(g)
+    dec_ref = parity.ragged_to_padded(g['dec'], g['dec_off'], CO.PROBE_CAP)
+    t0_ref = parity.ragged_to_padded(g['dec_t0'], g['dec_off'], CO.PROBE_CAP, fill=np.nan, dtype=np.float64)
+    t_s = np.linspace(0, 15 * 86400.0, 361)
+    nat = CO.run_ensemble(golden_env, basin, storms, probe=True)
+    k = parity.first_divergence(nat['dec'], dec_ref)
+    natural = g['kind'] == 'natural'
+    assert natural.sum() >= 6 and (~natural).sum() >= 8
+    assert (k[natural] >= 0).all()                       # that is what 'natural' means
+    assert (k >= 0).sum() >= 0.7 * len(k)                # and most scripted ones take another branch too
+    # without the replay these storms are far away from the reference ...
+    far = np.abs(np.nan_to_num(nat['traj']) - np.nan_to_num(g['traj'])).reshape(len(k), -1).max(axis=1)
+    assert (far[k >= 0] > 1e-6).sum() >= 0.7 * (k >= 0).sum()
+    # ... and with it every one of them is reproduced over its whole track
+    s = parity.check_tracks('forced-' + basin, nat, g, nat['dec'], dec_ref, t0_ref, t_s,
+                            replay=CO.replayer(golden_env, basin, storms), replay_as='got')
+    assert s['replayed'] == int((k >= 0).sum()) and s['pointwise'] == len(k) and s['hard_mismatch'] == 0
+    assert s['overridden'] >= s['replayed']
+    assert max(s['worst'].values()) <= 2e-9
+    # forcing is inert where the oracle's own decision already equals the forced one: replaying its own probe is bit-identical
+    own = CO.run_ensemble(golden_env, basin, storms, probe=True, force=nat['dec'])
+    assert own['overridden'].sum() == 0 and own['hard_mismatch'].sum() == 0
+    for key in ('traj', 'envw', 'vmax'):
+        assert np.array_equal(own[key], nat[key], equal_nan=True)
+    # a differing decision at a point that is NOT rounding-sensitive is reported as a hard mismatch, never applied:
+    # flip bit 0 of every evaluation of a storm that never comes near land == 1
+    clean = np.nonzero(~(((nat['dec'] != 0xff) & ((nat['dec'] & 4) != 0)).any(axis=1)) & (nat['status'] >= 0))[0]
+    if clean.size == 0:                                  # (the forced fixtures are all exposed storms: take golden ones)
+        g2 = np.load(os.path.join(GOLDEN, 'tracks_%s.npz' % basin))
+        st2 = _storms(g2)
+        n2 = CO.run_ensemble(golden_env, basin, st2, probe=True)
+        clean = np.nonzero(~(((n2['dec'] != 0xff) & ((n2['dec'] & 4) != 0)).any(axis=1)) & (n2['status'] >= 0) &
+                           (((n2['dec'] != 0xff) & ((n2['dec'] & 2) != 0)).any(axis=1)))[0][:4]
+        sub = {kk: vv[clean] for kk, vv in st2.items()}
+        flipped = np.where(n2['dec'][clean] != 0xff, n2['dec'][clean] ^ 1, 0xff).astype(np.uint8)
+        bad = CO.run_ensemble(golden_env, basin, sub, probe=True, force=flipped)
+        assert (bad['hard_mismatch'] > 0).all() and bad['overridden'].sum() == 0
+        assert np.array_equal(bad['traj'], n2['traj'][clean], equal_nan=True)
 
 
 @pytest.mark.parametrize('name,month', [('NA', 9), ('SI', 2)])
