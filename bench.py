@@ -90,8 +90,8 @@ def main():
         BYTES_PER_RHS, BYTES_PER_SAMPLE = 352.0, 260.0          # SURVEY.md §8d, fp32 mode
     pipe = pipes[0]
 
-    acc = torch.zeros(6, dtype=torch.int64, device=dev)       # storm-steps, nfev, samples, accepted, is_tc, is_tc samples (tcr_stats_dev)
-    short = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(n_str)]   # rounds with < B passing seeds
+    # storm-steps, nfev, samples, accepted, is_tc, is_tc samples, rounds with < B passing seeds (tcr_stats_dev)
+    acc = torch.zeros(7, dtype=torch.int64, device=dev)
     row = 9 * ns
     # N > 1: all-gather of every batch's final (accepted) tracks through distributed.DeferredRowGather:
     # nothing in a step waits on the host — batch k's count is read back only when batch k + n_str is
@@ -108,8 +108,7 @@ def main():
         pipe.seed_round(year, D.round_block(k, C, rank, world))
         pipe.select_passed(B)
         pipe.integrate(B)
-        pipe.add_stats(acc)
-        short[k % n_str].add_((pipe.n_passed < B).long())
+        pipe.add_stats(acc, n_dev=pipe.n_passed)
         if gather is not None:
             buf = gather.buffer()                # waits (on this stream) for the gather that last read it
             pipe.select_accepted()
@@ -128,8 +127,6 @@ def main():
     drain()
     torch.cuda.synchronize()
     acc.zero_()
-    for t in short:
-        t.zero_()
     D.barrier(); torch.cuda.synchronize()
     for e in engs:
         e.timing_enable(True)        # resets the event record: only the K timed steps count
@@ -172,9 +169,9 @@ def main():
         iso_passes = engs[0].pass_stats()
     if world > 1:
         D.allreduce_sum_(acc)
-    steps_total, nfev_total, samples_total, accepted_total, tc_total, tc_samples_total = (float(x) for x in acc.tolist())
+    steps_total, nfev_total, samples_total, accepted_total, tc_total, tc_samples_total, n_short = (float(x) for x in acc.tolist())
     emitted_total = tc_samples_total if args.rows == 'tc' else samples_total     # samples k_emit actually produced
-    n_short = int(sum(int(t.item()) for t in short))
+    n_short = int(n_short)
     value = steps_total / dt
 
     # ---- roofline of the dominant kernel (k_integrate): algorithmic bytes per launch

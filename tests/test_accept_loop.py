@@ -128,6 +128,55 @@ def test_step_record_overflow_raises_on_every_rank():
     assert all('gpu_max_rk_steps' in got[r] and got[r].startswith('3 storms') for r in (0, 1)), got
 
 
+def _grow_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from tropical_cyclone_risk_amd import compute, distributed as D
+    D.init_from_env(backend='gloo')
+
+    class Round:
+        """Rank 1's storms overflow until the record has been doubled twice; rank 0 never sees an overflow itself."""
+        cap, calls, grown = 16, 0, 0
+
+        def __call__(self, cand0, count):
+            self.calls += 1
+            out = fake_round(cand0, count)
+            out['bad'] = 2 if (rank == 1 and self.cap < 64) else 0
+            return out
+
+        def grow(self):
+            self.cap *= 2
+            self.grown += 1
+            return True
+    rf = Round()
+    res = compute.accept_loop(rf, 25, 64, NS)
+    q.put((rank, res['cand'], res['n_seeds'], rf.grown, rf.calls, res['rounds']))
+    D.barrier()
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_step_record_overflow_grows_on_every_rank():
+    """A round function that can grow its step record (compute.GpuRound.grow) is asked to — on EVERY rank, because the
+    overflow count is part of the round's one all-gather — and the round is integrated again; the result is the
+    sequential loop's."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grow_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rows, cands, n_seeds = sequential(25)
+    for rank, cand, seeds, grown, calls, rounds in got:
+        assert np.array_equal(cand, cands) and np.array_equal(seeds, n_seeds), rank
+        assert grown == 2 and calls == rounds + 2, (rank, grown, calls, rounds)       # both ranks grew, both re-ran the first round twice
+
+
 def test_allgather_rows_ragged_gloo():
     """Ragged all-gather incl. an empty contribution and the rank-order guarantee."""
     ctx = mp.get_context('spawn')

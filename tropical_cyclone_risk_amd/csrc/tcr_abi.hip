@@ -590,7 +590,11 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
     // With a chain, the forcing table is written in two segments: samples [0, 192) for every storm now, the rest after the
     // first pass and only for the storms that pass parks — the pass parks a storm (its lane takes the next one) as soon as
     // its next attempt could read beyond the first segment.  58 % of the storms never get there.
-    const bool segmented = kFsMfmaColGroups == 2 && thr > 0 && fourier_on_matrix_cores(ctx) && (int)P.n_steps > kFsSegSamples + 16 && table_segments_enabled();
+    // (only when the first pass is not also the last one: a last pass never parks, so a table cut at sample 191 would strand
+    // every storm that lives beyond it — ADVICE r2: TCR_PARK forced on a batch of <= 8 waves)
+    const unsigned final_waves = park_final_waves();
+    const bool segmented = kFsMfmaColGroups == 2 && thr > 0 && waves > final_waves && kMaxPasses > 1 && fourier_on_matrix_cores(ctx) &&
+                           (int)P.n_steps > kFsSegSamples + 16 && table_segments_enabled();
     // TC rows only: the 2-day half of accept test 1 is decided in flight when 2 d is an output sample (KArgsT::prune_sample)
     int prune_sample = -1;
     if (out.tc_rows_only && prune_enabled()) {
@@ -626,7 +630,6 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
             HIPCHK(ctx, hipMemsetAsync(out.flags, 0, sizeof(int32_t) * (size_t)n, st));
         }
         HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, kQueueWords * sizeof(unsigned long long), st));
-        const unsigned final_waves = park_final_waves();
         // (a segmented first pass can park any number of its storms)
         const size_t park_items = segmented ? (size_t)n : (size_t)waves * kWave;
         if (thr > 0 && grow(ctx, &ctx->d_park[0], &ctx->park_cap[0], park_items * kParkRec)) return -1;

@@ -842,7 +842,8 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
                             const R v2d = (R)h * acc + v_old;
                             doomed = !((double)v2d >= P.v_2d_thresh);
                         }
-                        if (status == kRunning && nacc >= a.max_rk_steps) status = TCR_STATUS_STEP_OVERFLOW;
+                        // (a doomed storm writes no records and nobody reads any: it cannot overflow its record — ADVICE r2)
+                        if (status == kRunning && !doomed && nacc >= a.max_rk_steps) status = TCR_STATUS_STEP_OVERFLOW;
                         if (status != kRunning) finalize();
                         else begin_step();
                     } else {

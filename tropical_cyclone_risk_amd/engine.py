@@ -97,6 +97,16 @@ class TCEngine:
         if rc != 0:
             raise _lib.TcrError(self.L.tcr_last_error(self.h).decode())
 
+    def grow_step_record(self, limit=4096):
+        """Double tcr_params.max_rk_steps (accepted RK45 steps recorded per storm; the workspaces follow at the next
+        integrate).  Returns False when the ABI's limit is reached."""
+        cur = int(self.params.max_rk_steps) or 64
+        if cur >= limit:
+            return False
+        self.params.max_rk_steps = min(limit, 2 * cur)
+        self._ck(self.L.tcr_params_set(self.h, C.byref(self.params)))
+        return True
+
     def close(self):
         if getattr(self, 'h', None):
             self.L.tcr_ctx_destroy(self.h)

@@ -134,11 +134,13 @@ class DevicePipeline:
         self.eng._ck(fn(self.eng.h, C.byref(si), C.byref(so), C.c_void_p(self._stream())))
         self.n_done = n
 
-    def add_stats(self, counters):
-        """counters (uint64/int64 tensor [6]) += storm-steps, RHS evaluations, samples, accepted, is_tc storms,
-        samples of is_tc storms."""
+    def add_stats(self, counters, n_dev=None):
+        """counters (uint64/int64 tensor [7]) += storm-steps, RHS evaluations, samples, accepted, is_tc storms,
+        samples of is_tc storms, 1 if the batch was short of storms (n_dev < n).  n_dev: device int64 scalar, default
+        the one integrate() was given."""
+        assert counters.numel() >= 7
         so = self._tracks_struct()
-        nd = getattr(self, '_n_dev', None)
+        nd = n_dev if n_dev is not None else getattr(self, '_n_dev', None)
         self.eng._ck(self.eng.L.tcr_stats_dev(self.eng.h, self.n_done, nd.data_ptr() if nd is not None else None,
                                               C.byref(so), counters.data_ptr(), C.c_void_p(self._stream())))
 
