@@ -8,8 +8,17 @@ One *step* = one pass of the hot path over one batch on every rank: device-side
 seeding of a round of candidates (compute.py:134-175), order-preserving selection
 of the first B that pass, the fused DP5(4) integration with env-wind recompute,
 vmax and accept flags (compute.py:176-209), and — for N > 1 — the RCCL all-gather
-of the accepted tracks of that batch.  Per-GPU work is fixed (B storms per rank),
-so scaling is weak; `value` is storm-steps of all ranks / wall time of the K steps.
+of the accepted tracks of that batch.  `value` is storm-steps of all ranks / wall
+time of the K steps.
+
+--scaling weak (default): per-GPU work is fixed — B storms per rank and step.
+--scaling strong (BASELINE config 4 as worded: "100k storms sharded across 8 GPUs"):
+the ENSEMBLE is fixed — one step = one ensemble drawn from a fixed block of candidates
+(sized so that ~B seeds pass), the candidate block sharded over the ranks as
+`compute.run_tracks` shards a round; every rank integrates all the passing seeds of
+its sub-block, and the accepted tracks of the ensemble are all-gathered once.  The set
+of storms of an ensemble does not depend on the number of ranks, so the storm-step
+total of a run is bit-for-bit the same at every N (tests/test_seeding.py checks 1 vs 2).
 
 A storm-step is one hourly output interval of one live storm.
 Inputs (fields) are resident in HBM before the timed region; candidates are drawn
@@ -36,7 +45,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=4)
-    ap.add_argument('--storms', type=int, default=100_000, help='storms integrated per GPU per step')
+    ap.add_argument('--storms', type=int, default=100_000, help='weak: storms integrated per GPU per step; strong: storms per '
+                                                                'ensemble (= per step), sharded over the GPUs')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--basin', default='GL')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sort', action='store_true', help='locality-sort the dense batch (see pipeline.py)')
@@ -83,15 +94,24 @@ def main():
     torch.cuda.synchronize()
     p_pass = float(((probe.cand['seed_flags'] & 2) != 0).double().mean().item())
     del probe
-    C = int(B / max(p_pass, 1e-3) * 1.15) + 4096
+    strong = args.scaling == 'strong'
+    if strong:
+        # one ensemble = the passing seeds of a fixed block of C_ens candidates (expected: args.storms of them); rank r owns
+        # the r-th of `world` equal sub-blocks and integrates every passing seed in it (n_dev = the device-side count)
+        C_ens = -(-int(round(args.storms / max(p_pass, 1e-3))) // 8) * 8        # the same block at 1, 2, 4 and 8 ranks
+        C = -(-C_ens // world)                                                  # candidates per rank and ensemble
+        C_ens = C * world
+        B = int(args.storms / world * 1.25) + 2048                             # capacity: 25 % + 2048 over the expected count
+    else:
+        C = int(B / max(p_pass, 1e-3) * 1.15) + 4096
     pipes = [DevicePipeline(e, C, B, sort_storms=args.sort, tc_rows_only=(args.rows == 'tc'), dtype=args.dtype) for e in engs]
     global BYTES_PER_RHS, BYTES_PER_SAMPLE
     if args.dtype == 'f32':
         BYTES_PER_RHS, BYTES_PER_SAMPLE = 352.0, 260.0          # SURVEY.md §8d, fp32 mode
     pipe = pipes[0]
 
-    # storm-steps, nfev, samples, accepted, is_tc, is_tc samples, rounds with < B passing seeds (tcr_stats_dev)
-    acc = torch.zeros(7, dtype=torch.int64, device=dev)
+    # storm-steps, nfev, samples, accepted, is_tc, is_tc samples, rounds with < B passing seeds, storms (tcr_stats_dev)
+    acc = torch.zeros(8, dtype=torch.int64, device=dev)
     row = 9 * ns
     # N > 1: all-gather of every batch's final (accepted) tracks through distributed.DeferredRowGather:
     # nothing in a step waits on the host — batch k's count is read back only when batch k + n_str is
@@ -105,9 +125,9 @@ def main():
 
     def _step(k, pipe):
         # warm-up steps run exactly the same code; the accumulators are zeroed after them
-        pipe.seed_round(year, D.round_block(k, C, rank, world))
+        pipe.seed_round(year, D.round_block(k, C, rank, world))        # = k * C * world + rank * C
         pipe.select_passed(B)
-        pipe.integrate(B)
+        pipe.integrate(B, n_dev=pipe.n_passed if strong else None)
         pipe.add_stats(acc, n_dev=pipe.n_passed)
         if gather is not None:
             buf = gather.buffer()                # waits (on this stream) for the gather that last read it
@@ -169,9 +189,15 @@ def main():
         iso_passes = engs[0].pass_stats()
     if world > 1:
         D.allreduce_sum_(acc)
-    steps_total, nfev_total, samples_total, accepted_total, tc_total, tc_samples_total, n_short = (float(x) for x in acc.tolist())
+    steps_total, nfev_total, samples_total, accepted_total, tc_total, tc_samples_total, n_short, storms_total = (float(x) for x in acc.tolist())
     emitted_total = tc_samples_total if args.rows == 'tc' else samples_total     # samples k_emit actually produced
     n_short = int(n_short)
+    if strong:
+        # every passing seed of every sub-block must have fitted its rank's capacity (else storms were dropped)
+        over = torch.tensor([max(int(p.n_passed.item()) for p in pipes) > B], dtype=torch.int64, device=dev)
+        if world > 1:
+            D.allreduce_sum_(over)
+        assert int(over.item()) == 0, 'strong scaling: a rank had more passing seeds than its capacity'
     value = steps_total / dt
 
     # ---- roofline of the dominant kernel (k_integrate): algorithmic bytes per launch
@@ -235,20 +261,25 @@ def main():
         out = {
             'metric': 'storm-steps/sec (100k-storm ensemble)', 'value': value, 'unit': 'storm-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'gpu_active_s': gpu_active_s,
-            'config': {'workload': '%s basin, %d storms per GPU per step, synthetic ERA5-shaped monthly fields '
+            'config': {'workload': '%s basin, %s, synthetic ERA5-shaped monthly fields '
                                    '(1 deg thermo/wind, 0.25 deg land/bathymetry), 15-day tracks, hourly output, '
-                                   'device-side seeding, %s; %s' % (args.basin, B, 'fp64' if args.dtype == 'f64' else 'fp32 fields/state/RHS/rows with fp64 time and step controller', (
+                                   'device-side seeding, %s; %s' % (args.basin, (
+                                       'one ensemble of %d candidates (%.0f storms pass on average) per step, sharded over %d GPU(s), '
+                                       'accepted tracks all-gathered once per ensemble' % (C_ens, storms_total / args.steps, world)) if strong
+                                       else '%d storms per GPU per step' % B, 'fp64' if args.dtype == 'f64' else 'fp32 fields/state/RHS/rows with fp64 time and step controller', (
                                        'env winds, vmax and rows only for storms that pass accept test 1, as the reference '
                                        'does (compute.py:190-204)' if args.rows == 'tc' else 'rows for every integrated storm')),
-                       'rows': args.rows, 'is_tc_fraction': tc_total / (B * args.steps * world),
+                       'rows': args.rows, 'is_tc_fraction': tc_total / storms_total,
+                       'storms_per_step': storms_total / args.steps, 'storm_steps_total': int(steps_total),
                        'emitted_samples_per_step': emitted_total / (args.steps * world),
-                       'storms_per_gpu': B, 'candidates_per_round': C, 'seed_pass_rate': p_pass,
-                       'n_steps_out': ns, 'rounds_short_of_storms': n_short, 'streams': n_str, 'warmup_effective': w_eff,
-                       'storm_steps_per_storm': steps_total / (B * args.steps * world),
+                       'storms_per_gpu': storms_total / (args.steps * world), 'candidates_per_round': C, 'seed_pass_rate': p_pass,
+                       'n_steps_out': ns, 'rounds_short_of_storms': None if strong else n_short, 'streams': n_str,
+                       'warmup_effective': w_eff,
+                       'storm_steps_per_storm': steps_total / storms_total,
                        'rhs_per_storm_step': nfev_total / max(steps_total, 1),
-                       'accepted_fraction': accepted_total / (B * args.steps * world),
+                       'accepted_fraction': accepted_total / storms_total, 'accepted_total': int(accepted_total),
                        'allgather_rows': gather.rows_gathered if gather is not None else None,
                        'allgather_rows_clipped': gather.rows_clipped if gather is not None else None},
             'roofline': roof,
@@ -302,10 +333,15 @@ def cpu_baseline(pipe, args, B):
                     'sample': 'failed: %r' % (e,)}
     best = res.get('all_cores', res['one_core'])
     return {'value': best['value'], 'unit': 'storm-steps/s', 'cores': best.get('procs', 1), 'kind': 'port',
-            'sample': 'oracle/scipy_port.py (solve_ivp RK45 + RectBivariateSpline.ev + numpy cholesky, integration + '
-                      'env-wind recompute + vmax) on the first %d storms of the last GPU batch, %d worker '
+            'sample': 'oracle/scipy_port.py (solve_ivp RK45 + RectBivariateSpline.ev + numpy cholesky; integration + accept '
+                      'tests + env-wind recompute and vmax for the candidates that pass accept test 1, as compute.py:176-209 '
+                      'and the GPU step do) on the first %d storms of the last GPU batch, %d worker '
                       'processes, %.1f s' % (best['storms'], best.get('procs', 1), best['seconds']),
-            'value_1core': res['one_core']['value'], 'storms_1core': res['one_core']['storms'],
+            'value_1core': res['one_core']['value'], 'storms_1core': res['one_core']['storms'], 'seconds_1core': res['one_core']['seconds'],
+            'integration_only': {'value': (res.get('all_cores_integration_only') or res['one_core_integration_only'])['value'],
+                                 'storms': (res.get('all_cores_integration_only') or res['one_core_integration_only'])['storms'],
+                                 'value_1core': res['one_core_integration_only']['value'],
+                                 'storms_1core': res['one_core_integration_only']['storms']},
             'per_core_efficiency': best.get('per_core_efficiency'), 'cgroup_cpu_quota': best.get('cgroup_cpu_quota'),
             'physical_cores_visible': best.get('physical_cores_visible'),
             'c_port_1core': res.get('c_port_one_core')}

@@ -226,7 +226,8 @@ int tcr_gather_seeds_dev(tcr_ctx *ctx, const tcr_seeds *src_dev, const int32_t *
  * (sum of max(n_valid-1, 0)), [1] = RHS evaluations, [2] = output samples, [3] = accepted tracks,
  * [4] = storms that passed accept test 1 (is_tc), [5] = output samples of those storms (the rows
  * tc_rows_only produces), [6] = 1 if *n_dev < n (the batch was short of storms: a round control signal that
- * needs no host round trip); the SEVEN uint64 counters are ADDED to (zero them first). */
+ * needs no host round trip), [7] = storms counted (min(n, *n_dev)); the EIGHT uint64 counters are ADDED to
+ * (zero them first). */
 int tcr_stats_dev(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const tcr_tracks *tracks_dev, uint64_t *out_dev, void *stream);
 /* survivor records for the all-gather of final tracks (compute.py:233-242 concatenation):
  * packed[r] = { lon[ns], lat[ns], v[ns], m[ns], vmax[ns], envw[ns][4] } of track idx[r],

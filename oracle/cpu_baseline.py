@@ -32,10 +32,17 @@ _BASIN = None
 _STORMS = None
 
 
-def _work(idx):
+def _work(idx, post='tc'):
+    """post='tc': integration + accept tests + env-wind recompute / vmax for the candidates that pass accept test 1 —
+    what the reference's loop does per candidate (compute.py:176-209) and what the GPU step does; post=False:
+    integration only (gen_track)."""
     from oracle import scipy_port as P
-    o = P.run_ensemble(_ENV, _BASIN, _STORMS, index=idx)
+    o = P.run_ensemble(_ENV, _BASIN, _STORMS, index=idx, post=post)
     return int(np.clip(o['n_valid'] - 1, 0, None).sum()), int(o['nfev'].sum()), len(idx)
+
+
+def _work_int_only(idx):
+    return _work(idx, post=False)
 
 
 def cgroup_cpu_quota():
@@ -98,22 +105,34 @@ def main():
     n_avail = len(_STORMS['lon'])
     procs = a.procs or usable_cores()
 
-    # calibrate on a handful of storms, then size both legs to the time budget
-    t0 = time.perf_counter(); s0, _, _ = _work(list(range(min(8, n_avail)))); per = (time.perf_counter() - t0) / min(8, n_avail)
+    # warm up (imports, SciPy's first calls, the month caches), THEN calibrate the per-storm cost on 24 storms and size
+    # every leg to the time budget (round 2 calibrated on the first call and ran 2 s of a 12 s budget)
+    _work(list(range(min(4, n_avail))))
+    nc = min(24, n_avail)
+    t0 = time.perf_counter(); _work(list(range(nc))); per = (time.perf_counter() - t0) / nc
     n1 = int(max(8, min(n_avail, a.budget / per)))
     t0 = time.perf_counter(); steps1, nfev1, _ = _work(list(range(n1))); dt1 = time.perf_counter() - t0
-    out = dict(one_core=dict(storm_steps=steps1, seconds=dt1, storms=n1, value=steps1 / dt1, nfev=nfev1))
+    out = dict(one_core=dict(storm_steps=steps1, seconds=dt1, storms=n1, value=steps1 / dt1, nfev=nfev1,
+                             what='integration + accept tests + env winds / vmax of the candidates that pass accept test 1 (compute.py:176-209)'))
+    ni = int(max(8, min(n_avail, 0.35 * a.budget / per)))
+    t0 = time.perf_counter(); stepsi, _, _ = _work(list(range(ni)), post=False); dti = time.perf_counter() - t0
+    out['one_core_integration_only'] = dict(storm_steps=stepsi, seconds=dti, storms=ni, value=stepsi / dti)
     if procs > 1:
-        nP = int(max(procs, min(n_avail, 0.6 * procs * a.budget / per)))     # all cores busy: lower per-core clock
+        nP = int(max(procs, min(n_avail, 0.7 * procs * a.budget / per)))     # all cores busy: lower per-core clock
         chunks = [list(range(i, nP, procs)) for i in range(procs)]
         ctx = mp.get_context('fork')
         with ctx.Pool(procs) as pool:
-            pool.map(_work, [[0]] * procs)                  # warm the workers (imports, caches)
+            pool.map(_work, [[0, 1]] * procs)               # warm the workers (imports, caches)
             t0 = time.perf_counter(); res = pool.map(_work, chunks); dtP = time.perf_counter() - t0
+            nPi = max(procs, nP // 3)
+            chunks_i = [list(range(i, nPi, procs)) for i in range(procs)]
+            t0 = time.perf_counter(); res_i = pool.map(_work_int_only, chunks_i); dtPi = time.perf_counter() - t0
         stepsP = sum(r[0] for r in res)
         out['all_cores'] = dict(storm_steps=stepsP, seconds=dtP, storms=nP, value=stepsP / dtP, procs=procs,
                                 physical_cores_visible=physical_cores(), cgroup_cpu_quota=cgroup_cpu_quota(),
                                 per_core_efficiency=(stepsP / dtP) / (procs * steps1 / dt1))
+        stepsPi = sum(r[0] for r in res_i)
+        out['all_cores_integration_only'] = dict(storm_steps=stepsPi, seconds=dtPi, storms=nPi, value=stepsPi / dtPi, procs=procs)
     # the plain-C restatement (oracle/tc_oracle.c) on one core, for scale: same algorithm without the
     # interpreter / SciPy call overhead that dominates the reference's own CPU path
     try:

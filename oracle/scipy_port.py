@@ -287,8 +287,9 @@ def max_wind(lon, lat, dt, v, envw):
     return np.sqrt(np.power(ug, 2) + np.power(vg, 2))
 
 
-def post_storm(prm, res):
-    """util/compute.py:178-209 for one candidate."""
+def post_storm(prm, res, tc_only=False):
+    """util/compute.py:178-209 for one candidate.  tc_only: env winds and vmax only `if is_tc:`, as the reference
+    computes them (compute.py:190-204); the default computes them for every candidate (what the parity tests compare)."""
     n = res['n']
     out = dict(is_tc=False, accepted=False, envw=np.zeros((n, 4)), vmax=np.full(n, np.nan))
     if res['status'] < 0:
@@ -297,6 +298,8 @@ def post_storm(prm, res):
     lon, lat, v = res['y'][0], res['y'][1], res['y'][2]
     v2d = np.interp(2 * 86400, res['t'], v)
     out['is_tc'] = bool(np.any(v >= prm.v_thresh) and v2d >= prm.v_2d_thresh)
+    if tc_only and not out['is_tc']:
+        return out
     t_s = prm.t_s
     for i in range(n):
         out['envw'][i] = st.env_winds(lon[i], lat[i], t_s[i])
@@ -332,8 +335,8 @@ def run_ensemble(env, basin, storms, prm=None, post=True, index=None):
             n = r['n']
             out['status'][k] = r['status']; out['n_valid'][k] = n; out['nfev'][k] = r['nfev']
             out['traj'][k, :, :n] = r['y']
-            if post:
-                p = post_storm(prm, r)
+            if post:                 # True: every candidate; 'tc': only candidates that pass accept test 1 (the reference)
+                p = post_storm(prm, r, tc_only=(post == 'tc'))
                 out['envw'][k, :n] = p['envw']; out['vmax'][k, :n] = p['vmax'][:n] if n else []
                 out['is_tc'][k] = p['is_tc']; out['accepted'][k] = p['accepted']
     return out

@@ -287,27 +287,43 @@ def test_run_tracks_fp32_knob(golden_env, built_lib):
 def test_bench_multi_rank_path(built_lib, tmp_path):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU) — here two ranks
     sharing this GPU with gloo as the collective backend: the step includes select / pack of the accepted tracks
-    and the deferred all-gather of survivor records; the JSON line carries the whole-job aggregate."""
+    and the deferred all-gather of survivor records; the JSON line carries the whole-job aggregate.
+    Both scaling modes: weak (B storms per rank and step) and strong (BASELINE config 4 as worded: one ensemble per step,
+    its candidate block sharded over the ranks, accepted tracks gathered once per ensemble) — in strong mode the set of
+    storms of an ensemble does not depend on the rank count, so the integer totals of a run must be identical at
+    world 1 and world 2."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TCR_DIST_BACKEND='gloo')
     out = {}
-    for world in (1, 2):
-        cmd = [sys.executable] + (['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr',
-                                   '127.0.0.1', '--master-port', '29531'] if world > 1 else []) + \
-              [os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', '4', '--warmup', '1', '--storms', '6000',
-               '--streams', '2', '--no-cpu-baseline']
-        r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-2000:]
-        out[world] = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
-    one, two = out[1], out[2]
+    for mode, storms in (('weak', 6000), ('strong', 12000)):
+        for world in (1, 2):
+            cmd = [sys.executable] + (['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr',
+                                       '127.0.0.1', '--master-port', '29531'] if world > 1 else []) + \
+                  [os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', '4', '--warmup', '1', '--storms', str(storms),
+                   '--streams', '2', '--no-cpu-baseline', '--scaling', mode]
+            r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stderr[-2000:]
+            out[mode, world] = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    one, two = out['weak', 1], out['weak', 2]
     assert two['n_gpus'] == 2 and two['scaling'] == 'weak' and two['value'] > 0 and two['steps'] == 4
     cfg = two['config']
     # the same per-rank work: two ranks integrate twice the storms of one
+    assert cfg['storms_per_step'] == 2 * one['config']['storms_per_step'] == 12000
     assert abs(cfg['storm_steps_per_storm'] - one['config']['storm_steps_per_storm']) / one['config']['storm_steps_per_storm'] < 0.05
     assert cfg['allgather_rows'] > 0 and cfg['allgather_rows_clipped'] == 0
     # every accepted track of both ranks went through the all-gather
-    assert cfg['allgather_rows'] == round(cfg['accepted_fraction'] * 6000 * 4 * 2)
+    assert cfg['allgather_rows'] == cfg['accepted_total'] == round(cfg['accepted_fraction'] * 6000 * 4 * 2)
     assert two['roofline']['frac'] > 0 and two['cpu_baseline'] is None and one['config']['allgather_rows'] is None
+    # ---- strong scaling: the ensemble is fixed, the ranks share it
+    s1, s2 = out['strong', 1], out['strong', 2]
+    assert s1['scaling'] == s2['scaling'] == 'strong' and s2['n_gpus'] == 2
+    c1, c2 = s1['config'], s2['config']
+    assert 'sharded over 2 GPU' in c2['workload'] and 'once per ensemble' in c2['workload']
+    assert abs(c1['storms_per_step'] - 12000) < 400                       # ~12 000 seeds of the candidate block pass
+    for k in ('storms_per_step', 'storm_steps_total', 'accepted_total', 'emitted_samples_per_step', 'is_tc_fraction'):
+        assert c1[k] == c2[k], (k, c1[k], c2[k])                          # the same storms, whoever integrates them
+    assert abs(c2['storms_per_gpu'] * 2 - c2['storms_per_step']) < 1e-9
+    assert c2['allgather_rows'] == c2['accepted_total'] and c2['allgather_rows_clipped'] == 0 and c1['allgather_rows'] is None

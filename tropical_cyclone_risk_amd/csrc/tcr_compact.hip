@@ -142,7 +142,10 @@ __global__ __launch_bounds__(256) void k_stats(int64_t n, const int64_t *__restr
 {
     const bool is_short = n_dev && *n_dev < n;         // the batch holds fewer storms than it was sized for
     if (is_short) n = *n_dev;
-    if (is_short && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(out + 6, 1ull);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (is_short) atomicAdd(out + 6, 1ull);
+        atomicAdd(out + 7, (unsigned long long)(n > 0 ? n : 0));
+    }
     __shared__ unsigned long long s[4][6];
     unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {

@@ -135,10 +135,10 @@ class DevicePipeline:
         self.n_done = n
 
     def add_stats(self, counters, n_dev=None):
-        """counters (uint64/int64 tensor [7]) += storm-steps, RHS evaluations, samples, accepted, is_tc storms,
-        samples of is_tc storms, 1 if the batch was short of storms (n_dev < n).  n_dev: device int64 scalar, default
-        the one integrate() was given."""
-        assert counters.numel() >= 7
+        """counters (uint64/int64 tensor [8]) += storm-steps, RHS evaluations, samples, accepted, is_tc storms,
+        samples of is_tc storms, 1 if the batch was short of storms (n_dev < n), storms counted.  n_dev: device int64
+        scalar, default the one integrate() was given."""
+        assert counters.numel() >= 8
         so = self._tracks_struct()
         nd = n_dev if n_dev is not None else getattr(self, '_n_dev', None)
         self.eng._ck(self.eng.L.tcr_stats_dev(self.eng.h, self.n_done, nd.data_ptr() if nd is not None else None,
