@@ -51,9 +51,10 @@ def main():
     ap.add_argument('--basin', default='GL')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sort', action='store_true', help='locality-sort the dense batch (see pipeline.py)')
-    ap.add_argument('--streams', type=int, default=4,
+    ap.add_argument('--streams', type=int, default=None,
                     help='HIP streams the steps are round-robined over (each with its own context and buffers): '
-                         'the low-occupancy tail of one batch overlaps the next batch')
+                         'the low-occupancy tail of one batch overlaps the next batch.  Default 4; 16 for the small '
+                         'per-rank batches of --scaling strong at N > 1 (with as many hardware queues, see below)')
     ap.add_argument('--cpu-budget', type=float, default=12.0)
     ap.add_argument('--traffic', type=float, default=None,
                     help='HBM bytes per integrate launch from a separate rocprofv3 --pmc pass (see profiles/)')
@@ -63,6 +64,16 @@ def main():
                     help="tc: env winds / vmax / rows only for storms that pass accept test 1, as the reference does "
                          "(compute.py:190-204); all: rows for every integrated storm (round 1's workload)")
     args = ap.parse_args()
+    # A batch is latency-bound by its longest storm (~300 sequential evaluations, ~2 ms), so throughput comes from batches
+    # in flight.  ROCm multiplexes a process's streams onto GPU_MAX_HW_QUEUES = 4 hardware queues by default; the small
+    # per-rank batches of a sharded ensemble need more of them in flight than that (measured on one MI355X, 12 500 storms
+    # per batch: 0.57 ms per step with 4 streams / 4 queues at any stream count, 0.44 with 8 / 8, 0.38 with 16 / 16;
+    # at 100 000 storms per batch the setting makes no difference, so the default stays at ROCm's).  Must be set before
+    # the HIP runtime starts.
+    if args.streams is None:
+        args.streams = 16 if (args.scaling == 'strong' and int(os.environ.get('WORLD_SIZE', '1')) > 1) else 4
+    if args.streams > 4:
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', str(min(args.streams, 16)))
 
     import numpy as np
     import torch
@@ -276,6 +287,7 @@ def main():
                        'emitted_samples_per_step': emitted_total / (args.steps * world),
                        'storms_per_gpu': storms_total / (args.steps * world), 'candidates_per_round': C, 'seed_pass_rate': p_pass,
                        'n_steps_out': ns, 'rounds_short_of_storms': None if strong else n_short, 'streams': n_str,
+                       'hw_queues': int(os.environ.get('GPU_MAX_HW_QUEUES', '4')),
                        'warmup_effective': w_eff,
                        'storm_steps_per_storm': steps_total / storms_total,
                        'rhs_per_storm_step': nfev_total / max(steps_total, 1),

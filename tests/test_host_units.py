@@ -264,6 +264,39 @@ def test_hdf5lite_reads_the_reference_land_mask():
     assert ds['land'].shape == (1440, 2880) and float(ds['lat'][0]) == -89.875
 
 
+REF_DATA = '/root/reference/intensity/data'
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DATA + '/mld_climatology.nc'),
+                    reason='needs the reference data files (build container only; they never travel to the GPU box)')
+def test_ocean_climatologies_through_hdf5lite_match_the_reference_code():
+    """intensity/ocean.py:11-64 + util/compute.py:117-118 on the reference's own mld / strat climatology files
+    (NetCDF-4: HDF5 with shuffle + deflate), read through hdf5lite and regridded by fields._climatology, against
+    tests/golden/clim_ref.npz — what the reference's `mld_climatology`, `strat_climatology` and `mat.interp_2d_grid` lines
+    returned for months 1 and 7 (tests/golden/make_golden_clim.py)."""
+    from tropical_cyclone_risk_amd import fields, hdf5lite
+    g = np.load(os.path.join(GOLDEN, 'clim_ref.npz'))
+    for name, var, fn in (('mld', 'mixed_layer', 'mld_climatology.nc'), ('strat', 'strat', 'strat_climatology.nc')):
+        f = hdf5lite.File(os.path.join(REF_DATA, fn))
+        X = np.asarray(f[var])
+        lon, lat = np.asarray(f['lon']), np.asarray(f['lat'])
+        assert X.shape == (180, 361, 12) and X.dtype == np.float32 and lon[0] == 0.0 and lon[-1] == 360.0
+        # the decoding, by the file's own redundancy: its last longitude column (360 E) repeats the first (0 E)
+        assert np.array_equal(X[:, 360, :], X[:, 0, :], equal_nan=True)
+        assert abs(np.isnan(X).mean() - 0.2924) < 1e-3 and (name != 'mld' or np.nanmin(X) >= 0)      # land is NaN; depths are not negative
+        got = fields._climatology(os.path.join(REF_DATA, fn), var, g['lon'], g['lat'])
+        assert got.shape == (12, 73, 144) and not np.isnan(got).any()                    # NaN -> 0 before regridding (compute.py:117)
+        for mo in (1, 7):
+            assert np.array_equal(got[mo - 1], g['%s_%d' % (name, mo)]), (name, mo)      # bit for bit
+        # the wrap column: the source axis the reference regrids from stops at 359 E (ocean.py:26 drops lon[-1]), so the
+        # target column 357.5 E interpolates between 357 and 358, and 0 E is the file's first column itself
+        assert np.array_equal(g[name + '_src_lon'], np.arange(360.0))
+        j = 36                                                                            # the equator row of the 2.5-degree target
+        src_eq = np.nan_to_num(X[:, :, 0].astype(np.float64))
+        assert got[0][j, 0] == pytest.approx(0.5 * (src_eq[89, 0] + src_eq[90, 0]), rel=1e-12)
+        assert (got[0] == 0).mean() > 0.2                                                 # land (and ice) came through as 0, not NaN
+
+
 def test_hdf5lite_rejects_garbage(tmp_path):
     from tropical_cyclone_risk_amd import fields, hdf5lite
     fn = tmp_path / 'x.nc'

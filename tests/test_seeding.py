@@ -323,7 +323,8 @@ def test_bench_multi_rank_path(built_lib, tmp_path):
     c1, c2 = s1['config'], s2['config']
     assert 'sharded over 2 GPU' in c2['workload'] and 'once per ensemble' in c2['workload']
     assert abs(c1['storms_per_step'] - 12000) < 400                       # ~12 000 seeds of the candidate block pass
-    for k in ('storms_per_step', 'storm_steps_total', 'accepted_total', 'emitted_samples_per_step', 'is_tc_fraction'):
+    for k in ('storms_per_step', 'storm_steps_total', 'accepted_total', 'is_tc_fraction'):
         assert c1[k] == c2[k], (k, c1[k], c2[k])                          # the same storms, whoever integrates them
+    assert c1['emitted_samples_per_step'] == 2 * c2['emitted_samples_per_step']      # (a per-GPU figure)
     assert abs(c2['storms_per_gpu'] * 2 - c2['storms_per_step']) < 1e-9
     assert c2['allgather_rows'] == c2['accepted_total'] and c2['allgather_rows_clipped'] == 0 and c1['allgather_rows'] is None
