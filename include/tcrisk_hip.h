@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TCR_ABI_VERSION 3
+#define TCR_ABI_VERSION 4
 #define TCR_NW 4            /* ua250, va250, ua850, va850  (track/env_wind.py:22-26) */
 #define TCR_NCOV 10         /* packed lower triangle (0,0),(1,0),(1,1),(2,0)..(3,3) (env_wind.py:31-42) */
 #define TCR_MAX_SERIES 32
@@ -276,6 +276,17 @@ int tcr_potential_intensity_dev(tcr_ctx *ctx, int64_t n_points, int32_t n_lev, c
  * mid level p_mid (Pa), as thermo/calc_thermo.py:66-74 calls them. */
 int tcr_chi_rh_host(tcr_ctx *ctx, int64_t n_points, const double *sst, const double *psl, const double *T_mid,
                     const double *q_mid, double p_mid, double *chi, double *rh_mid);
+
+/* ---- gen_track(clon, clat, v, m=None) ---------------------------------------- */
+/* replaces: Coupled_FAST._init_m(y, dvdt) (intensity/coupled_fast.py:153-173), which gen_track calls with dvdt = 0
+ * when it is given no m (coupled_fast.py:258-261): the inner-core moisture that makes dv/dt equal `dvdt` at t = 0,
+ * with the potential intensity taken as the maximum over the point and the four points 0.25 degrees diagonally off
+ * it.  m_out[i] = storms->m0[i] where that is a number (or storms->m0 is not NULL and not NaN), else _init_m's value
+ * (storms->m0 may be NULL: every storm is initialised).  run_tracks always passes m (compute.py:173-176), so the
+ * integrate entry points require m0; a caller that wants the reference's m=None behaviour calls this first and hands
+ * m_out to tcr_integrate_* as m0.  Uses lon0, lat0, v0, h_bl, slot and phases (the env winds at t = 0). */
+int tcr_init_m_dev(tcr_ctx *ctx, const tcr_storms *storms_dev, double dvdt, double *m_out_dev, void *stream);
+int tcr_init_m_host(tcr_ctx *ctx, const tcr_storms *storms_host, double dvdt, double *m_out_host);
 
 /* ---- single-point probes (parity tests of the seam's leaf methods) -------- */
 /* replaces: Coupled_FAST.dydt (coupled_fast.py:196-207), ._env_winds

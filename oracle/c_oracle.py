@@ -141,6 +141,17 @@ def rhs_points(cme, Fs, h_bl, t, lon, lat, v, m, prm=None):
     return dydt, envw, alpha
 
 
+def init_m(cme, Fs, h_bl, lon, lat, v, dvdt=0.0, prm=None):
+    """Coupled_FAST._init_m at points of one month environment with one forcing table Fs [4, n_steps]."""
+    p = c_params(prm)
+    Fs = np.ascontiguousarray(Fs, dtype=np.float64)
+    f = lib().orc_init_m
+    f.restype = C.c_double
+    f.argtypes = [C.c_void_p, C.c_void_p, _DP, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]
+    return np.array([f(C.addressof(cme.c), C.addressof(p), _dp(Fs), float(h_bl), float(a), float(b), float(c), float(dvdt))
+                     for a, b, c in zip(lon, lat, v)])
+
+
 def bilinear(cme, which, plane_name, lon, lat):
     g = {'w': cme.c.wg, 't': cme.c.tg, 'h': cme.c.hg if plane_name != 'bathy' else cme.c.bg}[which]
     plane = getattr(cme.c, plane_name)

@@ -351,6 +351,39 @@ void orc_rhs(orc_storm *s, double t, const double *y, double *dy, double *w_out)
     if (w_out) memcpy(w_out, w, sizeof w);
 }
 
+/* Coupled_FAST._init_m(y, dvdt) (coupled_fast.py:153-173): the m gen_track(m=None) starts from (:258-261) */
+double orc_init_m(const orc_env *e, const orc_params *p, const double *Fs, double h_bl,
+                  double lon, double lat, double v, double dvdt)
+{
+    orc_storm s = { e, p, Fs, h_bl, 0, 0, NULL, NULL, 0, 0.0, NULL, 0, 0, 0 };
+    double c[2], vb[2], w[NW];
+    steering(p, v, c);
+    if (fabs(lat) >= 80) { vb[0] = vb[1] = 0.0; }
+    else {
+        orc_env_winds(e, p, Fs, lon, lat, 0.0, w);
+        double cl = cos(lat * (PI_ / 180.0));
+        vb[0] = (w[0] * c[0] + w[2] * c[1]) + p->u_beta * cl;
+        vb[1] = (w[1] * c[0] + w[3] * c[1]) + (sgn(lat) * p->v_beta) * cl;
+    }
+    const double dx[5] = { 0, -0.25, -0.25, 0.25, 0.25 }, dy[5] = { 0, -0.25, 0.25, -0.25, 0.25 };
+    double vp = 0;
+    for (int k = 0; k < 5; k++) {                       /* np.max: NaN propagates */
+        double x = lon + dx[k], y = lat + dy[k];
+        double c5 = vpot_given(e, over_land(&s, 0, x, y, 0), x, y);
+        if (k == 0) vp = c5;
+        else vp = (vp != vp) ? vp : ((c5 != c5) ? c5 : (c5 > vp ? c5 : vp));
+    }
+    double al = ocean_alpha(&s, over_land(&s, 0, lon, lat, 0), lon, lat, vb, v);
+    double gamma = p->epsilon + al * p->kappa;
+    double beta = 1 - p->epsilon - p->kappa;
+    double numer = 2 * h_bl / p->Ck * dvdt + pow(v, 2.0);
+    double denom = al * beta * pow(vp, 2.0) + gamma * pow(v, 2.0);
+    double m = cbrt(numer / denom);
+    m = (m != m) ? m : (m < 1 ? m : 1.0);
+    m = (m != m) ? m : (m > 0 ? m : 0.0);
+    return m;
+}
+
 /* standalone entry points for RHS-level parity tests */
 void orc_rhs_points(const orc_env *e, const orc_params *p, const double *Fs, double h_bl, int n,
                     const double *t, const double *lon, const double *lat, const double *v,

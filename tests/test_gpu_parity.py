@@ -111,6 +111,37 @@ def test_ensemble_vs_c_oracle(engines, golden_env, basin, n, seed):
         assert np.array_equal(plain[k], got[k]), k
 
 
+def test_init_m_vs_reference(engines, golden_env):
+    """gen_track(clon, clat, v, m=None) (coupled_fast.py:258-261): k_init_m against the reference's own `_init_m`
+    (coupled_fast.py:153-173) at 240 points for dvdt = 0 and dvdt != 0, and twelve whole reference tracks started
+    without m — `TCEngine.integrate` fills a missing / NaN m0 through tcr_init_m_host first."""
+    from oracle import c_oracle, parity
+    g = np.load(os.path.join(GOLDEN, 'init_m_NA.npz'))
+    eng = engines('NA')
+    n = len(g['lon'])
+    st = dict(lon=g['lon'], lat=g['lat'], v0=g['v'], h_bl=np.full(n, float(g['h_bl'])), month=np.full(n, int(g['month'])), phases=g['phases'])
+    for key, dvdt in (('m_dvdt0', 0.0), ('m_dvdt2em5', float(g['dvdt1']))):
+        got = eng.init_m(st, dvdt)
+        assert np.abs(got - g[key]).max() <= 1e-13, (key, np.abs(got - g[key]).max())
+        assert np.array_equal(got == 1, g[key] == 1) and np.array_equal(got == 0, g[key] == 0)      # the clips land on the same points
+    # a given m0 is kept; NaN entries are initialised
+    m_in = np.where(np.arange(n) % 2 == 0, 0.37, np.nan)
+    got = eng.init_m(dict(st, m0=m_in))
+    assert (got[::2] == 0.37).all() and np.abs(got[1::2] - g['m_dvdt0'][1::2]).max() <= 1e-13
+    # whole tracks without m
+    storms = dict(lon=g['t_lon0'], lat=g['t_lat0'], v0=g['t_v0'], h_bl=g['t_h_bl'], month=g['t_month'], phases=g['t_phases'])
+    want = dict(traj=g['t_traj'], status=g['t_status'], n_valid=g['t_n_valid'], nfev=g['t_nfev'], accepted=np.zeros(12, bool))
+    out = eng.integrate(storms, probe_cap=PROBE_CAP)
+    alive = want['n_valid'] > 0
+    assert np.abs(out['m'][alive, 0] - want['traj'][alive, 3, 0]).max() <= 1e-13
+    dec_w = parity.ragged_to_padded(g['t_dec'], g['t_dec_off'], PROBE_CAP)
+    t0_w = parity.ragged_to_padded(g['t_dec_t0'], g['t_dec_off'], PROBE_CAP, fill=np.nan, dtype=np.float64)
+    st2 = dict(storms, m0=eng.init_m(storms))
+    s = parity.check_tracks('init-m', out, want, out['dec'], dec_w, t0_w, eng.t_s, flags=(), names=('traj',),
+                            replay=c_oracle.replayer(golden_env, 'NA', st2), tol_95=1e-10)
+    assert s['pointwise'] == 12
+
+
 def test_empty_and_single(engines):
     """Edge cases: n = 0 and n = 1 batches, a v0 <= 4 seed (1-sample track), a gated seed."""
     from tropical_cyclone_risk_amd import synthetic

@@ -151,3 +151,37 @@ def test_cholesky_failure_branch(golden_env):
     zero = (o['envw'] == 0).all(axis=2)
     assert zero.any(), 'expected exactly-zero env winds inside the zero-covariance patch'
     assert np.array_equal(zero, (g['envw'][idx] == 0).all(axis=2))
+
+
+def _init_m_tracks(g):
+    storms = dict(lon=g['t_lon0'], lat=g['t_lat0'], v0=g['t_v0'], h_bl=g['t_h_bl'], month=g['t_month'], phases=g['t_phases'])
+    want = dict(traj=g['t_traj'], status=g['t_status'], n_valid=g['t_n_valid'], nfev=g['t_nfev'], accepted=np.zeros(len(g['t_status']), bool))
+    return storms, want
+
+
+def test_c_oracle_init_m_vs_reference(golden_env):
+    """gen_track(m=None): Coupled_FAST._init_m (coupled_fast.py:153-173) at 240 points (incl. points whose +-0.25 degree
+    PI probes sit on grid lines, over land, and with dvdt != 0), and twelve whole tracks started without m
+    (tests/golden/make_golden_init_m.py ran the reference's own code)."""
+    from oracle import c_oracle as CO, parity
+    g = np.load(os.path.join(GOLDEN, 'init_m_NA.npz'))
+    cme = CO.CMonthEnv(golden_env, 'NA', int(g['month']) - 1)
+    for key, dvdt in (('m_dvdt0', 0.0), ('m_dvdt2em5', float(g['dvdt1']))):
+        got = np.array([CO.init_m(cme, CO.fourier_table(g['phases'][i]), float(g['h_bl']), g['lon'][i:i + 1], g['lat'][i:i + 1],
+                                  g['v'][i:i + 1], dvdt)[0] for i in range(len(g['lon']))])
+        assert np.abs(got - g[key]).max() <= 2e-15, key
+        assert (g[key] == 1).sum() > 50 and ((g[key] > 0.1) & (g[key] < 0.9)).sum() > 50       # clipped and interior values
+    storms, want = _init_m_tracks(g)
+    ens = CO.Ensemble(golden_env, 'NA')
+    ens._need(storms['month'])
+    m0 = np.array([CO.init_m(ens.cmes[int(storms['month'][i])], CO.fourier_table(storms['phases'][i]), storms['h_bl'][i],
+                             storms['lon'][i:i + 1], storms['lat'][i:i + 1], storms['v0'][i:i + 1])[0] for i in range(12)])
+    alive = want['n_valid'] > 0
+    assert np.abs(m0[alive] - want['traj'][alive, 3, 0]).max() <= 2e-15            # sample 0 of the reference's track IS _init_m's value
+    st = dict(storms, m0=m0)
+    o = ens.run(st, probe=True, post=False)
+    dec_ref = parity.ragged_to_padded(g['t_dec'], g['t_dec_off'], CO.PROBE_CAP)
+    t0_ref = parity.ragged_to_padded(g['t_dec_t0'], g['t_dec_off'], CO.PROBE_CAP, fill=np.nan, dtype=np.float64)
+    s = parity.check_tracks('init-m', o, want, o['dec'], dec_ref, t0_ref, np.linspace(0, 15 * 86400.0, 361), flags=(),
+                            names=('traj',), replay=CO.replayer(golden_env, 'NA', st), replay_as='got', tol_95=1e-10)
+    assert s['pointwise'] == 12 and (want['status'] == -1).sum() >= 2 and (want['status'] == 0).sum() >= 2

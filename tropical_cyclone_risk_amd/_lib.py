@@ -10,7 +10,7 @@ import os
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, 'libtcrisk_hip.so')
 
-TCR_ABI_VERSION = 3
+TCR_ABI_VERSION = 4
 TCR_NW, TCR_NCOV, TCR_MAX_SERIES, TCR_N_BASINS = 4, 10, 32, 7
 STATUS_GATED, STATUS_FINISHED, STATUS_EVENT, STATUS_STEP_FAIL, STATUS_STEP_OVERFLOW = -1, 0, 1, -2, -3
 FLAG_IS_TC, FLAG_ACCEPTED = 1, 2
@@ -28,7 +28,7 @@ EXPORTS = ('tcr_abi_version', 'tcr_ctx_create', 'tcr_ctx_destroy', 'tcr_last_err
            'tcr_gather_seeds_dev', 'tcr_pack_tracks_dev', 'tcr_stats_dev', 'tcr_integrate_pass_stats', 'tcr_wind_stats_dev', 'tcr_wind_stats_host', 'tcr_entropy_table_upload',
            'tcr_potential_intensity_host', 'tcr_potential_intensity_dev', 'tcr_chi_rh_host',
            'tcr_integrate_probe_host', 'tcr_integrate_f32_dev', 'tcr_integrate_f32_host', 'tcr_pack_tracks_f32_dev',
-           'tcr_wind_stats_f32_dev', 'tcr_wind_stats_f32_host', 'tcr_static_upload2')
+           'tcr_wind_stats_f32_dev', 'tcr_wind_stats_f32_host', 'tcr_static_upload2', 'tcr_init_m_dev', 'tcr_init_m_host')
 
 
 class Grid(C.Structure):
@@ -128,6 +128,8 @@ def lib():
     L.tcr_params_set.argtypes = [C.c_void_p, C.POINTER(Params)]
     L.tcr_static_upload.argtypes = [C.c_void_p, C.POINTER(Grid), DP, DP]
     L.tcr_static_upload2.argtypes = [C.c_void_p, C.POINTER(Grid), DP, C.POINTER(Grid), DP]
+    L.tcr_init_m_dev.argtypes = [C.c_void_p, C.POINTER(Storms), C.c_double, C.c_void_p, C.c_void_p]
+    L.tcr_init_m_host.argtypes = [C.c_void_p, C.POINTER(Storms), C.c_double, DP]
     L.tcr_fields_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Grid), C.POINTER(DP), C.POINTER(DP),
                                     C.POINTER(Grid), DP, DP, DP, DP]
     L.tcr_rh_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Grid), DP]

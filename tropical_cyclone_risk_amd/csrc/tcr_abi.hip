@@ -1281,6 +1281,65 @@ int tcr_probe_rhs_host(tcr_ctx *ctx, int slot, double h_bl, const double *Fs, in
     return 0;
 }
 
+extern "C++" {
+namespace {
+int init_m_launch(tcr_ctx *ctx, const tcr_storms *in, double dvdt, double *m_out, hipStream_t st)
+{
+    const DevFields DF = dev_fields(ctx);
+    EvalK EK{};
+    bool affine = false;
+    host_eval_k<double>(ctx, EK, &affine);
+    const dim3 grid((unsigned)((in->n + 63) / 64)), block(64);
+#define INIT_M(A, S) hipLaunchKernelGGL((k_init_m<A, S>), grid, block, 0, st, ctx->prm, DF, EK, in->n, in->n_dev, in->lon0, in->lat0, \
+                                        in->v0, in->m0, in->h_bl, in->slot, in->phases, dvdt, m_out)
+    if (affine && !ctx->split_static) INIT_M(true, false);
+    else if (!affine && !ctx->split_static) INIT_M(false, false);
+    else if (affine) INIT_M(true, true);
+    else INIT_M(false, true);
+#undef INIT_M
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+}  // namespace
+}  // extern "C++"
+
+int tcr_init_m_dev(tcr_ctx *ctx, const tcr_storms *in, double dvdt, double *m_out_dev, void *stream_)
+{
+    if (ready(ctx, false)) return -1;
+    if (!in || !m_out_dev || !in->lon0 || !in->lat0 || !in->v0 || !in->h_bl || !in->slot || !in->phases)
+        return fail(ctx, "tcr_init_m_dev: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (in->n <= 0) return 0;
+    return init_m_launch(ctx, in, dvdt, m_out_dev, stream_ ? (hipStream_t)stream_ : ctx->stream);
+}
+
+int tcr_init_m_host(tcr_ctx *ctx, const tcr_storms *in, double dvdt, double *m_out)
+{
+    if (ready(ctx, false)) return -1;
+    if (!in || !m_out || !in->lon0 || !in->lat0 || !in->v0 || !in->h_bl || !in->slot || !in->phases)
+        return fail(ctx, "tcr_init_m_host: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int64_t n = in->n;
+    if (n <= 0) return 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (in->slot[i] < 0 || (size_t)in->slot[i] >= ctx->slots.size() || !ctx->slots[in->slot[i]].wind)
+            return fail(ctx, "tcr_init_m_host: a storm uses a slot that is not staged");
+    DevBuf B;
+    tcr_storms d = *in;
+    d.n_dev = nullptr;
+    d.lon0 = B.put(in->lon0, n); d.lat0 = B.put(in->lat0, n); d.v0 = B.put(in->v0, n);
+    d.m0 = in->m0 ? B.put(in->m0, n) : nullptr;
+    d.h_bl = B.put(in->h_bl, n); d.slot = B.put(in->slot, n);
+    d.phases = B.put(in->phases, n * 4 * (int64_t)ctx->prm.n_series);
+    double *d_out = B.get<double>(n);
+    if (!d.lon0 || !d.lat0 || !d.v0 || (in->m0 && !d.m0) || !d.h_bl || !d.slot || !d.phases || !d_out)
+        return fail(ctx, "tcr_init_m_host: device allocation failed");
+    if (init_m_launch(ctx, &d, dvdt, d_out, ctx->stream)) return -1;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(m_out, d_out, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int tcr_seed_dev(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t cand0,
                  const tcr_seeds *out, void *stream_)
 {

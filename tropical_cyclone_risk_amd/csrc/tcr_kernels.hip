@@ -1357,6 +1357,92 @@ __global__ __launch_bounds__(256) void k_flags(tcr_params P, int64_t n_storms, c
     flags[sid] = fl;
 }
 
+// Coupled_FAST._init_m(y, dvdt) (intensity/coupled_fast.py:153-173): the inner-core moisture gen_track(m=None) starts
+// from (:258-261, dvdt = 0) — the m that makes dv/dt equal `dvdt` at t = 0, with PI taken as the maximum over the
+// point and the four points 0.25 degrees diagonally off it.  One thread per storm; storms whose m0 is a number keep it.
+template <bool AFFINE, bool SPLIT>
+__global__ __launch_bounds__(64) void k_init_m(tcr_params P, DevFields D, EvalK K_host, int64_t n, const int64_t *__restrict__ n_dev,
+                                               const double *__restrict__ lon0, const double *__restrict__ lat0,
+                                               const double *__restrict__ v0, const double *__restrict__ m0,
+                                               const double *__restrict__ h_bl, const int32_t *__restrict__ slot,
+                                               const double *__restrict__ phases, double dvdt, double *__restrict__ m_out)
+{
+    __shared__ EvalK K;
+    if (threadIdx.x == 0) K = K_host;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_eff(n, n_dev)) return;
+    if (m0 && m0[i] == m0[i]) { m_out[i] = m0[i]; return; }
+    const double lon = lon0[i], lat = lat0[i], v = v0[i];
+    const DevSlot S = D.slots[slot[i]];
+    // self.Fs_i(0): the forcing series at t = 0 (bam_track.py:23-31 with t = 0; interp1d at its first knot)
+    double F[4];
+    {
+        const int N = P.n_series;
+        const double two_pi = 2. * kPi;
+        const double *ph = phases + i * 4 * N;
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            double acc = 0.0;
+            for (int k = 0; k < N; ++k) {
+                const double arg = two_pi * (((double)(k + 1) * 0.0) / P.T_Fs + ph[sidx * N + k]);
+                const double term = P.fs_wgt[k] * sin(arg);
+                acc = (k == 0) ? term : acc + term;
+            }
+            F[sidx] = P.fs_amp * acc;
+        }
+    }
+    // _calc_steering_coefs(v), _step_bam_track(lon, lat, 0, coefs) -> v_bam (coupled_fast.py:155-156)
+    RhsT<double> r{};
+    TrackMidT<double> mid{};
+    {
+        const Cell cx = locate_t<double, AFFINE>(K.wx, lon), cy = locate_t<double, AFFINE>(K.wy, lat);
+        CornersT<double, 14, 2> CW;
+        gather<double, 14, kWindStride, 2>(S.wind, K.wx.n, cx, cy, CW);
+        double q[14];
+        blend<double, 14, 2>(CW, cx, cy, q);
+        winds_from_lookups<double>(q, F, lon, 0.0, r.w);
+        rhs_track<double>(K, lat, v, r, mid);
+    }
+    // _get_current_vpot at a point (coupled_fast.py:35-58)
+    auto vpot_at = [&](double x, double y) {
+        StaticLookup<double, AFFINE, SPLIT> SL;
+        SL.issue(K, x, y);
+        const Cell tx = locate_t<double, AFFINE>(K.tx, x), ty = locate_t<double, AFFINE>(K.ty, y);
+        CornersT<double, 4, 2> CT;
+        gather<double, 4, kThermoStride, 2>(S.thermo, K.tx.n, tx, ty, CT);
+        double th[4], lb[2];
+        blend<double, 4, 2>(CT, tx, ty, th);
+        SL.finish(lb);
+        return (lb[0] == 1.0) ? 0.0 : th[0];
+    };
+    // np.max over the five points: NaN propagates (coupled_fast.py:157-161)
+    double vp = vpot_at(lon, lat);
+    const double dx[4] = {-0.25, -0.25, 0.25, 0.25}, dy[4] = {-0.25, 0.25, -0.25, 0.25};
+    for (int k = 0; k < 4; ++k) {
+        const double c = vpot_at(lon + dx[k], lat + dy[k]);
+        vp = (vp != vp) ? vp : ((c != c) ? c : (c > vp ? c : vp));
+    }
+    // alpha = _calc_alpha(lon, lat, v_bam, v) (coupled_fast.py:65-94): the intensity half of the RHS has it
+    double th[4], lb[2];
+    {
+        StaticLookup<double, AFFINE, SPLIT> SL;
+        SL.issue(K, lon, lat);
+        const Cell tx = locate_t<double, AFFINE>(K.tx, lon), ty = locate_t<double, AFFINE>(K.ty, lat);
+        CornersT<double, 4, 2> CT;
+        gather<double, 4, kThermoStride, 2>(S.thermo, K.tx.n, tx, ty, CT);
+        blend<double, 4, 2>(CT, tx, ty, th);
+        SL.finish(lb);
+    }
+    rhs_intensity<double>(K, h_bl[i], lat, v, 0.5, th, lb, mid, r);
+    const double al = r.alpha;
+    const double gamma = K.epsilon + al * K.kappa;
+    const double beta = 1 - K.epsilon - K.kappa;
+    const double numer = 2 * h_bl[i] / K.Ck * dvdt + (v * v);
+    const double denom = al * beta * (vp * vp) + gamma * (v * v);
+    const double c = cbrt(numer / denom);
+    m_out[i] = np_max(np_min(c, 1.0), 0.0);
+}
+
 template <bool AFFINE, bool SPLIT>
 __global__ __launch_bounds__(64) void k_probe_rhs(tcr_params P, DevFields D, EvalK K_host, int slot, double h_bl, const double *fs,
                             int64_t n, const double *t, const double *lon, const double *lat,

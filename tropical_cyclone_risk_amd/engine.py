@@ -177,13 +177,32 @@ class TCEngine:
         return self
 
     # -------------------------------------------------------------- hot path
+    def init_m(self, storms, dvdt=0.0):
+        """Coupled_FAST._init_m(y, dvdt) (coupled_fast.py:153-173) for a host batch: the m0 gen_track(m=None) starts from.
+        Storms whose 'm0' is a number keep it; a missing 'm0' or NaN entries are initialised."""
+        n = len(storms['lon'])
+        lon0, lat0, v0, h_bl = (_f64(storms[k]) for k in ('lon', 'lat', 'v0', 'h_bl'))
+        m0 = _f64(storms['m0']) if storms.get('m0') is not None else None
+        slot = np.ascontiguousarray(np.asarray(storms['month']) - 1, dtype=np.int32)
+        ph = _f64(storms['phases']).reshape(n, 4 * self.n_series)
+        out = np.empty(n)
+        if n:
+            si = _lib.Storms(n, lon0.ctypes.data, lat0.ctypes.data, v0.ctypes.data, m0.ctypes.data if m0 is not None else None,
+                             h_bl.ctypes.data, slot.ctypes.data, ph.ctypes.data)
+            self._ck(self.L.tcr_init_m_host(self.h, C.byref(si), float(dvdt), _dp(out)))
+        return out
+
     def integrate(self, storms, probe_cap=0, dtype='f64'):
         """Integrate + post-process a batch given as host arrays (dict with lon, lat, v0,
         m0, h_bl, month (1..12), phases [n,4,N]); returns a dict of NumPy arrays.  probe_cap > 0 adds
         'dec' [n, probe_cap] uint8, the per-evaluation `land == 1` decisions (tcr_integrate_probe_host).
-        dtype='f32': the fp32 variant (tcr_integrate_f32_host), rows come back as float32."""
+        dtype='f32': the fp32 variant (tcr_integrate_f32_host), rows come back as float32.
+        gen_track(m=None) (coupled_fast.py:258-261): a batch without 'm0', or with NaN entries in it, gets those from
+        `init_m` (dv/dt = 0 at t = 0) first."""
         n = len(storms['lon'])
         ns = self.n_steps
+        if n and (storms.get('m0') is None or np.isnan(np.asarray(storms['m0'], dtype=np.float64)).any()):
+            storms = dict(storms, m0=self.init_m(storms))
         lon0, lat0, v0, m0, h_bl = (_f64(storms[k]) for k in ('lon', 'lat', 'v0', 'm0', 'h_bl'))
         slot = np.ascontiguousarray(np.asarray(storms['month']) - 1, dtype=np.int32)
         ph = _f64(storms['phases']).reshape(n, 4 * self.n_series)
