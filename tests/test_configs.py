@@ -221,6 +221,28 @@ def test_step_record_grows_instead_of_aborting(golden_env, built_lib):
     assert list(outs[8][0][7]) == list(outs[128][0][7]) and np.array_equal(outs[8][0][8], outs[128][0][8])
 
 
+def test_survivor_buffer_grows_when_a_round_accepts_more(golden_env, built_lib):
+    """compute.GpuRound sizes its survivor-record buffer for a quarter of a round's candidates (it used to hold a
+    26 kB row for every candidate, 1.7 GB per 65 536); a round that accepts more tracks than it holds grows it and packs
+    again — same result as a buffer that was large enough from the start."""
+    import torch
+    from tropical_cyclone_risk_amd import compute
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    eng = TCEngine('NA', device=0).stage_env(golden_env)
+    res = {}
+    for tag, cap in (('small', 3), ('default', None)):
+        rf = compute.GpuRound(eng, 2003, 1500)
+        if cap:
+            rf.cap = cap
+            rf.packed = torch.zeros(cap, rf.packed.shape[1], dtype=torch.float64, device=rf.pipe.dev)
+        res[tag] = compute.accept_loop(rf, 40, 1500, eng.n_steps)
+        if cap:
+            assert rf.cap > cap                               # it had to grow
+    eng.close()
+    for k in ('rows', 'month', 'basin_idx', 'cand', 'n_seeds'):
+        assert np.array_equal(res['small'][k], res['default'][k], equal_nan=True), k
+
+
 def test_forced_chain_on_a_small_batch(golden_env, built_lib):
     """with TCR_PARK forced on a batch of <= 8 waves the first pass was also the last one, yet it ran against a
     forcing table cut at sample 191 and parked — i.e. dropped — every storm that lives beyond it.  The segmented table now

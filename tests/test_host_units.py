@@ -406,7 +406,11 @@ def test_multi_file_monthly_inputs(tmp_path):
             v = f.createVariable('lat', 'd', ('lat',)); v[:] = [0, 1, 2]
             v = f.createVariable('lon', 'd', ('lon',)); v[:] = [0, 1, 2, 3]
             v = f.createVariable('x', 'd', ('time', 'lat', 'lon')); v[:] = recs[sl]
+            # a level axis as long as the FIRST file's record count: a coordinate, not a record
+            f.createDimension('lev', 2)
+            v = f.createVariable('lev', 'd', ('lev',)); v[:] = [85000.0, 25000.0]
     m = pp.MultiFile(fns)
+    assert np.array_equal(m['lev'], [85000.0, 25000.0])
     assert [(t.month, t.day) for t in m.times] == [(1, 15), (2, 15), (3, 15), (4, 15), (5, 15)]
     assert np.array_equal(m['x'], recs) and np.array_equal(m['lat'], [0, 1, 2])
     for i in range(5):

@@ -9,7 +9,21 @@ import glob
 import json
 import sys
 
+import os
+
 out_dir = sys.argv[1]
+# FETCH_SIZE correction for THIS project's access pattern (16-byte-per-lane gathers of 128-byte grid-point lines), measured
+# on a known byte count (tools/calibrate_fetch.hip -> profiles/r03_fetch_calibration.json): 1.9986 for scattered line
+# gathers, 2.0000 for streaming reads and for single 16-byte pieces of distinct lines (the L2 always fills whole 128-B lines
+# and the counter tallies them at 64 B).  WRITE_SIZE is exact for coalesced stores and over-reports scattered 112-of-128-B
+# line writes (the step records) by 1.24x; it is used as reported.
+CAL = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r03_fetch_calibration.json')
+FETCH_FACTOR, FETCH_SRC = 2.0, 'MI355X_MICROARCH.md (uncalibrated)'
+try:
+    cal = json.load(open(CAL))['kernels']
+    FETCH_FACTOR, FETCH_SRC = cal['cal_gather_line']['true_over_reported'], 'profiles/r03_fetch_calibration.json: cal_gather_line'
+except Exception:
+    pass
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 for f in glob.glob(out_dir + '/pmc*/**/*counter_collection.csv', recursive=True):
@@ -36,7 +50,7 @@ for k, e in res.items():
         # rocprofv3 reports both in KiB.  gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE =
         # TCC_EA0_RDREQ x 64 B while the L2 fills 128-B lines, i.e. it reports half the bytes read -> doubled.
         e['hbm_bytes_per_batch_raw'] = 1024.0 * (e['FETCH_SIZE_per_batch'] + e['WRITE_SIZE_per_batch'])
-        e['hbm_bytes_per_batch'] = 1024.0 * (2.0 * e['FETCH_SIZE_per_batch'] + e['WRITE_SIZE_per_batch'])
+        e['hbm_bytes_per_batch'] = 1024.0 * (FETCH_FACTOR * e['FETCH_SIZE_per_batch'] + e['WRITE_SIZE_per_batch'])
     if e.get('TCC_REQ_sum_per_batch'):
         e['l2_hit_rate'] = e['TCC_HIT_sum_per_batch'] / e['TCC_REQ_sum_per_batch']
 rows = sys.argv[2] if len(sys.argv) > 2 else 'tc'
@@ -44,8 +58,10 @@ command = ('rocprofv3 --kernel-trace --output-format csv --pmc <FETCH_SIZE | WRI
            'python bench.py --steps 3 --warmup 1 --streams 1 --rows %s --no-cpu-baseline (three separate runs)' % rows)
 meta = dict(workload='GL, 100000 storms per batch; the first batch of each run pads whole plane rows (pad_state = -1)',
             units='FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; *_per_batch = summed over the dispatches of a bench step',
-            note='hbm_bytes_per_batch = 2 x FETCH_SIZE + WRITE_SIZE: MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B '
-                 'while requests are 128-B line fills, so reads are under-reported 2x; calibrated there on 16-B/lane streaming loads, '
-                 'these kernels issue 16-B/lane gathers (same request size).  WRITE_SIZE matches known byte counts (Fourier table '
-                 '1.155 GB).  *_raw = FETCH_SIZE + WRITE_SIZE uncorrected.  Infinity-Cache hits are counted, so this is fabric-side traffic.')
+            fetch_factor=FETCH_FACTOR, fetch_factor_source=FETCH_SRC,
+            note='hbm_bytes_per_batch = fetch_factor x FETCH_SIZE + WRITE_SIZE.  On gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B while the L2 fills '
+                 '128-B lines; the factor is calibrated on this project\'s own gather pattern against a known byte count (1 GiB, every '
+                 'line once, 4x the Infinity Cache): 1.9986; streaming reads 2.0000.  WRITE_SIZE is exact for coalesced stores (1 GiB fill) '
+                 'and over-reports scattered 112-of-128-B line writes by 1.24x.  *_raw = FETCH_SIZE + WRITE_SIZE uncorrected.  '
+                 'Infinity-Cache hits are counted, so this is fabric-side traffic.')
 print(json.dumps(dict(command=command, rows=rows, meta=meta, kernels=res), indent=1))

@@ -97,7 +97,10 @@ def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000):
                 raise RuntimeError('%d storms needed more accepted RK steps than the step record holds; raise '
                                    'namelist.gpu_max_rk_steps (tcr_params.max_rk_steps)' % sum(bads))
         if counts[rk] > out['rows'].shape[0]:
-            raise RuntimeError('accept_loop: accepted %d tracks but the round packs only %d' % (counts[rk], out['rows'].shape[0]))
+            # more accepted tracks than this rank's survivor buffer holds: grow it and pack again (local, no collective)
+            if not hasattr(round_fn, 'repack'):
+                raise RuntimeError('accept_loop: accepted %d tracks but the round packs only %d' % (counts[rk], out['rows'].shape[0]))
+            out['rows'] = round_fn.repack(counts[rk])
         # ---- the data-path collective: all-gather of this round's survivor records, device to device
         gathered, _ = D.allgather_rows(out['rows'], None, counts=counts)
         got.append(gathered.clone() if W == 1 else gathered)     # one rank: a view of the round's own (reused) buffer
@@ -136,31 +139,46 @@ class GpuRound:
         self.year = int(year)
         self.seed = experiment_seed
         self.pipe = DevicePipeline(engine, per_rank, per_rank, tc_rows_only=True, dtype=getattr(engine.nl, 'gpu_dtype', 'f64'))
-        # every candidate of a round could be accepted: 26 kB per row
-        self.packed = torch.zeros(per_rank, ROW_VARS * engine.n_steps + N_META, dtype=torch.float64, device=self.pipe.dev)
+        # survivor records: 26 kB per accepted track.  1-6 % of a round's candidates are accepted, so the buffer is sized
+        # for a quarter of them (65 536 candidates: 0.43 GB instead of 1.7) and grows — `repack` — in the round that needs more
+        self.cap = max(1024, per_rank // 4)
+        self.packed = torch.zeros(self.cap, ROW_VARS * engine.n_steps + N_META, dtype=torch.float64, device=self.pipe.dev)
         self.ar = torch.arange(per_rank, device=self.pipe.dev)
 
     def grow(self):
         """Double the per-storm step record (tcr_params.max_rk_steps); False once it is at the ABI's limit."""
         return self.eng.grow_step_record()
 
+    def _pack(self, cand0, count):
+        torch, p = self.torch, self.pipe
+        width = ROW_VARS * self.eng.n_steps
+        cap = min(self.cap, count)
+        p.pack_accepted(self.packed, cap)
+        # meta columns, fixed shapes (rows beyond the accepted count are never read)
+        dense = p.acc_idx[:cap].long().clamp_(0, count - 1)            # position in the dense batch
+        cand_local = p.cand_idx[:count].long().clamp_(0, count - 1)[dense]   # position in this rank's candidate block
+        self.packed[:cap, width] = (cand_local + int(cand0)).double()
+        self.packed[:cap, width + 1] = (p.storms['slot'][:count][dense] + 1).double()
+        self.packed[:cap, width + 2] = p.storms['basin_idx'][:count][dense].double()
+        return self.packed[:cap]
+
+    def repack(self, need):
+        """The last round accepted more tracks than the survivor buffer holds: grow it and pack again (the tracks are
+        still in the pipeline's planes).  Local to this rank, no collective."""
+        self.cap = int(min(self.pipe.B, max(need, 2 * self.cap)))
+        self.packed = self.torch.zeros(self.cap, self.packed.shape[1], dtype=self.torch.float64, device=self.pipe.dev)
+        return self._pack(*self._last)
+
     def __call__(self, cand0, count):
         torch, p = self.torch, self.pipe
-        ns = self.eng.n_steps
-        width = ROW_VARS * ns
         p.seed_round(self.year, cand0, count, self.seed)
         p.select_passed(count)
         p.integrate(count, n_dev=p.n_passed)
         exists = self.ar[:count] < p.n_passed
         bad = ((p.tracks['status'][:count] == -3) & exists).sum().reshape(1)
         p.select_accepted()
-        p.pack_accepted(self.packed, count)
-        # meta columns, fixed shapes (rows beyond the accepted count are never read)
-        dense = p.acc_idx[:count].long().clamp_(0, count - 1)          # position in the dense batch
-        cand_local = p.cand_idx[:count].long().clamp_(0, count - 1)[dense]   # position in this rank's candidate block
-        self.packed[:count, width] = (cand_local + int(cand0)).double()
-        self.packed[:count, width + 1] = (p.storms['slot'][:count][dense] + 1).double()
-        self.packed[:count, width + 2] = p.storms['basin_idx'][:count][dense].double()
+        self._last = (cand0, count)
+        rows = self._pack(cand0, count)
         flags = p.cand['seed_flags'][:count]
         key = p.cand['basin_idx'][:count].long() * 12 + p.cand['slot'][:count].long()
         counted = (flags & 1) != 0
@@ -169,7 +187,7 @@ class GpuRound:
         def hist(cutoff=None):
             keep = counted if cutoff is None else counted & (idx.double() <= cutoff)
             return torch.zeros(len(BASIN_IDS) * 12, dtype=torch.float64, device=p.dev).index_add_(0, key, keep.double())
-        return dict(rows=self.packed[:count], count=p.n_accepted, bad=bad, hist=hist)
+        return dict(rows=rows, count=p.n_accepted, bad=bad, hist=hist)
 
 
 def rows_to_tuple(res, n_steps):

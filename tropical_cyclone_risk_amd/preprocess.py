@@ -249,8 +249,12 @@ class MultiFile:
 
     def __getitem__(self, k):
         first = np.asarray(self.parts[0][k])
-        if len(self.parts) == 1 or first.ndim == 0 or first.shape[0] != self.n_time[0] or k in ('lat', 'lon', 'latitude', 'longitude'):
-            return self.parts[0][k]                       # a coordinate: the first file's
+        # Coordinates come from the first file (combine="nested" concatenates data variables along `time` only).  Every
+        # 1-D variable other than `time` is a coordinate — a level axis whose length happens to equal the first file's
+        # record count (12 levels, 12 monthly records) must not be concatenated.
+        is_coord = first.ndim == 0 or (first.ndim == 1 and k != 'time') or first.shape[0] != self.n_time[0]
+        if len(self.parts) == 1 or is_coord:
+            return self.parts[0][k]
         return np.concatenate([np.asarray(p[k]) for p in self.parts], axis=0)
 
     def record(self, k, i):
