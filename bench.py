@@ -182,6 +182,10 @@ def main():
                 tot[kk] += m1[kk]
         return tot
     ms = sum_timings()
+    # SIMD time of the integrator chains as they ran INSIDE the timed region (the last batch of every stream: wave residency
+    # summed from the waves' own wall-clock stamps): under load the waves of several batches share the CUs' address paths,
+    # so this is what a chain costs the pipeline; `integrate_passes` below is the same for an isolated batch
+    pipe_passes = [e.pass_stats() for e in engs]
     # The same kernels once more, one launch at a time on one stream (after the timed region, not
     # part of `value`): with several streams the event-bracketed duration of a launch includes the
     # time it shared the GPU with other batches, so the per-kernel roofline is quoted both ways.
@@ -264,6 +268,13 @@ def main():
         # the same algorithmic bytes over the SIMD time the chain occupies (what it costs a pipelined run)
         achieved_over_simd_time=ib / (st_ms * 1e-3) / 1e9, frac_over_simd_time=ib / (st_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
 
+    simds_ = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+    pw = [sum(p['wave_ms'] for p in ps) for ps in pipe_passes if ps]
+    if pw:
+        roof['integrate_passes_pipelined'] = dict(
+            simd_time_ms=sum(pw) / len(pw) / simds_, batches=len(pw),
+            lane_utilisation=sum(p['lane_cycles'] for ps in pipe_passes for p in ps) / max(1, 64 * sum(p['wave_cycles'] for ps in pipe_passes for p in ps)),
+            note='wave residency of the k_integrate passes of the last timed batch of every stream / SIMDs')
     out = None
     if rank == 0:
         cpu = None

@@ -292,6 +292,12 @@ int park_threshold(const tcr_ctx *ctx, unsigned waves, int wps)
     return waves >= (unsigned)ctx->cu_count * 4u ? 12 : 0;
 }
 
+// TCR_PASS_FILL=p: passes after the first launch only p % as many lanes as they have parked storms (k_integrate, fill_pct)
+int pass_fill_pct()
+{
+    if (const char *e = getenv("TCR_PASS_FILL")) { const long v = atol(e); if (v > 0 && v <= 100) return (int)v; }
+    return 100;
+}
 // TCR_PRUNE=0: no in-flight 2-day test (every storm writes all its step records, k_screen looks at every storm)
 bool prune_enabled()
 {
@@ -640,6 +646,7 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
         for (int pass = 0; pass < kMaxPasses; ++pass) {
             const bool last = thr <= 0 || waves <= final_waves || pass == kMaxPasses - 1;
             a.pass = pass;
+            a.fill_pct = pass_fill_pct();
             a.threshold = last ? 0 : thr;
             a.park_in = ctx->d_park[(pass + 1) & 1];
             a.park_out = ctx->d_park[pass & 1];

@@ -48,6 +48,8 @@ struct KArgsT {
     // multi-pass tail compaction (see k_integrate)
     int pass;                    // 0: storms come fresh from the batch; >0: from the list parked by pass-1
     int threshold;               // park the wave's storms and exit once fewer lanes than this are live (0: run to the end)
+    int fill_pct;                // pass > 0: only ceil(items * fill_pct / 100 / 64) waves take part, so that a lane works through
+                                 // 100 / fill_pct parked storms in turn instead of one (0 or 100: one lane per parked storm)
     const double *park_in;       // [.. ][kParkRec] list written by the previous pass
     double *park_out;            // list this pass writes
     double t_limit;              // a storm whose next attempt ends beyond this time is parked for the next pass (the forcing table
@@ -519,7 +521,10 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
     const DevFields &D = a.D;
     const int lane = threadIdx.x;
     const long long n_items = a.pass == 0 ? (long long)n_eff(a.n, a.n_dev) : (long long)a.queue[kMaxPasses + a.pass - 1];
-    if (a.pass > 0 && (long long)blockIdx.x * kWave >= n_items) return;     // the list fits the first waves
+    if (a.pass > 0) {                                                       // the list fits the first waves
+        const long long lanes = (a.fill_pct > 0 && a.fill_pct < 100) ? (n_items * a.fill_pct + 99) / 100 : n_items;
+        if ((long long)blockIdx.x * kWave >= lanes) return;
+    }
     unsigned long long *const q_head = a.queue + a.pass;
     for (unsigned w = lane; w < sizeof(EvalKT<R>) / 8; w += kWave)
         reinterpret_cast<uint64_t *>(&K)[w] = reinterpret_cast<const uint64_t *>(&a.K)[w];
@@ -961,6 +966,15 @@ constexpr int kEmitSlotCache = 32;      // field-slot wind pointers kept in LDS 
 #ifndef TCR_EMIT_WPS
 #define TCR_EMIT_WPS 3     // waves per SIMD k_emit is register-budgeted for (<= 168 VGPRs)
 #endif
+// Register budget of the post-processing kernels.  An integrator wave owns 256 VGPRs + 164 AGPRs = 424 of its SIMD's 512
+// registers (allocated in eights), so a wave of another kernel can be resident NEXT to it — and issue in the 40 % of the
+// issue slots the integrator's dependent fp64 chains leave empty — only if it needs at most 88.  k_emit took 90 and
+// k_screen 92 (96 allocated: 424 + 96 > 512), i.e. every batch's post-processing had to wait for SIMDs without an
+// integrator wave of the three other batches in flight.  Budgeted for 6 waves per SIMD they get at most 80.
+// DESIGN.md §9 (round 3) has the measurement.
+#ifndef TCR_SHADOW_WPS
+#define TCR_SHADOW_WPS 6
+#endif
 
 // body of an accepted-step record: R y_old[4], then K[7][4] (k_integrate) / Q[4][4] in its place (k_dense)
 template <typename R>
@@ -1096,7 +1110,7 @@ __device__ __forceinline__ void dense_at(const double *__restrict__ srec_storm, 
 // make this kernel wait on memory ~60 % of the time, so the transcendental-heavy vmax math of
 // the same sample runs in its shadow (as a kernel of its own it cost 0.34 ms per 100k storms).
 template <typename R, bool AFFINE, bool LIST>
-__global__ __launch_bounds__(kPostThreads, TCR_EMIT_WPS) void k_emit(EArgsT<R> a, const uint16_t *__restrict__ sidx)
+__global__ __launch_bounds__(kPostThreads, (LIST ? TCR_EMIT_WPS : TCR_SHADOW_WPS)) void k_emit(EArgsT<R> a, const uint16_t *__restrict__ sidx)
 {
     __shared__ EvalKT<R> K_lds;
     __shared__ const R *s_wind[kEmitSlotCache];
@@ -1203,7 +1217,7 @@ constexpr int kScreenGroup = 16;                                   // lanes per 
 constexpr int kScreenStorms = kScreenThreads / kScreenGroup;       // storms per workgroup
 
 template <typename R>
-__global__ __launch_bounds__(kScreenThreads) void k_screen(EArgsT<R> a)
+__global__ __launch_bounds__(kScreenThreads, TCR_SHADOW_WPS) void k_screen(EArgsT<R> a)
 {
     __shared__ R cap[kScreenStorms][3];      // v at sample j2d, j2d + 1, n - 1
     const tcr_params &P = a.P;
