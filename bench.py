@@ -268,6 +268,18 @@ def main():
         # the same algorithmic bytes over the SIMD time the chain occupies (what it costs a pipelined run)
         achieved_over_simd_time=ib / (st_ms * 1e-3) / 1e9, frac_over_simd_time=ib / (st_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
 
+    # The whole step against the memory system: fabric-side bytes of ALL kernels of a step (rocprofv3 --pmc, corrected with the
+    # factor calibrated on this access pattern) over the measured time per step.  Reducing the integrator's SIMD time (lane
+    # utilisation 0.73 -> 0.91) does not move the step, removing the forcing table's traffic does:
+    # the step sits at ~0.9 of what scattered 128-byte line fills reach on this chip (tools/calibrate_fetch.hip: 4.26 TB/s).
+    step_bytes, step_src = measured_traffic('*', B, args.rows, args.dtype) if not strong else (None, None)
+    if step_bytes and world == 1:
+        gbs = step_bytes / (dt / args.steps) / 1e9
+        roof['whole_step'] = dict(traffic=step_bytes, traffic_source=step_src, achieved=gbs, unit='GB/s', peak=HBM_PEAK_GBS,
+                                  frac=gbs / HBM_PEAK_GBS, scattered_line_fill_ceiling=4260.0,
+                                  frac_of_scattered_line_fill_ceiling=gbs / 4260.0,
+                                  note='fabric-side traffic (L2 misses incl. Infinity-Cache hits) of every kernel of a step / ms_per_step; '
+                                       'ceiling = 1 GiB of 128-B lines gathered once each, 7 x 16 B per lane (profiles/r03_fetch_calibration*)')
     simds_ = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
     pw = [sum(p['wave_ms'] for p in ps) for ps in pipe_passes if ps]
     if pw:
@@ -318,16 +330,18 @@ def measured_traffic(kernel, storms, rows, dtype='f64'):
     """(HBM bytes per batch, source) of a kernel from the committed rocprofv3 --pmc runs of this same workload
     (tools/collect_profiles.sh; counters are collected in separate passes from timing, as MI355X_MICROARCH.md
     prescribes, so they cannot be measured inside this process).  Only valid for the profiled size."""
-    fn = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm.json')
+    fn = os.path.join(ROOT, 'profiles', 'r03_pmc_hbm.json')
     if storms != 100_000 or dtype != 'f64' or not os.path.exists(fn):
         return None, None
     try:
         d = json.load(open(fn))
         if d.get('rows') != rows:
             return None, None
+            if kernel == '*':          # every kernel of a step
+            return d['step_total']['hbm_bytes_per_batch'], 'profiles/r03_pmc_hbm.json: sum over the kernels of a step'
         for name, v in d['kernels'].items():
             if kernel in name:
-                return v['hbm_bytes_per_batch'], 'profiles/r02_pmc_hbm.json: rocprofv3 --pmc, separate passes, %s' % d.get('command', '')
+                return v['hbm_bytes_per_batch'], 'profiles/r03_pmc_hbm.json: rocprofv3 --pmc, separate passes, %s' % d.get('command', '')
     except Exception:
         pass
     return None, None

@@ -32,17 +32,28 @@ _BASIN = None
 _STORMS = None
 
 
+_CACHE = {}
+
+
 def _work(idx, post='tc'):
     """post='tc': integration + accept tests + env-wind recompute / vmax for the candidates that pass accept test 1 —
     what the reference's loop does per candidate (compute.py:176-209) and what the GPU step does; post=False:
     integration only (gen_track)."""
     from oracle import scipy_port as P
-    o = P.run_ensemble(_ENV, _BASIN, _STORMS, index=idx, post=post)
+    o = P.run_ensemble(_ENV, _BASIN, _STORMS, index=idx, post=post, cache=_CACHE)
     return int(np.clip(o['n_valid'] - 1, 0, None).sum()), int(o['nfev'].sum()), len(idx)
 
 
-def _work_int_only(idx):
-    return _work(idx, post=False)
+def _work_timed(args):
+    """Work through `idx` eight storms at a time until `seconds` have passed (storm cost varies by two orders of
+    magnitude with its lifetime, so a leg is sized by the clock, not by a calibration): (storm-steps, nfev, storms, seconds)."""
+    idx, seconds, post = args
+    t0 = time.perf_counter()
+    steps = nfev = done = 0
+    while done < len(idx) and time.perf_counter() - t0 < seconds:
+        s, f, n = _work(idx[done:done + 8], post)
+        steps += s; nfev += f; done += n
+    return steps, nfev, done, time.perf_counter() - t0
 
 
 def cgroup_cpu_quota():
@@ -105,33 +116,26 @@ def main():
     n_avail = len(_STORMS['lon'])
     procs = a.procs or usable_cores()
 
-    # warm up (imports, SciPy's first calls, the month caches), THEN calibrate the per-storm cost on 24 storms and size
-    # every leg to the time budget (round 2 calibrated on the first call and ran 2 s of a 12 s budget)
-    _work(list(range(min(4, n_avail))))
-    nc = min(24, n_avail)
-    t0 = time.perf_counter(); _work(list(range(nc))); per = (time.perf_counter() - t0) / nc
-    n1 = int(max(8, min(n_avail, a.budget / per)))
-    t0 = time.perf_counter(); steps1, nfev1, _ = _work(list(range(n1))); dt1 = time.perf_counter() - t0
+    # warm up (imports, SciPy's first calls; 64 storms touch all twelve month environments, each 20 spline constructions)
+    _work(list(range(min(64, n_avail))))
+    every = list(range(n_avail))
+    steps1, nfev1, n1, dt1 = _work_timed((every, a.budget, 'tc'))
     out = dict(one_core=dict(storm_steps=steps1, seconds=dt1, storms=n1, value=steps1 / dt1, nfev=nfev1,
                              what='integration + accept tests + env winds / vmax of the candidates that pass accept test 1 (compute.py:176-209)'))
-    ni = int(max(8, min(n_avail, 0.35 * a.budget / per)))
-    t0 = time.perf_counter(); stepsi, _, _ = _work(list(range(ni)), post=False); dti = time.perf_counter() - t0
+    stepsi, _, ni, dti = _work_timed((every, 0.35 * a.budget, False))
     out['one_core_integration_only'] = dict(storm_steps=stepsi, seconds=dti, storms=ni, value=stepsi / dti)
     if procs > 1:
-        nP = int(max(procs, min(n_avail, 0.7 * procs * a.budget / per)))     # all cores busy: lower per-core clock
-        chunks = [list(range(i, nP, procs)) for i in range(procs)]
+        chunks = [list(range(i, n_avail, procs)) for i in range(procs)]
         ctx = mp.get_context('fork')
         with ctx.Pool(procs) as pool:
-            pool.map(_work, [[0, 1]] * procs)               # warm the workers (imports, caches)
-            t0 = time.perf_counter(); res = pool.map(_work, chunks); dtP = time.perf_counter() - t0
-            nPi = max(procs, nP // 3)
-            chunks_i = [list(range(i, nPi, procs)) for i in range(procs)]
-            t0 = time.perf_counter(); res_i = pool.map(_work_int_only, chunks_i); dtPi = time.perf_counter() - t0
-        stepsP = sum(r[0] for r in res)
+            pool.map(_work, [list(range(16))] * procs)      # warm the workers (imports; the month environments are inherited)
+            t0 = time.perf_counter(); res = pool.map(_work_timed, [(c, a.budget, 'tc') for c in chunks]); dtP = time.perf_counter() - t0
+            t0 = time.perf_counter(); res_i = pool.map(_work_timed, [(c, 0.35 * a.budget, False) for c in chunks]); dtPi = time.perf_counter() - t0
+        stepsP, nP = sum(r[0] for r in res), sum(r[2] for r in res)
         out['all_cores'] = dict(storm_steps=stepsP, seconds=dtP, storms=nP, value=stepsP / dtP, procs=procs,
                                 physical_cores_visible=physical_cores(), cgroup_cpu_quota=cgroup_cpu_quota(),
                                 per_core_efficiency=(stepsP / dtP) / (procs * steps1 / dt1))
-        stepsPi = sum(r[0] for r in res_i)
+        stepsPi, nPi = sum(r[0] for r in res_i), sum(r[2] for r in res_i)
         out['all_cores_integration_only'] = dict(storm_steps=stepsPi, seconds=dtPi, storms=nPi, value=stepsPi / dtPi, procs=procs)
     # the plain-C restatement (oracle/tc_oracle.c) on one core, for scale: same algorithm without the
     # interpreter / SciPy call overhead that dominates the reference's own CPU path

@@ -310,10 +310,11 @@ def post_storm(prm, res, tc_only=False):
     return out
 
 
-def run_ensemble(env, basin, storms, prm=None, post=True, index=None):
+def run_ensemble(env, basin, storms, prm=None, post=True, index=None, cache=None):
     """Integrate (and post-process) a set of storms; returns padded arrays + counters.
 
-    storms: dict of arrays as produced by ``synthetic.draw_storm_inputs``.
+    storms: dict of arrays as produced by ``synthetic.draw_storm_inputs``.  cache: a dict that keeps the month
+    environments (the twelve `cpl_fast` objects of run_tracks) between calls.
     """
     prm = prm or Params()
     idx = range(len(storms['lon'])) if index is None else index
@@ -323,7 +324,7 @@ def run_ensemble(env, basin, storms, prm=None, post=True, index=None):
                vmax=np.full((len(idx), ns), np.nan), n_valid=np.zeros(len(idx), np.int32),
                status=np.zeros(len(idx), np.int32), nfev=np.zeros(len(idx), np.int32),
                is_tc=np.zeros(len(idx), bool), accepted=np.zeros(len(idx), bool))
-    cache = {}
+    cache = {} if cache is None else cache
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         for k, i in enumerate(idx):

@@ -3,7 +3,7 @@
 #   bash tools/collect_profiles.sh r02 [tc|all]
 # Timing (kernel-trace/stats) and counters (--pmc) are separate rocprofv3 runs, as MI355X_MICROARCH.md prescribes.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROWS=${2:-tc}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp

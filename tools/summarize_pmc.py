@@ -53,6 +53,8 @@ for k, e in res.items():
         e['hbm_bytes_per_batch'] = 1024.0 * (FETCH_FACTOR * e['FETCH_SIZE_per_batch'] + e['WRITE_SIZE_per_batch'])
     if e.get('TCC_REQ_sum_per_batch'):
         e['l2_hit_rate'] = e['TCC_HIT_sum_per_batch'] / e['TCC_REQ_sum_per_batch']
+tot = sum(e.get('hbm_bytes_per_batch', 0.0) for e in res.values())
+tot_raw = sum(e.get('hbm_bytes_per_batch_raw', 0.0) for e in res.values())
 rows = sys.argv[2] if len(sys.argv) > 2 else 'tc'
 command = ('rocprofv3 --kernel-trace --output-format csv --pmc <FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum> -- '
            'python bench.py --steps 3 --warmup 1 --streams 1 --rows %s --no-cpu-baseline (three separate runs)' % rows)
@@ -64,4 +66,5 @@ meta = dict(workload='GL, 100000 storms per batch; the first batch of each run p
                  'line once, 4x the Infinity Cache): 1.9986; streaming reads 2.0000.  WRITE_SIZE is exact for coalesced stores (1 GiB fill) '
                  'and over-reports scattered 112-of-128-B line writes by 1.24x.  *_raw = FETCH_SIZE + WRITE_SIZE uncorrected.  '
                  'Infinity-Cache hits are counted, so this is fabric-side traffic.')
-print(json.dumps(dict(command=command, rows=rows, meta=meta, kernels=res), indent=1))
+print(json.dumps(dict(command=command, rows=rows, meta=meta, step_total=dict(hbm_bytes_per_batch=tot, hbm_bytes_per_batch_raw=tot_raw,
+                                                                          note='sum over the tcr:: kernels of one bench step'), kernels=res), indent=1))
