@@ -337,7 +337,7 @@ def measured_traffic(kernel, storms, rows, dtype='f64'):
         d = json.load(open(fn))
         if d.get('rows') != rows:
             return None, None
-            if kernel == '*':          # every kernel of a step
+        if kernel == '*':          # every kernel of a step
             return d['step_total']['hbm_bytes_per_batch'], 'profiles/r03_pmc_hbm.json: sum over the kernels of a step'
         for name, v in d['kernels'].items():
             if kernel in name:

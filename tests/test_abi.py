@@ -102,3 +102,13 @@ def test_product_never_imports_oracle():
             if fn.endswith(('.py', '.hip', '.h', '.cpp')):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert 'oracle' not in re.sub(r'#.*|//.*', '', text).replace('"oracle"', ''), (dirpath, fn)
+
+
+def test_entry_scripts_compile():
+    """bench.py / run.py / __graft_entry__.py are only executed on the GPU box: a syntax error in them must not wait for it."""
+    import py_compile
+    for f in ('bench.py', 'run.py', '__graft_entry__.py'):
+        py_compile.compile(os.path.join(ROOT, f), doraise=True)
+    for f in os.listdir(os.path.join(ROOT, 'tools')):
+        if f.endswith('.py'):
+            py_compile.compile(os.path.join(ROOT, 'tools', f), doraise=True)

@@ -197,11 +197,12 @@ class TCEngine:
         m0, h_bl, month (1..12), phases [n,4,N]); returns a dict of NumPy arrays.  probe_cap > 0 adds
         'dec' [n, probe_cap] uint8, the per-evaluation `land == 1` decisions (tcr_integrate_probe_host).
         dtype='f32': the fp32 variant (tcr_integrate_f32_host), rows come back as float32.
-        gen_track(m=None) (coupled_fast.py:258-261): a batch without 'm0', or with NaN entries in it, gets those from
-        `init_m` (dv/dt = 0 at t = 0) first."""
+        gen_track(m=None) (coupled_fast.py:258-261): a batch without 'm0' gets it from `init_m` (dv/dt = 0 at t = 0) first.
+        (A NaN *entry* of a given m0 is not "None": the reference integrates it as it is, and so does this — call `init_m`
+        explicitly to fill NaN entries.)"""
         n = len(storms['lon'])
         ns = self.n_steps
-        if n and (storms.get('m0') is None or np.isnan(np.asarray(storms['m0'], dtype=np.float64)).any()):
+        if n and storms.get('m0') is None:
             storms = dict(storms, m0=self.init_m(storms))
         lon0, lat0, v0, m0, h_bl = (_f64(storms[k]) for k in ('lon', 'lat', 'v0', 'm0', 'h_bl'))
         slot = np.ascontiguousarray(np.asarray(storms['month']) - 1, dtype=np.int32)
