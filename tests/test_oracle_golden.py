@@ -185,3 +185,58 @@ def test_c_oracle_init_m_vs_reference(golden_env):
     s = parity.check_tracks('init-m', o, want, o['dec'], dec_ref, t0_ref, np.linspace(0, 15 * 86400.0, 361), flags=(),
                             names=('traj',), replay=CO.replayer(golden_env, 'NA', st), replay_as='got', tol_95=1e-10)
     assert s['pointwise'] == 12 and (want['status'] == -1).sum() >= 2 and (want['status'] == 0).sum() >= 2
+
+
+def test_checker_is_not_vacuous(golden_env):
+    """oracle/parity.check_tracks must FAIL on the regressions the round-2 bar would have let through:
+    4 % of the storms wrong at 1e-8, a wrong land decision at a point that is not rounding-sensitive, a wrong discrete
+    result of a storm whose decisions differ, and a replay that is asked to force a decision it must not take."""
+    from oracle import c_oracle as CO, parity
+    from tropical_cyclone_risk_amd import synthetic
+    storms = synthetic.draw_storm_inputs(400, 'NA', seed=321)
+    ref = CO.run_ensemble(golden_env, 'NA', storms, probe=True)
+    t_s = np.linspace(0, 15 * 86400.0, 361)
+    replay = CO.replayer(golden_env, 'NA', storms)
+
+    def check(got, dec=None):
+        return parity.check_tracks('neg', got, ref, ref['dec'] if dec is None else dec, ref['dec'], ref['dec_t0'], t_s,
+                                   verbose=False, replay=replay)
+    s = check(ref)                                               # the oracle against itself passes, everything pointwise
+    assert s['pointwise'] == 400 and s['diverged'] == 0
+    # (a) 4 % of the storms off by 1e-8 (the round-2 tiers allowed 5 % up to 1e-6)
+    bad = {k: (v.copy() if hasattr(v, 'copy') else v) for k, v in ref.items()}
+    alive = np.nonzero(ref['n_valid'] > 5)[0][:16]
+    bad['traj'][alive, 2, 3] += 1e-8
+    with pytest.raises(AssertionError, match='p99 tier|p95 tier'):
+        check(bad)
+    # (b) a land decision flipped where nothing is rounding-sensitive and PI != 0: not flicker, a bug
+    clean = np.nonzero(~(((ref['dec'] != 0xff) & ((ref['dec'] & 4) != 0)).any(axis=1)) &
+                       (((ref['dec'] != 0xff) & ((ref['dec'] & 2) != 0)).any(axis=1)))[0]
+    assert clean.size > 50
+    dec = ref['dec'].copy()
+    i = int(clean[0]); k = int(np.nonzero((dec[i] != 0xff) & ((dec[i] & 2) != 0))[0][0])
+    dec[i, k] ^= 1
+    with pytest.raises(AssertionError, match='not within 1e-12 of land == 1'):
+        check(ref, dec)
+    # (c) a storm whose decision differs at a sensitive evaluation: the replay then demands the WHOLE track and the discrete
+    #     results — a wrong n_valid or a wrong tail sample that the prefix check never saw must fail
+    exposed = np.nonzero(((ref['dec'] != 0xff) & ((ref['dec'] & 6) == 6)).any(axis=1) & (ref['n_valid'] > 40))[0]
+    assert exposed.size > 5
+    i = int(exposed[0]); k = int(np.nonzero((ref['dec'][i] != 0xff) & ((ref['dec'][i] & 6) == 6))[0][0])
+    dec = ref['dec'].copy(); dec[i, k] ^= 1                      # pretend the other side's rounding fell the other way there
+    forced = CO.run_ensemble(golden_env, 'NA', {kk: vv[i:i + 1] for kk, vv in storms.items()}, probe=True, force=dec[i:i + 1])
+    got = {kk: (vv.copy() if hasattr(vv, 'copy') else vv) for kk, vv in ref.items()}
+    for kk in ('traj', 'envw', 'vmax', 'status', 'n_valid', 'nfev', 'is_tc', 'accepted'):
+        got[kk][i] = forced[kk][0]
+    got_dec = ref['dec'].copy(); got_dec[i] = forced['dec'][0]
+    s = check(got, got_dec)                                      # consistent: passes through the replay
+    assert s['replayed'] == 1 and s['overridden'] >= 1
+    nv = int(got['n_valid'][i])
+    worse = {kk: (vv.copy() if hasattr(vv, 'copy') else vv) for kk, vv in got.items()}
+    worse['traj'][i, 0, nv - 1] += 1e-5                          # the last sample: far behind the first differing decision
+    with pytest.raises(AssertionError):
+        check(worse, got_dec)
+    worse = {kk: (vv.copy() if hasattr(vv, 'copy') else vv) for kk, vv in got.items()}
+    worse['nfev'][i] += 6
+    with pytest.raises(AssertionError, match='after forced replay'):
+        check(worse, got_dec)
