@@ -50,7 +50,9 @@ def main():
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--basin', default='GL')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--sort', action='store_true', help='locality-sort the dense batch (see pipeline.py)')
+    ap.add_argument('--order', choices=('cells', 'candidate'), default='cells',
+                    help='cells: the dense batch in locality order (2-degree genesis cells, tcr_cell_order_dev; DESIGN.md §9); '
+                         'candidate: candidate order')
     ap.add_argument('--streams', type=int, default=None,
                     help='HIP streams the steps are round-robined over (each with its own context and buffers): '
                          'the low-occupancy tail of one batch overlaps the next batch.  Default 4; 16 for the small '
@@ -115,7 +117,7 @@ def main():
         B = int(args.storms / world * 1.25) + 2048                             # capacity: 25 % + 2048 over the expected count
     else:
         C = int(B / max(p_pass, 1e-3) * 1.15) + 4096
-    pipes = [DevicePipeline(e, C, B, sort_storms=args.sort, tc_rows_only=(args.rows == 'tc'), dtype=args.dtype) for e in engs]
+    pipes = [DevicePipeline(e, C, B, sort_storms=(args.order == 'cells'), tc_rows_only=(args.rows == 'tc'), dtype=args.dtype) for e in engs]
     global BYTES_PER_RHS, BYTES_PER_SAMPLE
     if args.dtype == 'f32':
         BYTES_PER_RHS, BYTES_PER_SAMPLE = 352.0, 260.0          # SURVEY.md §8d, fp32 mode
@@ -305,7 +307,7 @@ def main():
                                        else '%d storms per GPU per step' % B, 'fp64' if args.dtype == 'f64' else 'fp32 fields/state/RHS/rows with fp64 time and step controller', (
                                        'env winds, vmax and rows only for storms that pass accept test 1, as the reference '
                                        'does (compute.py:190-204)' if args.rows == 'tc' else 'rows for every integrated storm')),
-                       'rows': args.rows, 'is_tc_fraction': tc_total / storms_total,
+                       'rows': args.rows, 'batch_order': args.order, 'is_tc_fraction': tc_total / storms_total,
                        'storms_per_step': storms_total / args.steps, 'storm_steps_total': int(steps_total),
                        'emitted_samples_per_step': emitted_total / (args.steps * world),
                        'storms_per_gpu': storms_total / (args.steps * world), 'candidates_per_round': C, 'seed_pass_rate': p_pass,

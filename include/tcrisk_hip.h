@@ -215,6 +215,14 @@ int tcr_seed_host(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t 
  * order, first max_out of them -> idx; *count = how many matched (device scalar). */
 int tcr_compact_dev(tcr_ctx *ctx, int64_t n, const int32_t *flags_dev, int32_t mask, int64_t max_out,
                     int32_t *idx_dev, int64_t *count_dev, void *stream);
+/* Locality order of a selection (no reference counterpart: the reference integrates one storm at a time): reorders
+ * idx_dev[0 .. min(n, *count_dev)) — candidate indices as tcr_compact_dev leaves them — by the cell_deg-degree cell of
+ * the candidates' genesis points (latitude row major, stable: candidate order within a cell), so that the storms
+ * tcr_gather_seeds_dev then places next to each other, and the integrator runs in one wave, read the same parts of the
+ * fields.  Per-storm results do not depend on the order of a batch; a caller that needs candidate order (the accept loop
+ * of run_tracks) sorts the few accepted rows back by their candidate index. */
+int tcr_cell_order_dev(tcr_ctx *ctx, const tcr_seeds *cand_dev, int32_t *idx_dev, int64_t n, const int64_t *count_dev,
+                       double cell_deg, void *stream);
 /* dense storm batch dst[r] = src[idx[r]], r < min(n_out, *count_dev) (count_dev, the device scalar
  * written by tcr_compact_dev, may be NULL = all n_out rows are valid).  If src_dev->phases is NULL (tcr_seed_dev was
  * asked not to write them: most candidates never pass) the 4*n_series Fourier phases of the selected

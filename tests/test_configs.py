@@ -265,3 +265,39 @@ def test_forced_chain_on_a_small_batch(golden_env, built_lib):
         for k in ('status', 'n_valid', 'nfev', 'flags', 'n_accept', 'n_reject'):
             assert np.array_equal(base[k], got[k]), (env_over, k)
     eng.close()
+
+
+def test_locality_order_is_a_stable_sort_and_changes_no_storm(golden_env, built_lib):
+    """tcr_cell_order_dev: the selected candidates ordered by the 2-degree cell of their genesis point (latitude row major),
+    exactly numpy's stable argsort of that key; the batch integrated in that order gives, storm for storm, bit for bit
+    what candidate order gives; and the selection is the same set of candidates."""
+    import torch
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    from tropical_cyclone_risk_amd.pipeline import DevicePipeline
+    B = 20_000
+    eng = TCEngine('GL', device=0).stage_env(golden_env)
+    res = {}
+    for tag, so in (('cand', False), ('cells', True), ('cells3', 3.0)):
+        p = DevicePipeline(eng, 120_000, B, sort_storms=so)
+        p.seed_round(2011, 0); p.select_passed(B)
+        assert int(p.n_passed.item()) >= B
+        p.integrate(B); torch.cuda.synchronize()
+        res[tag] = (p.cand_idx[:B].cpu().numpy().astype(np.int64), p.host_tracks(),
+                    p.cand['lon0'].cpu().numpy(), p.cand['lat0'].cpu().numpy())
+        del p
+    eng.close()
+    ci, a, lon, lat = res['cand']
+    assert (np.diff(ci) > 0).all()
+    for tag, deg in (('cells', 2.0), ('cells3', 3.0)):
+        cj, b, _, _ = res[tag]
+        ncol = int(np.ceil(360.0 / deg))
+        lo = lon[ci] - 360.0 * np.floor(lon[ci] / 360.0)
+        key = np.floor((lat[ci] + 90.0) * (1.0 / deg)).astype(np.int64) * ncol + np.floor(lo * (1.0 / deg)).astype(np.int64)
+        want = ci[np.argsort(key, kind='stable')]
+        assert np.array_equal(cj, want), tag
+        assert len(np.unique(key)) > 500                       # it is a real reordering
+        back = np.searchsorted(ci, cj)                        # dense position in candidate order of every cell-ordered storm
+        for k in ('lon', 'lat', 'v', 'm', 'vmax', 'envw'):
+            assert np.array_equal(b[k], a[k][back], equal_nan=True), (tag, k)
+        for k in ('status', 'n_valid', 'nfev', 'flags', 'n_accept', 'n_reject'):
+            assert np.array_equal(b[k], a[k][back]), (tag, k)

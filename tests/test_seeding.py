@@ -174,7 +174,8 @@ def test_product_round_is_device_resident(golden_env, built_lib):
     n_acc = int(out['count'].item())
     width = 9 * eng.n_steps
     rows = out['rows'][:n_acc].cpu().numpy()
-    assert n_acc > 0 and (np.diff(rows[:, width]) > 0).all() and rows[:, width].min() >= 4096 and rows[:, width].max() < 8192
+    # (the round integrates in locality order; accept_loop sorts the accepted rows back by this candidate column)
+    assert out['unordered'] and n_acc > 0 and len(np.unique(rows[:, width])) == n_acc and rows[:, width].min() >= 4096 and rows[:, width].max() < 8192
     assert int(out['bad'].item()) == 0 and h.sum().item() > h2.sum().item() > 0
     # the same round through the host-visible pieces: seeds, flags
     flags = rf.pipe.tracks['flags'][:4096].cpu().numpy()

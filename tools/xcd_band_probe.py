@@ -48,8 +48,14 @@ def banded(key, n_bands=8, chunk=64, interleave=True):
     return torch.cat(out)
 
 
-run('candidate order', None)
 lon = orig['lon0']
+mode = sys.argv[2] if len(sys.argv) > 2 else 'all'
+if mode != 'all':            # one ordering only (for rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum runs)
+    perm = {'cand': None, 'band': banded(lon), 'sorted': banded(lon, interleave=False),
+            'tiles': banded(torch.floor(orig['lat0'] / 15) * 1000 + lon)}[mode]
+    run(mode, perm)
+    sys.exit(0)
+run('candidate order', None)
 run('lon bands x8, wave w <- band w%8', banded(lon))
 run('lon-sorted, not interleaved', banded(lon, interleave=False))
 run('slot bands (12 -> 8 XCDs)', banded(orig['slot'].double() * 400 + lon))

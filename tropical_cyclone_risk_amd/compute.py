@@ -103,7 +103,13 @@ def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000):
             out['rows'] = round_fn.repack(counts[rk])
         # ---- the data-path collective: all-gather of this round's survivor records, device to device
         gathered, _ = D.allgather_rows(out['rows'], None, counts=counts)
-        got.append(gathered.clone() if W == 1 else gathered)     # one rank: a view of the round's own (reused) buffer
+        if out.get('unordered'):
+            # the round integrated its storms in locality order (pipeline.select_passed): back to candidate order — rank
+            # blocks are contiguous and ascending, so one sort of the round's few accepted rows by their candidate index
+            gathered = gathered[torch.argsort(gathered[:, width])]
+        else:
+            gathered = gathered.clone() if W == 1 else gathered     # one rank: a view of the round's own (reused) buffer
+        got.append(gathered)
         total += sum(counts)
         last = out
         if total >= n_tracks:
@@ -138,7 +144,9 @@ class GpuRound:
         self.eng = engine
         self.year = int(year)
         self.seed = experiment_seed
-        self.pipe = DevicePipeline(engine, per_rank, per_rank, tc_rows_only=True, dtype=getattr(engine.nl, 'gpu_dtype', 'f64'))
+        self.unordered = bool(getattr(engine.nl, 'gpu_locality_order', True))
+        self.pipe = DevicePipeline(engine, per_rank, per_rank, tc_rows_only=True, dtype=getattr(engine.nl, 'gpu_dtype', 'f64'),
+                                   sort_storms=self.unordered)
         # survivor records: 26 kB per accepted track.  1-6 % of a round's candidates are accepted, so the buffer is sized
         # for a quarter of them (65 536 candidates: 0.43 GB instead of 1.7) and grows — `repack` — in the round that needs more
         self.cap = max(1024, per_rank // 4)
@@ -187,7 +195,7 @@ class GpuRound:
         def hist(cutoff=None):
             keep = counted if cutoff is None else counted & (idx.double() <= cutoff)
             return torch.zeros(len(BASIN_IDS) * 12, dtype=torch.float64, device=p.dev).index_add_(0, key, keep.double())
-        return dict(rows=rows, count=p.n_accepted, bad=bad, hist=hist)
+        return dict(rows=rows, count=p.n_accepted, bad=bad, hist=hist, unordered=self.unordered)
 
 
 def rows_to_tuple(res, n_steps):

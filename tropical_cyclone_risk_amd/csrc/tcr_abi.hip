@@ -109,6 +109,7 @@ struct tcr_ctx {
     int32_t *d_tc_idx = nullptr;                // storms that passed accept test 1 (k_screen -> compaction), tc_rows_only
     size_t tc_idx_cap = 0;
     int64_t *d_tc_count = nullptr;
+    double *d_cell = nullptr; size_t cell_cap = 0; int cell_bins = 0;     // scratch of tcr_cell_order_dev
     uint8_t *d_probe = nullptr;                 // decision probe of the next tcr_integrate_dev (tcr_integrate_probe_host)
     int probe_cap = 0;
     // timing: four events per timed tcr_integrate_dev call since tcr_timing_enable(ctx, 1)
@@ -774,7 +775,7 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_mask_bits);
     (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_srec); (void)hipFree(ctx->d_vrec);
     for (auto &ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
-    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_seg_sids); (void)hipFree(ctx->d_screen_skip); (void)hipFree(ctx->d_und_list); (void)hipFree(ctx->d_und_count); (void)hipFree(ctx->d_tab);
+    (void)hipFree(ctx->d_cell); (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_seg_sids); (void)hipFree(ctx->d_screen_skip); (void)hipFree(ctx->d_und_list); (void)hipFree(ctx->d_und_count); (void)hipFree(ctx->d_tab);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -1410,6 +1411,44 @@ int tcr_compact_dev(tcr_ctx *ctx, int64_t n, const int32_t *flags, int32_t mask,
     if (tiles > 0)
         hipLaunchKernelGGL(k_compact_write, dim3((unsigned)tiles), dim3(kScanThreads), 0, st, n, flags, mask,
                            ctx->d_tiles, max_out, idx);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+int tcr_cell_order_dev(tcr_ctx *ctx, const tcr_seeds *cand, int32_t *idx, int64_t n, const int64_t *count,
+                       double cell_deg, void *stream_)
+{
+    if (!ctx) return -1;
+    if (!cand || !cand->lon0 || !cand->lat0 || !idx || n < 0) return fail(ctx, "tcr_cell_order_dev: bad argument");
+    if (!(cell_deg >= 0.25 && cell_deg <= 90.0)) return fail(ctx, "tcr_cell_order_dev: cell_deg must be in [0.25, 90]");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n == 0) return 0;
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    CellOrderArgs a{};
+    a.ncol = (int)ceil(360.0 / cell_deg);
+    const int nrow = (int)ceil(180.0 / cell_deg) + 1;
+    a.nbins = a.ncol * nrow;
+    if (a.nbins > (1 << 20)) return fail(ctx, "tcr_cell_order_dev: too many cells");
+    // scratch (int32): cell counters [nbins + 1] (zero between calls: k_cell_rank leaves them so), offsets [nbins + 1],
+    // then idx copy [n], key [n], tmp [n], tmp_key [n]
+    const size_t head = 2 * ((size_t)a.nbins + 1) + 6;
+    const size_t words = head + 4 * (size_t)n;
+    if ((words + 1) / 2 > ctx->cell_cap || ctx->cell_bins != a.nbins) {
+        if (grow(ctx, &ctx->d_cell, &ctx->cell_cap, (words + 1) / 2 + 4096)) return -1;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_cell, 0, sizeof(int32_t) * head, st));
+        ctx->cell_bins = a.nbins;
+    }
+    int32_t *w = reinterpret_cast<int32_t *>(ctx->d_cell);
+    a.hist = w; a.start = w + a.nbins + 1;
+    int32_t *body = w + head;
+    a.idx_in = body; a.key = body + n; a.tmp = body + 2 * n; a.tmp_key = body + 3 * n;
+    a.lon0 = cand->lon0; a.lat0 = cand->lat0; a.idx_out = idx; a.count = count; a.n = n;
+    a.inv_cell = 1.0 / cell_deg;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_cell_key, dim3(blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k_cell_scatter, dim3(blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_cell_rank, dim3((unsigned)((std::max<int64_t>(n, a.nbins + 1) + 255) / 256)), dim3(256), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }

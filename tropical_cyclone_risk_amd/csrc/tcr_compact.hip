@@ -135,6 +135,95 @@ __global__ __launch_bounds__(256) void k_gather_seeds(GatherSeedArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Locality order of the dense batch (round 3).  The step is bound by L2 misses on the 142 MB field set:
+// storms are drawn at random positions, so the 64 lanes of an integrator wave gather from 64 unrelated places.  Ordering
+// the selected candidates by the 2-degree cell of their genesis point (latitude row major) — a stable counting sort of the
+// index list, before the seeds are gathered, so no storm data moves — puts neighbours into the same wave: the
+// integrator's L2 misses drop by ~20 %, the 100 000-storm step by 5-7 %.  Per-storm results do not depend on the order.
+// key = row * ncol + col; bins <= 65536.
+struct CellOrderArgs {
+    const double *lon0, *lat0;       // candidate arrays (indexed by idx[])
+    int32_t *idx_in;                 // [n] scratch: the selection (ascending candidate indices), copied aside by k_cell_key
+    int32_t *idx_out;
+    const int64_t *count;            // device scalar: how many entries of idx_in are valid (may be NULL: n)
+    int64_t n;
+    double inv_cell;
+    int ncol, nbins;
+    int32_t *key;                    // [n] scratch
+    int32_t *hist;                   // [nbins + 1]: counts -> exclusive offsets (k_cell_scan) -> running cursors (k_cell_scatter)
+    int32_t *start;                  // [nbins + 1]: a copy of the exclusive offsets for k_cell_rank
+    int32_t *tmp, *tmp_key;          // [n] each: the scatter's output (cell-grouped, unordered inside a cell) and its keys
+};
+
+__device__ __forceinline__ int64_t cell_n(const CellOrderArgs &a) { return (a.count && *a.count < a.n) ? *a.count : a.n; }
+
+__global__ __launch_bounds__(256) void k_cell_key(CellOrderArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= cell_n(a)) return;
+    const int32_t c = a.idx_out[i];                   // the selection as tcr_compact_dev left it (in place: idx_out == the list)
+    a.idx_in[i] = c;                                  // ... copied aside: the ranked result overwrites the list
+    double lo = a.lon0[c], la = a.lat0[c];
+    lo = lo - 360.0 * floor(lo / 360.0);
+    int col = (int)(lo * a.inv_cell), row = (int)((la + 90.0) * a.inv_cell);
+    const int nrow = a.nbins / a.ncol;
+    col = col < 0 ? 0 : (col >= a.ncol ? a.ncol - 1 : col);
+    row = row < 0 ? 0 : (row >= nrow ? nrow - 1 : row);
+    const int k = (lo == lo && la == la) ? row * a.ncol + col : 0;          // (a NaN position: cell 0)
+    a.key[i] = k;
+    atomicAdd(a.hist + k, 1);
+}
+
+// exclusive scan of the cell counts by one workgroup: every thread owns a contiguous run of cells, the 1024 run totals are
+// scanned once in LDS
+__global__ __launch_bounds__(1024) void k_cell_scan(CellOrderArgs a)
+{
+    __shared__ int s[1024];
+    const int per = (a.nbins + 1023) / 1024;
+    const int b0 = threadIdx.x * per, b1 = min(b0 + per, a.nbins);
+    int sum = 0;
+    for (int b = b0; b < b1; ++b) sum += a.hist[b];
+    s[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+        __syncthreads();
+        s[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = s[threadIdx.x] - sum;                   // exclusive offset of this thread's first cell
+    for (int b = b0; b < b1; ++b) { const int v = a.hist[b]; a.hist[b] = run; a.start[b] = run; run += v; }
+    if (threadIdx.x == 1023) { a.hist[a.nbins] = s[1023]; a.start[a.nbins] = s[1023]; }
+}
+
+__global__ __launch_bounds__(256) void k_cell_scatter(CellOrderArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= cell_n(a)) return;
+    const int k = a.key[i];
+    const int pos = atomicAdd(a.hist + k, 1);
+    a.tmp[pos] = a.idx_in[i];
+    a.tmp_key[pos] = k;
+}
+
+// The atomic scatter leaves a cell's entries in arbitrary order.  One thread per entry ranks it inside its cell's (short)
+// segment — independent loads of neighbouring words — and writes it to its final place, so that the result is THE stable
+// sort: the dense order, and with it every row-by-row comparison between two runs, is deterministic.  The same launch
+// zeroes the cell counters for the next call (nothing reads them here).
+__global__ __launch_bounds__(256) void k_cell_rank(CellOrderArgs a)
+{
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p <= a.nbins) a.hist[p] = 0;
+    if (p >= cell_n(a)) return;
+    const int k = a.tmp_key[p];
+    const int lo = a.start[k], hi = a.start[k + 1];
+    const int32_t v = a.tmp[p];
+    int r = lo;
+    for (int q = lo; q < hi; ++q) r += (a.tmp[q] < v) ? 1 : 0;
+    a.idx_out[r] = v;
+}
+
 // Sums over a finished batch (throughput accounting / round control): one atomic per workgroup.
 __global__ __launch_bounds__(256) void k_stats(int64_t n, const int64_t *__restrict__ n_dev, const int32_t *__restrict__ n_valid,
                                                const int32_t *__restrict__ nfev, const int32_t *__restrict__ flags,
