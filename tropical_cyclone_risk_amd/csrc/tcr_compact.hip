@@ -175,26 +175,41 @@ __global__ __launch_bounds__(256) void k_cell_key(CellOrderArgs a)
     atomicAdd(a.hist + k, 1);
 }
 
-// exclusive scan of the cell counts by one workgroup: every thread owns a contiguous run of cells, the 1024 run totals are
-// scanned once in LDS
+// exclusive scan of the cell counts by one workgroup: the counts are staged in LDS with coalesced loads (cells beyond the
+// LDS window are handled in further rounds with a carry), every thread owns a contiguous run of 16 cells, and the 1024 run
+// totals are scanned once per round
+constexpr int kCellScanRun = 16;
+constexpr int kCellScanWin = 1024 * kCellScanRun;
 __global__ __launch_bounds__(1024) void k_cell_scan(CellOrderArgs a)
 {
+    __shared__ int v[kCellScanWin];
     __shared__ int s[1024];
-    const int per = (a.nbins + 1023) / 1024;
-    const int b0 = threadIdx.x * per, b1 = min(b0 + per, a.nbins);
-    int sum = 0;
-    for (int b = b0; b < b1; ++b) sum += a.hist[b];
-    s[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+    int carry = 0;
+    for (int base = 0; base < a.nbins; base += kCellScanWin) {
+        for (int i = threadIdx.x; i < kCellScanWin; i += 1024) v[i] = (base + i < a.nbins) ? a.hist[base + i] : 0;
         __syncthreads();
-        s[threadIdx.x] += t;
+        int sum = 0;
+#pragma unroll
+        for (int j = 0; j < kCellScanRun; ++j) sum += v[threadIdx.x * kCellScanRun + j];
+        s[threadIdx.x] = sum;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        int run = carry + s[threadIdx.x] - sum;          // exclusive offset of this thread's first cell
+#pragma unroll
+        for (int j = 0; j < kCellScanRun; ++j) { const int c = v[threadIdx.x * kCellScanRun + j]; v[threadIdx.x * kCellScanRun + j] = run; run += c; }
+        const int total = s[1023];
+        __syncthreads();
+        for (int i = threadIdx.x; i < kCellScanWin; i += 1024)
+            if (base + i < a.nbins) { a.hist[base + i] = v[i]; a.start[base + i] = v[i]; }
+        carry += total;
         __syncthreads();
     }
-    int run = s[threadIdx.x] - sum;                   // exclusive offset of this thread's first cell
-    for (int b = b0; b < b1; ++b) { const int v = a.hist[b]; a.hist[b] = run; a.start[b] = run; run += v; }
-    if (threadIdx.x == 1023) { a.hist[a.nbins] = s[1023]; a.start[a.nbins] = s[1023]; }
+    if (threadIdx.x == 0) { a.hist[a.nbins] = carry; a.start[a.nbins] = carry; }
 }
 
 __global__ __launch_bounds__(256) void k_cell_scatter(CellOrderArgs a)
