@@ -229,7 +229,7 @@ def main():
     # HIP-event time of every kernel of the timed region, summed over launches and streams (overlapping
     # streams make this exceed the wall time; it shows the GPU was busy even when SMI sampling misses a 50 ms region)
     gpu_active_s = (ms['fourier_ms'] + ms['integrate_ms'] + ms['post_ms']) * 1e-3
-    traffic, traffic_src = (args.traffic, 'command line') if args.traffic is not None else measured_traffic('k_integrate', B, args.rows, args.dtype)
+    traffic, traffic_src = (args.traffic, 'command line') if args.traffic is not None else measured_traffic('k_integrate', B, args.rows, args.dtype, args.order)
     # Exclusive duration: the same launch, one batch at a time on one stream right after the timed region
     # (3 batches).  With several streams the event-bracketed duration of a launch in the timed region
     # includes time it shared the GPU with other batches (it can exceed ms_per_step), so that figure is
@@ -238,7 +238,7 @@ def main():
     ib = BYTES_PER_RHS * iso_counts[1] / iso['calls']
     eb = BYTES_PER_SAMPLE * (iso_counts[5] if args.rows == 'tc' else iso_counts[2]) / iso['calls']
     achieved = ib / (ik * 1e-3) / 1e9
-    e_traffic, e_src = measured_traffic('k_emit', B, args.rows, args.dtype)
+    e_traffic, e_src = measured_traffic('k_emit', B, args.rows, args.dtype, args.order)
     roof = dict(bound='hbm', kernel='k_integrate', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
                 frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                 note='a launch = the chain of k_integrate passes of one batch (tail compaction); achieved = %d B x RHS ' % BYTES_PER_RHS +
@@ -274,7 +274,7 @@ def main():
     # factor calibrated on this access pattern) over the measured time per step.  Reducing the integrator's SIMD time (lane
     # utilisation 0.73 -> 0.91) does not move the step, removing the forcing table's traffic does:
     # the step sits at ~0.9 of what scattered 128-byte line fills reach on this chip (tools/calibrate_fetch.hip: 4.26 TB/s).
-    step_bytes, step_src = measured_traffic('*', B, args.rows, args.dtype) if not strong else (None, None)
+    step_bytes, step_src = measured_traffic('*', B, args.rows, args.dtype, args.order) if not strong else (None, None)
     if step_bytes and world == 1:
         gbs = step_bytes / (dt / args.steps) / 1e9
         roof['whole_step'] = dict(traffic=step_bytes, traffic_source=step_src, achieved=gbs, unit='GB/s', peak=HBM_PEAK_GBS,
@@ -328,7 +328,7 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def measured_traffic(kernel, storms, rows, dtype='f64'):
+def measured_traffic(kernel, storms, rows, dtype='f64', order='cells'):
     """(HBM bytes per batch, source) of a kernel from the committed rocprofv3 --pmc runs of this same workload
     (tools/collect_profiles.sh; counters are collected in separate passes from timing, as MI355X_MICROARCH.md
     prescribes, so they cannot be measured inside this process).  Only valid for the profiled size."""
@@ -337,7 +337,7 @@ def measured_traffic(kernel, storms, rows, dtype='f64'):
         return None, None
     try:
         d = json.load(open(fn))
-        if d.get('rows') != rows:
+        if d.get('rows') != rows or d.get('order', 'cells') != order:
             return None, None
         if kernel == '*':          # every kernel of a step
             return d['step_total']['hbm_bytes_per_batch'], 'profiles/r03_pmc_hbm.json: sum over the kernels of a step'

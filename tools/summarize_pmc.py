@@ -66,5 +66,5 @@ meta = dict(workload='GL, 100000 storms per batch; the first batch of each run p
                  'line once, 4x the Infinity Cache): 1.9986; streaming reads 2.0000.  WRITE_SIZE is exact for coalesced stores (1 GiB fill) '
                  'and over-reports scattered 112-of-128-B line writes by 1.24x.  *_raw = FETCH_SIZE + WRITE_SIZE uncorrected.  '
                  'Infinity-Cache hits are counted, so this is fabric-side traffic.')
-print(json.dumps(dict(command=command, rows=rows, meta=meta, step_total=dict(hbm_bytes_per_batch=tot, hbm_bytes_per_batch_raw=tot_raw,
+print(json.dumps(dict(command=command, rows=rows, order='cells', meta=meta, step_total=dict(hbm_bytes_per_batch=tot, hbm_bytes_per_batch_raw=tot_raw,
                                                                           note='sum over the tcr:: kernels of one bench step'), kernels=res), indent=1))
