@@ -12,8 +12,8 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 # 1. the bench line itself (default flags, as the driver runs it)
 timeout 900 python bench.py --rows $ROWS > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 600 "$OUT/bench.json"
-# 2. per-kernel timing, one stream and the default four
-for s in 1 4; do
+# 2. per-kernel timing, one stream and the default eight
+for s in 1 8; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats$s" -o s -- \
       python bench.py --steps 10 --warmup 2 --streams $s --rows $ROWS --no-cpu-baseline > /dev/null 2>&1
   cp "$(find "$OUT/stats$s" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_streams$s.csv"
