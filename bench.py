@@ -117,7 +117,7 @@ def main():
         B = int(args.storms / world * 1.25) + 2048                             # capacity: 25 % + 2048 over the expected count
     else:
         C = int(B / max(p_pass, 1e-3) * 1.15) + 4096
-    pipes = [DevicePipeline(e, C, B, sort_storms=(args.order == 'cells'), tc_rows_only=(args.rows == 'tc'), dtype=args.dtype) for e in engs]
+    pipes = [DevicePipeline(e, C, B, sort_storms=(float(os.environ.get('TCR_CELL_DEG', '2')) if args.order == 'cells' else False), tc_rows_only=(args.rows == 'tc'), dtype=args.dtype) for e in engs]
     global BYTES_PER_RHS, BYTES_PER_SAMPLE
     if args.dtype == 'f32':
         BYTES_PER_RHS, BYTES_PER_SAMPLE = 352.0, 260.0          # SURVEY.md §8d, fp32 mode
