@@ -301,3 +301,22 @@ def test_locality_order_is_a_stable_sort_and_changes_no_storm(golden_env, built_
             assert np.array_equal(b[k], a[k][back], equal_nan=True), (tag, k)
         for k in ('status', 'n_valid', 'nfev', 'flags', 'n_accept', 'n_reject'):
             assert np.array_equal(b[k], a[k][back]), (tag, k)
+
+
+def test_run_tracks_is_independent_of_the_batch_order(golden_env, built_lib):
+    """namelist.gpu_locality_order: run_tracks integrates a round's storms ordered by genesis cell and sorts the accepted rows
+    back by candidate index — the 9-tuple, the kept candidates and n_seeds are those of candidate order, bit for bit."""
+    from tropical_cyclone_risk_amd import compute
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    outs = {}
+    for flag in (True, False):
+        nl = _nl(gpu_locality_order=flag)
+        eng = TCEngine('GL', device=0, nl=nl).stage_env(golden_env)
+        info = {}
+        outs[flag] = (compute.run_tracks(2009, 150, 'GL', engine=eng, nl=nl, per_rank=3000, info=info), info)
+        eng.close()
+    (a, ia), (b, ib) = outs[True], outs[False]
+    assert ia['rounds'] == ib['rounds'] >= 2 and np.array_equal(ia['cand'], ib['cand']) and (np.diff(ia['cand']) > 0).all()
+    for x, y in zip(a[:7], b[:7]):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert list(a[7]) == list(b[7]) and np.array_equal(a[8], b[8])
