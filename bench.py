@@ -11,14 +11,19 @@ vmax and accept flags (compute.py:176-209), and — for N > 1 — the RCCL all-g
 of the accepted tracks of that batch.  `value` is storm-steps of all ranks / wall
 time of the K steps.
 
---scaling weak (default): per-GPU work is fixed — B storms per rank and step.
---scaling strong (BASELINE config 4 as worded: "100k storms sharded across 8 GPUs"):
-the ENSEMBLE is fixed — one step = one ensemble drawn from a fixed block of candidates
+--scaling strong (default; BASELINE's metric and config 4 as worded: "storm-steps/sec (100k-storm ensemble) at 1/2/4/8
+MI355X", "100k storms sharded across 8 GPUs"): the ENSEMBLE is fixed — one step = one ensemble drawn from a fixed block of candidates
 (sized so that ~B seeds pass), the candidate block sharded over the ranks as
 `compute.run_tracks` shards a round; every rank integrates all the passing seeds of
 its sub-block, and the accepted tracks of the ensemble are all-gathered once.  The set
 of storms of an ensemble does not depend on the number of ranks, so the storm-step
-total of a run is bit-for-bit the same at every N (tests/test_seeding.py checks 1 vs 2).
+total of a run is bit-for-bit the same at every N (tests/test_seeding.py checks 1 vs 2).  At N = 1 this is the same
+100 000-storm step as --scaling weak.
+--scaling weak: per-GPU work is fixed — B storms per rank and step, every step's accepted tracks all-gathered.
+
+A step is ONE library call per rank (tcr_round_dev: seed → select → locality order → forcing table → integrate →
+post-processing → stats [→ select accepted → pack]); --graph replays it from a captured hipGraph (default: for batches
+of fewer than 50 000 storms per rank, where the host's launch rate is what bounds the step).
 
 A storm-step is one hourly output interval of one live storm.
 Inputs (fields) are resident in HBM before the timed region; candidates are drawn
@@ -36,6 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0      # MI355X_MICROARCH.md: ~6.3 TB/s achievable
 BYTES_PER_RHS = 704.0            # 20 lookups x 4 corners x 8 B + Fs 64 B
 BYTES_PER_SAMPLE = 520.0         # 14 lookups x 32 B + 9 outputs x 8 B
 
@@ -47,7 +53,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--storms', type=int, default=100_000, help='weak: storms integrated per GPU per step; strong: storms per '
                                                                 'ensemble (= per step), sharded over the GPUs')
-    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='strong')
+    ap.add_argument('--graph', choices=('auto', 'on', 'off'), default='auto',
+                    help='replay every step from a captured hipGraph (tcr_round_dev use_graph); auto: when a rank integrates '
+                         'fewer than 50 000 storms per step')
+    ap.add_argument('--staged', action='store_true', help="round 3's step: one library call per stage instead of tcr_round_dev")
     ap.add_argument('--basin', default='GL')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--order', choices=('cells', 'candidate'), default='cells',
@@ -123,8 +133,10 @@ def main():
         BYTES_PER_RHS, BYTES_PER_SAMPLE = 352.0, 260.0          # SURVEY.md §8d, fp32 mode
     pipe = pipes[0]
 
-    # storm-steps, nfev, samples, accepted, is_tc, is_tc samples, rounds with < B passing seeds, storms (tcr_stats_dev)
-    acc = torch.zeros(8, dtype=torch.int64, device=dev)
+    # storm-steps, nfev, samples, accepted, is_tc, is_tc samples, rounds with < B passing seeds, storms, step-record overflows,
+    # passing seeds a batch had no room for (tcr_stats_dev)
+    acc = torch.zeros(10, dtype=torch.int64, device=dev)
+    use_graph = args.graph == 'on' or (args.graph == 'auto' and B < 50_000)
     row = 9 * ns
     # N > 1: all-gather of every batch's final (accepted) tracks through distributed.DeferredRowGather:
     # nothing in a step waits on the host — batch k's count is read back only when batch k + n_str is
@@ -136,17 +148,26 @@ def main():
         with torch.cuda.stream(streams[k % n_str]):
             _step(k, pipes[k % n_str])
 
-    def _step(k, pipe):
+    def _step(k, pipe, graph=None):
         # warm-up steps run exactly the same code; the accumulators are zeroed after them
-        pipe.seed_round(year, D.round_block(k, C, rank, world))        # = k * C * world + rank * C
-        pipe.select_passed(B)
-        pipe.integrate(B, n_dev=pipe.n_passed if strong else None)
-        pipe.add_stats(acc, n_dev=pipe.n_passed)
-        if gather is not None:
-            buf = gather.buffer()                # waits (on this stream) for the gather that last read it
-            pipe.select_accepted()
-            pipe.pack_accepted(buf, cap)
+        graph = use_graph if graph is None else graph
+        cand0 = D.round_block(k, C, rank, world)                       # = k * C * world + rank * C
+        if args.staged:
+            pipe.seed_round(year, cand0)
+            pipe.select_passed(B)
+            pipe.integrate(B, n_dev=pipe.n_passed if strong else None)
+            pipe.add_stats(acc, n_dev=pipe.n_passed)
+            if gather is not None:
+                buf = gather.buffer()                # waits (on this stream) for the gather that last read it
+                pipe.select_accepted()
+                pipe.pack_accepted(buf, cap)
+                gather.submit(pipe.n_accepted)
+        elif gather is not None:
+            buf = gather.buffer()
+            pipe.round(year, cand0, C, B, exact_count=strong, stats=acc, accepted=True, packed=buf, pack_cap=cap, graph=graph)
             gather.submit(pipe.n_accepted)
+        else:
+            pipe.round(year, cand0, C, B, exact_count=strong, stats=acc, graph=graph)
 
     def drain():
         if gather is not None:
@@ -183,7 +204,7 @@ def main():
             for kk in tot:
                 tot[kk] += m1[kk]
         return tot
-    ms = sum_timings()
+    ms = sum_timings()              # (calls == 0 when the steps were graph replays: those record no events)
     # SIMD time of the integrator chains as they ran INSIDE the timed region (the last batch of every stream: wave residency
     # summed from the waves' own wall-clock stamps): under load the waves of several batches share the CUs' address paths,
     # so this is what a chain costs the pipeline; `integrate_passes` below is the same for an isolated batch
@@ -198,7 +219,7 @@ def main():
             e.timing_enable(True)
         for k in range(w_eff + args.steps, w_eff + args.steps + 3):
             with torch.cuda.stream(streams[0]):
-                _step(k, pipes[0])
+                _step(k, pipes[0], graph=False)          # direct enqueue: the library's timing events are recorded
             torch.cuda.synchronize()
         iso = sum_timings()
         iso_counts = (acc - acc_keep).tolist()
@@ -206,15 +227,15 @@ def main():
         iso_passes = engs[0].pass_stats()
     if world > 1:
         D.allreduce_sum_(acc)
-    steps_total, nfev_total, samples_total, accepted_total, tc_total, tc_samples_total, n_short, storms_total = (float(x) for x in acc.tolist())
+    (steps_total, nfev_total, samples_total, accepted_total, tc_total, tc_samples_total, n_short, storms_total, n_overflow,
+     n_dropped) = (float(x) for x in acc.tolist())
     emitted_total = tc_samples_total if args.rows == 'tc' else samples_total     # samples k_emit actually produced
     n_short = int(n_short)
+    # every passing seed of every sub-block of every step must have fitted its rank's capacity (else storms were dropped):
+    # counted on the device by every step's stats kernel (acc[9]), summed over the ranks above
     if strong:
-        # every passing seed of every sub-block must have fitted its rank's capacity (else storms were dropped)
-        over = torch.tensor([max(int(p.n_passed.item()) for p in pipes) > B], dtype=torch.int64, device=dev)
-        if world > 1:
-            D.allreduce_sum_(over)
-        assert int(over.item()) == 0, 'strong scaling: a rank had more passing seeds than its capacity'
+        assert int(n_dropped) == 0, 'strong scaling: %d passing seeds did not fit a rank\'s batch capacity' % int(n_dropped)
+    assert int(n_overflow) == 0, '%d storms overflowed their step record (tcr_params.max_rk_steps)' % int(n_overflow)
     value = steps_total / dt
 
     # ---- roofline of the dominant kernel (k_integrate): algorithmic bytes per launch
@@ -222,14 +243,19 @@ def main():
     # (events recorded on the launch stream by the library).  The per-sample share of the
     # algorithmic bytes (520 B x output samples) is k_emit's and is reported next to it.
     launches = ms['calls']
-    k_ms = ms['integrate_ms'] / launches
-    e_ms = ms['post_ms'] / launches
-    int_bytes = BYTES_PER_RHS * nfev_total / (launches * world)
-    emit_bytes = BYTES_PER_SAMPLE * emitted_total / (launches * world)
+    have_events = launches > 0
+    if have_events:
+        k_ms = ms['integrate_ms'] / launches
+        e_ms = ms['post_ms'] / launches
+        int_bytes = BYTES_PER_RHS * nfev_total / (launches * world)
     # HIP-event time of every kernel of the timed region, summed over launches and streams (overlapping
-    # streams make this exceed the wall time; it shows the GPU was busy even when SMI sampling misses a 50 ms region)
-    gpu_active_s = (ms['fourier_ms'] + ms['integrate_ms'] + ms['post_ms']) * 1e-3
-    traffic, traffic_src = (args.traffic, 'command line') if args.traffic is not None else measured_traffic('k_integrate', B, args.rows, args.dtype, args.order)
+    # streams make this exceed the wall time; it shows the GPU was busy even when SMI sampling misses a 50 ms region).
+    # Graph replays record no events: the figure is then the isolated batches' kernel time x the timed steps.
+    if have_events:
+        gpu_active_s = (ms['fourier_ms'] + ms['integrate_ms'] + ms['post_ms']) * 1e-3
+    else:
+        gpu_active_s = (iso['fourier_ms'] + iso['integrate_ms'] + iso['post_ms']) / iso['calls'] * args.steps * 1e-3
+    traffic, traffic_src = (args.traffic, 'command line') if args.traffic is not None else measured_traffic('k_integrate', args.storms if world == 1 else B, args.rows, args.dtype, args.order)
     # Exclusive duration: the same launch, one batch at a time on one stream right after the timed region
     # (3 batches).  With several streams the event-bracketed duration of a launch in the timed region
     # includes time it shared the GPU with other batches (it can exceed ms_per_step), so that figure is
@@ -238,7 +264,7 @@ def main():
     ib = BYTES_PER_RHS * iso_counts[1] / iso['calls']
     eb = BYTES_PER_SAMPLE * (iso_counts[5] if args.rows == 'tc' else iso_counts[2]) / iso['calls']
     achieved = ib / (ik * 1e-3) / 1e9
-    e_traffic, e_src = measured_traffic('k_emit', B, args.rows, args.dtype, args.order)
+    e_traffic, e_src = measured_traffic('k_emit', args.storms if world == 1 else B, args.rows, args.dtype, args.order)
     roof = dict(bound='hbm', kernel='k_integrate', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
                 frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                 note='a launch = the chain of k_integrate passes of one batch (tail compaction); achieved = %d B x RHS ' % BYTES_PER_RHS +
@@ -246,10 +272,11 @@ def main():
                      'stream, after the timed region); profiles/ lists k_integrate once per pass',
                 algorithmic_bytes_per_launch=ib, launch_ms=ik,
                 kernel_ms=dict(fourier=iso['fourier_ms'] / iso['calls'], integrate=ik, post=ie),
-                pipelined_events=dict(note='event-bracketed durations inside the timed region, %d streams overlapping' % n_str,
-                                      launch_ms=k_ms, achieved=int_bytes / (k_ms * 1e-3) / 1e9,
-                                      frac=int_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                      kernel_ms=dict(fourier=ms['fourier_ms'] / launches, integrate=k_ms, post=e_ms)),
+                pipelined_events=(dict(note='event-bracketed durations inside the timed region, %d streams overlapping' % n_str,
+                                       launch_ms=k_ms, achieved=int_bytes / (k_ms * 1e-3) / 1e9,
+                                       frac=int_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       kernel_ms=dict(fourier=ms['fourier_ms'] / launches, integrate=k_ms, post=e_ms))
+                                  if have_events else None),
                 sustained=dict(note='algorithmic bytes of all k_integrate launches / wall time of the timed region',
                                achieved=BYTES_PER_RHS * nfev_total / world / dt / 1e9,
                                frac=BYTES_PER_RHS * nfev_total / world / dt / 1e9 / HBM_PEAK_GBS),
@@ -274,14 +301,23 @@ def main():
     # factor calibrated on this access pattern) over the measured time per step.  Reducing the integrator's SIMD time (lane
     # utilisation 0.73 -> 0.91) does not move the step, removing the forcing table's traffic does:
     # the step sits at ~0.9 of what scattered 128-byte line fills reach on this chip (tools/calibrate_fetch.hip: 4.26 TB/s).
-    step_bytes, step_src = measured_traffic('*', B, args.rows, args.dtype, args.order) if not strong else (None, None)
+    # BASELINE.md section 3's figure for the whole step, from the one driver-timed number: algorithmic bytes of everything the
+    # timed region did — 704 B x RHS evaluations + 520 B x samples emitted — over its wall time, against the 8 TB/s peak
+    alg_gbs = (BYTES_PER_RHS * nfev_total + BYTES_PER_SAMPLE * emitted_total) / world / dt / 1e9
+    roof['step_algorithmic'] = dict(achieved=alg_gbs, unit='GB/s', peak=HBM_PEAK_GBS, frac=alg_gbs / HBM_PEAK_GBS,
+                                    note='(%d B x RHS evaluations + %d B x emitted samples) of the timed region / its wall time, per GPU'
+                                         % (BYTES_PER_RHS, BYTES_PER_SAMPLE))
+    step_bytes, step_src = measured_traffic('*', args.storms, args.rows, args.dtype, args.order) if world == 1 else (None, None)
     if step_bytes and world == 1:
         gbs = step_bytes / (dt / args.steps) / 1e9
+        ceil_gbs, ceil_src = scattered_line_fill_ceiling()
         roof['whole_step'] = dict(traffic=step_bytes, traffic_source=step_src, achieved=gbs, unit='GB/s', peak=HBM_PEAK_GBS,
-                                  frac=gbs / HBM_PEAK_GBS, scattered_line_fill_ceiling=4260.0,
-                                  frac_of_scattered_line_fill_ceiling=gbs / 4260.0,
+                                  frac=gbs / HBM_PEAK_GBS, achievable=HBM_ACHIEVABLE_GBS, frac_of_achievable=gbs / HBM_ACHIEVABLE_GBS,
+                                  scattered_line_fill_ceiling=ceil_gbs, scattered_line_fill_ceiling_source=ceil_src,
+                                  frac_of_scattered_line_fill_ceiling=(gbs / ceil_gbs) if ceil_gbs else None,
                                   note='fabric-side traffic (L2 misses incl. Infinity-Cache hits) of every kernel of a step / ms_per_step; '
-                                       'ceiling = 1 GiB of 128-B lines gathered once each, 7 x 16 B per lane (profiles/r03_fetch_calibration*)')
+                                       'achievable = MI355X_MICROARCH.md (~6.3 TB/s of the 8 TB/s peak); the line-fill ceiling is this '
+                                       "project's own calibration run (1 GiB of 128-B lines gathered once each, 7 x 16 B per lane)")
     simds_ = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
     pw = [sum(p['wave_ms'] for p in ps) for ps in pipe_passes if ps]
     if pw:
@@ -313,6 +349,10 @@ def main():
                        'storms_per_gpu': storms_total / (args.steps * world), 'candidates_per_round': C, 'seed_pass_rate': p_pass,
                        'n_steps_out': ns, 'rounds_short_of_storms': None if strong else n_short, 'streams': n_str,
                        'hw_queues': int(os.environ.get('GPU_MAX_HW_QUEUES', '4')),
+                       'step_call': 'staged (one library call per stage)' if args.staged else ('tcr_round_dev, replayed from a hipGraph' if use_graph else 'tcr_round_dev, direct enqueue'),
+                       'graph_replays': sum(p.graph_stats()['replays'] for p in pipes),
+                       'allgather': ('accepted tracks of every %s all-gathered once (26 kB records, RCCL, one collective per step, '
+                                     '%d steps behind compute)' % ('ensemble' if strong else 'step', n_str)) if world > 1 else 'none (one GPU)',
                        'warmup_effective': w_eff,
                        'storm_steps_per_storm': steps_total / storms_total,
                        'rhs_per_storm_step': nfev_total / max(steps_total, 1),
@@ -326,6 +366,21 @@ def main():
     if world > 1:
         D.barrier()
         torch.distributed.destroy_process_group()
+
+
+def scattered_line_fill_ceiling():
+    """(GB/s, source) that scattered 128-byte line fills reached in this project's calibration run: true bytes of
+    `cal_gather_line` (profiles/r03_fetch_calibration.json) over its average duration in the rocprofv3 kernel statistics of
+    the same run (profiles/r03_fetch_calibration_kernel_stats.csv).  (None, None) when the files are missing."""
+    import csv
+    try:
+        cal = json.load(open(os.path.join(ROOT, 'profiles', 'r03_fetch_calibration.json')))['kernels']['cal_gather_line']
+        for row in csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r03_fetch_calibration_kernel_stats.csv'))):
+            if row['Name'].startswith('cal_gather_line'):
+                return cal['true_bytes'] / float(row['AverageNs']), 'profiles/r03_fetch_calibration{.json,_kernel_stats.csv}: cal_gather_line'
+    except Exception:
+        pass
+    return None, None
 
 
 def measured_traffic(kernel, storms, rows, dtype='f64', order='cells'):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TCR_ABI_VERSION 4
+#define TCR_ABI_VERSION 5
 #define TCR_NW 4            /* ua250, va250, ua850, va850  (track/env_wind.py:22-26) */
 #define TCR_NCOV 10         /* packed lower triangle (0,0),(1,0),(1,1),(2,0)..(3,3) (env_wind.py:31-42) */
 #define TCR_MAX_SERIES 32
@@ -234,9 +234,14 @@ int tcr_gather_seeds_dev(tcr_ctx *ctx, const tcr_seeds *src_dev, const int32_t *
  * (sum of max(n_valid-1, 0)), [1] = RHS evaluations, [2] = output samples, [3] = accepted tracks,
  * [4] = storms that passed accept test 1 (is_tc), [5] = output samples of those storms (the rows
  * tc_rows_only produces), [6] = 1 if *n_dev < n (the batch was short of storms: a round control signal that
- * needs no host round trip), [7] = storms counted (min(n, *n_dev)); the EIGHT uint64 counters are ADDED to
- * (zero them first). */
-int tcr_stats_dev(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const tcr_tracks *tracks_dev, uint64_t *out_dev, void *stream);
+ * needs no host round trip), [7] = storms counted (min(n, *n_dev)), [8] = storms whose step record overflowed
+ * (status TCR_STATUS_STEP_OVERFLOW), [9] = storms the batch had no room for (max(*n_dev - n, 0): passing seeds that
+ * tcr_compact_dev clipped).  The counters are uint64 and are ADDED to (zero them first).  n_out is the capacity of
+ * out_dev in words — 6, 8 or 10 (TCR_N_STATS): only counters below it are written (ABI v5; v4 wrote eight through an
+ * unsized pointer). */
+#define TCR_N_STATS 10
+int tcr_stats_dev(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const tcr_tracks *tracks_dev, uint64_t *out_dev,
+                  int32_t n_out, void *stream);
 /* survivor records for the all-gather of final tracks (compute.py:233-242 concatenation):
  * packed[r] = { lon[ns], lat[ns], v[ns], m[ns], vmax[ns], envw[ns][4] } of track idx[r],
  * r < min(*count_dev, cap); rows are row_stride doubles apart (0 = 9 * ns; larger leaves room for the
@@ -246,6 +251,61 @@ int tcr_pack_tracks_dev(tcr_ctx *ctx, const tcr_tracks *src_dev, const int32_t *
 /* the same from fp32 rows; the packed records are fp64 (the 9-tuple is float64 like the reference's) */
 int tcr_pack_tracks_f32_dev(tcr_ctx *ctx, const tcr_tracks_f32 *src_dev, const int32_t *idx_dev,
                             const int64_t *count_dev, int64_t cap, double *packed_dev, int64_t row_stride, void *stream);
+/* tcr_pack_tracks_dev with the three columns run_tracks keeps next to a track's rows (compute.py:206-208) appended to
+ * every record — packed[r][9*ns + 0..2] = global candidate index (cand0 + cand_idx[j], cand_idx NULL: cand0 + j), month
+ * (slot[j] + 1), genesis-basin index (basin_idx[j]) of dense-batch row j = idx[r]; row_stride >= 9*ns + 3.  `f32` != 0:
+ * src_dev is a tcr_tracks_f32. */
+int tcr_pack_tracks_meta_dev(tcr_ctx *ctx, const tcr_tracks *src_dev, int32_t f32, const int32_t *idx_dev,
+                             const int64_t *count_dev, int64_t cap, double *packed_dev, int64_t row_stride,
+                             const int32_t *cand_idx_dev, const int32_t *slot_dev, const int32_t *basin_idx_dev,
+                             int64_t cand0, void *stream);
+/* replaces: `n_seeds[basin_idx, month - 1] += 1` (compute.py:165-167) for a finished round of candidates: out_dev[7][12]
+ * (int64, SET) = candidates [cand0, cand0 + cand_dev->n) that count toward n_seeds (seed_flags bit 0) per (genesis basin,
+ * month); with cutoff_dev (device scalar, a candidate index held as a double as the survivor records hold it) only the
+ * candidates with global index <= *cutoff_dev — the candidate that completed the quota. */
+int tcr_seed_hist_dev(tcr_ctx *ctx, const tcr_seeds *cand_dev, int64_t cand0, const double *cutoff_dev,
+                      int64_t *out_dev, void *stream);
+
+/* ---- one round of the accept loop in one call ------------------------------------------------------------------ */
+/* replaces: one pass of the body of run_tracks' `while nt < n_tracks` loop (compute.py:134-209) over a block of
+ * candidates — and, one level up, the fan-out of run_downscaling (compute.py:223-242), which hands run_tracks calls to
+ * dask workers: here a round is ONE library call that enqueues
+ *     tcr_seed_dev -> tcr_compact_dev (seeds that passed) -> tcr_cell_order_dev -> tcr_gather_seeds_dev ->
+ *     tcr_integrate[_f32]_dev -> tcr_stats_dev -> tcr_compact_dev (accepted tracks) -> tcr_pack_tracks_meta_dev ->
+ *     tcr_seed_hist_dev
+ * on `stream`, with nothing returning to the host in between; every stage is optional through a NULL buffer.  The results
+ * are exactly those of the separate calls (the same kernels in the same order).  All pointers are device memory and the
+ * caller owns them; they must stay valid until the stream has run the round. */
+typedef struct {
+    int64_t n_cand;             /* candidates of the round: [cand0, cand0 + n_cand) */
+    int64_t n_storms;           /* capacity of the dense batch: the first n_storms passing seeds are integrated */
+    tcr_seeds cand;             /* [n_cand] candidate arrays (cand.n is ignored; phases may be NULL, see tcr_seed_dev) */
+    tcr_seeds storms;           /* [n_storms] the dense batch (storms.n is ignored) */
+    int32_t *cand_idx;          /* [n_storms] position in the candidate block of every dense-batch storm */
+    int64_t *n_passed;          /* [1] seeds that passed (may exceed n_storms) */
+    double cell_deg;            /* > 0: dense batch in locality order (tcr_cell_order_dev); 0: candidate order */
+    int32_t exact_count;        /* 1: integrate min(n_storms, *n_passed) storms (tcr_storms.n_dev); 0: the caller sized the
+                                   round so that n_storms seeds pass (short rounds show in stats[6]) */
+    int32_t f32;                /* 1: `tracks` is a tcr_tracks_f32 (tcr_integrate_f32_dev) */
+    tcr_tracks tracks;          /* [n_storms] outputs */
+    uint64_t *stats;            /* [TCR_N_STATS] added to (tcr_stats_dev), or NULL */
+    int32_t *acc_idx;           /* [n_storms] dense-batch rows of the accepted tracks, or NULL (then no packing) */
+    int64_t *n_accepted;        /* [1] */
+    double *packed;             /* [pack_cap][pack_stride] survivor records (tcr_pack_tracks_dev; with the meta columns of
+                                   tcr_pack_tracks_meta_dev when pack_stride >= 9 * n_steps + 3), or NULL */
+    int64_t pack_cap, pack_stride;
+    int64_t *seed_hist;         /* [7][12] the round's n_seeds contribution (tcr_seed_hist_dev, no cutoff), or NULL */
+} tcr_round;
+/* use_graph != 0: the round is captured into a hipGraph the first time a (ctx, descriptor) pair is seen and replayed from
+ * then on — one graph launch instead of ~30 kernel launches, which is what bounds small rounds.  The graph
+ * is keyed by the descriptor's bytes; it is dropped whenever the context allocates or its parameters change.  seed / year /
+ * cand0 reach the replayed kernels through a device-side key that a one-thread launch refreshes in front of the graph.
+ * The TCR_* scheduling knobs are read when the graph is captured.  Timing events (tcr_timing_enable) are not recorded by
+ * replayed rounds.  A context is used from one stream at a time, as for every other entry point. */
+int tcr_round_dev(tcr_ctx *ctx, const tcr_round *round, uint64_t experiment_seed, int32_t year, int64_t cand0,
+                  int32_t use_graph, void *stream);
+/* graphs this context holds / replays since it was created (test and measurement aid) */
+int tcr_round_graph_stats(tcr_ctx *ctx, int64_t *n_graphs, int64_t *n_replays);
 
 /* ---- preprocessing next to the path ----------------------- */
 /* replaces: calc_wnd_stat (track/env_wind.py:180-228) for one month: wnd[c] = ua250, va250,

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     for name in _declared():
         assert hasattr(L, name), name
     from tropical_cyclone_risk_amd import _lib
-    assert L.tcr_abi_version() == _lib.TCR_ABI_VERSION == 4
+    assert L.tcr_abi_version() == _lib.TCR_ABI_VERSION == 5
 
 
 def test_struct_layout_matches_header(built_lib):
@@ -33,15 +33,17 @@ def test_struct_layout_matches_header(built_lib):
     import subprocess
     import tempfile
     from tropical_cyclone_risk_amd import _lib
-    src = ('#include <stdio.h>\n#include "tcrisk_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n",'
-           'sizeof(tcr_params),sizeof(tcr_storms),sizeof(tcr_tracks),sizeof(tcr_seeds),sizeof(tcr_grid));return 0;}\n')
+    src = ('#include <stdio.h>\n#include "tcrisk_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+           'sizeof(tcr_params),sizeof(tcr_storms),sizeof(tcr_tracks),sizeof(tcr_seeds),sizeof(tcr_grid),sizeof(tcr_round),'
+           'offsetof(tcr_round, tracks),offsetof(tcr_round, seed_hist));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, 'sz.c')
         open(c, 'w').write(src)
         exe = os.path.join(d, 'sz')
         subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
-    mine = [ctypes.sizeof(t) for t in (_lib.Params, _lib.Storms, _lib.Tracks, _lib.Seeds, _lib.Grid)]
+    mine = [ctypes.sizeof(t) for t in (_lib.Params, _lib.Storms, _lib.Tracks, _lib.Seeds, _lib.Grid, _lib.Round)]
+    mine += [_lib.Round.tracks.offset, _lib.Round.seed_hist.offset]
     assert sizes == mine
 
 

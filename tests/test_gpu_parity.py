@@ -377,7 +377,7 @@ def test_tc_rows_only_matches_all_rows(golden_env, built_lib):
         ps = tc.tracks['pad_state'][:B].cpu().numpy()
         assert np.array_equal(ps[is_tc], a['n_valid'][is_tc])
         prev_tc = {k: b[k].copy() for k in keys}
-        stats = torch.zeros(8, dtype=torch.int64, device=tc.dev)
+        stats = torch.zeros(10, dtype=torch.int64, device=tc.dev)
         tc.add_stats(stats); torch.cuda.synchronize()
         st = stats.cpu().numpy()
         assert st[4] == is_tc.sum() and st[5] == a['n_valid'][is_tc].sum() and st[3] == a['accepted'].sum()

@@ -21,7 +21,7 @@ copy_stream = torch.cuda.Stream(device=dev)
 bufs = [torch.empty(cap, row, dtype=torch.float64, device=dev) for _ in range(n_str)]
 hosts = [torch.empty(cap, row, dtype=torch.float64).pin_memory() for _ in range(n_str)]
 done = [torch.cuda.Event() for _ in range(n_str)]
-acc = torch.zeros(8, dtype=torch.int64, device=dev)
+acc = torch.zeros(10, dtype=torch.int64, device=dev)
 rows_out = 0
 
 

@@ -10,10 +10,11 @@ import os
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, 'libtcrisk_hip.so')
 
-TCR_ABI_VERSION = 4
+TCR_ABI_VERSION = 5
 TCR_NW, TCR_NCOV, TCR_MAX_SERIES, TCR_N_BASINS = 4, 10, 32, 7
 STATUS_GATED, STATUS_FINISHED, STATUS_EVENT, STATUS_STEP_FAIL, STATUS_STEP_OVERFLOW = -1, 0, 1, -2, -3
 FLAG_IS_TC, FLAG_ACCEPTED = 1, 2
+N_STATS = 10        # TCR_N_STATS: words of a tcr_stats_dev / tcr_round.stats counter block
 
 DP = C.POINTER(C.c_double)
 IP = C.POINTER(C.c_int32)
@@ -28,7 +29,8 @@ EXPORTS = ('tcr_abi_version', 'tcr_ctx_create', 'tcr_ctx_destroy', 'tcr_last_err
            'tcr_gather_seeds_dev', 'tcr_pack_tracks_dev', 'tcr_stats_dev', 'tcr_integrate_pass_stats', 'tcr_wind_stats_dev', 'tcr_wind_stats_host', 'tcr_entropy_table_upload',
            'tcr_potential_intensity_host', 'tcr_potential_intensity_dev', 'tcr_chi_rh_host',
            'tcr_integrate_probe_host', 'tcr_integrate_f32_dev', 'tcr_integrate_f32_host', 'tcr_pack_tracks_f32_dev',
-           'tcr_wind_stats_f32_dev', 'tcr_wind_stats_f32_host', 'tcr_static_upload2', 'tcr_init_m_dev', 'tcr_init_m_host', 'tcr_cell_order_dev')
+           'tcr_wind_stats_f32_dev', 'tcr_wind_stats_f32_host', 'tcr_static_upload2', 'tcr_init_m_dev', 'tcr_init_m_host', 'tcr_cell_order_dev',
+           'tcr_round_dev', 'tcr_round_graph_stats', 'tcr_seed_hist_dev', 'tcr_pack_tracks_meta_dev')
 
 
 class Grid(C.Structure):
@@ -73,6 +75,15 @@ class Seeds(C.Structure):
     _fields_ = [('n', C.c_int64), ('lon0', C.c_void_p), ('lat0', C.c_void_p), ('v0', C.c_void_p),
                 ('m0', C.c_void_p), ('h_bl', C.c_void_p), ('slot', C.c_void_p),
                 ('phases', C.c_void_p), ('basin_idx', C.c_void_p), ('seed_flags', C.c_void_p)]
+
+
+class Round(C.Structure):
+    """tcr_round: one round of the accept loop (tcr_round_dev)."""
+    _fields_ = [('n_cand', C.c_int64), ('n_storms', C.c_int64), ('cand', Seeds), ('storms', Seeds),
+                ('cand_idx', C.c_void_p), ('n_passed', C.c_void_p), ('cell_deg', C.c_double),
+                ('exact_count', C.c_int32), ('f32', C.c_int32), ('tracks', Tracks),
+                ('stats', C.c_void_p), ('acc_idx', C.c_void_p), ('n_accepted', C.c_void_p),
+                ('packed', C.c_void_p), ('pack_cap', C.c_int64), ('pack_stride', C.c_int64), ('seed_hist', C.c_void_p)]
 
 
 class TcrError(RuntimeError):
@@ -162,7 +173,12 @@ def lib():
                                   C.c_void_p, C.c_void_p, C.c_void_p]
     L.tcr_gather_seeds_dev.argtypes = [C.c_void_p, C.POINTER(Seeds), C.c_void_p, C.c_int64, C.c_void_p,
                                        C.POINTER(Seeds), C.c_uint64, C.c_int32, C.c_int64, C.c_void_p]
-    L.tcr_stats_dev.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(Tracks), C.c_void_p, C.c_void_p]
+    L.tcr_stats_dev.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(Tracks), C.c_void_p, C.c_int32, C.c_void_p]
+    L.tcr_round_dev.argtypes = [C.c_void_p, C.POINTER(Round), C.c_uint64, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]
+    L.tcr_round_graph_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.tcr_seed_hist_dev.argtypes = [C.c_void_p, C.POINTER(Seeds), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tcr_pack_tracks_meta_dev.argtypes = [C.c_void_p, C.POINTER(Tracks), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                           C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     L.tcr_pack_tracks_dev.argtypes = [C.c_void_p, C.POINTER(Tracks), C.c_void_p, C.c_void_p,
                                       C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
     L.tcr_pack_tracks_f32_dev.argtypes = L.tcr_pack_tracks_dev.argtypes

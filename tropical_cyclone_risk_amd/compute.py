@@ -133,69 +133,74 @@ def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000):
 
 
 class GpuRound:
-    """round_fn backed by the device pipeline: seed → select → integrate → pack, all on the current stream with
-    no host synchronisation: the number of passing seeds and of accepted tracks stay device scalars
-    (tcr_storms.n_dev, tcr_pack_tracks_dev's count)."""
+    """round_fn backed by the device pipeline.  A round — seed → select → locality order → integrate → stats → select
+    accepted → pack (+ candidate index / month / basin columns) → n_seeds histogram — is ONE library call
+    (`DevicePipeline.round` = tcr_round_dev), replayed from a captured hipGraph after its first use
+    (`namelist.gpu_round_graph`); the number of passing seeds, of accepted tracks and of overflowed step records stay
+    device scalars, and nothing in a round synchronises with the host."""
 
     def __init__(self, engine, year, per_rank, experiment_seed=None):
         import torch
+        from . import _lib
         from .pipeline import DevicePipeline
         self.torch = torch
         self.eng = engine
         self.year = int(year)
         self.seed = experiment_seed
+        self.per_rank = int(per_rank)
         self.unordered = bool(getattr(engine.nl, 'gpu_locality_order', True))
+        self.graph = bool(getattr(engine.nl, 'gpu_round_graph', True))
         self.pipe = DevicePipeline(engine, per_rank, per_rank, tc_rows_only=True, dtype=getattr(engine.nl, 'gpu_dtype', 'f64'),
                                    sort_storms=self.unordered)
+        dev = self.pipe.dev
         # survivor records: 26 kB per accepted track.  1-6 % of a round's candidates are accepted, so the buffer is sized
         # for a quarter of them (65 536 candidates: 0.43 GB instead of 1.7) and grows — `repack` — in the round that needs more
         self.cap = max(1024, per_rank // 4)
-        self.packed = torch.zeros(self.cap, ROW_VARS * engine.n_steps + N_META, dtype=torch.float64, device=self.pipe.dev)
-        self.ar = torch.arange(per_rank, device=self.pipe.dev)
+        self.packed = torch.zeros(self.cap, ROW_VARS * engine.n_steps + N_META, dtype=torch.float64, device=dev)
+        self.stats = torch.zeros(_lib.N_STATS, dtype=torch.int64, device=dev)
+        self.hist_round = torch.zeros(len(BASIN_IDS) * 12, dtype=torch.int64, device=dev)
+        self.hist_cut = torch.zeros(len(BASIN_IDS) * 12, dtype=torch.int64, device=dev)
+
+    def set_year(self, year):
+        """Reuse the buffers (and the captured round) for another year: the year is part of the round key, not of the graph."""
+        self.year = int(year)
+        return self
 
     def grow(self):
-        """Double the per-storm step record (tcr_params.max_rk_steps); False once it is at the ABI's limit."""
+        """Double the per-storm step record (tcr_params.max_rk_steps).  False once it is at its limit, or when the records
+        of a round (per_rank x max_rk_steps x ~400 B) would take more than half of the free HBM — the caller then raises
+        the explicit 'raise gpu_max_rk_steps' error instead of running into an allocation failure."""
+        cur = int(self.eng.params.max_rk_steps) or 64
+        free = self.torch.cuda.mem_get_info(self.pipe.dev)[0] if self.pipe.dev.type == 'cuda' else 1 << 62
+        if self.per_rank * 2 * cur * 400 > free // 2:
+            return False
         return self.eng.grow_step_record()
-
-    def _pack(self, cand0, count):
-        torch, p = self.torch, self.pipe
-        width = ROW_VARS * self.eng.n_steps
-        cap = min(self.cap, count)
-        p.pack_accepted(self.packed, cap)
-        # meta columns, fixed shapes (rows beyond the accepted count are never read)
-        dense = p.acc_idx[:cap].long().clamp_(0, count - 1)            # position in the dense batch
-        cand_local = p.cand_idx[:count].long().clamp_(0, count - 1)[dense]   # position in this rank's candidate block
-        self.packed[:cap, width] = (cand_local + int(cand0)).double()
-        self.packed[:cap, width + 1] = (p.storms['slot'][:count][dense] + 1).double()
-        self.packed[:cap, width + 2] = p.storms['basin_idx'][:count][dense].double()
-        return self.packed[:cap]
 
     def repack(self, need):
         """The last round accepted more tracks than the survivor buffer holds: grow it and pack again (the tracks are
         still in the pipeline's planes).  Local to this rank, no collective."""
         self.cap = int(min(self.pipe.B, max(need, 2 * self.cap)))
         self.packed = self.torch.zeros(self.cap, self.packed.shape[1], dtype=self.torch.float64, device=self.pipe.dev)
-        return self._pack(*self._last)
+        cand0, count = self._last
+        cap = min(self.cap, count)
+        self.pipe.pack_accepted_meta(self.packed, cap, cand0)
+        return self.packed[:cap]
 
     def __call__(self, cand0, count):
-        torch, p = self.torch, self.pipe
-        p.seed_round(self.year, cand0, count, self.seed)
-        p.select_passed(count)
-        p.integrate(count, n_dev=p.n_passed)
-        exists = self.ar[:count] < p.n_passed
-        bad = ((p.tracks['status'][:count] == -3) & exists).sum().reshape(1)
-        p.select_accepted()
+        p = self.pipe
+        self.stats.zero_()
+        cap = min(self.cap, count)
+        p.round(self.year, cand0, count, count, self.seed, exact_count=True, stats=self.stats, accepted=True,
+                packed=self.packed, pack_cap=cap, seed_hist=self.hist_round, graph=self.graph)
         self._last = (cand0, count)
-        rows = self._pack(cand0, count)
-        flags = p.cand['seed_flags'][:count]
-        key = p.cand['basin_idx'][:count].long() * 12 + p.cand['slot'][:count].long()
-        counted = (flags & 1) != 0
-        idx = self.ar[:count] + int(cand0)
+        hist_full = self.hist_round.double()          # a copy: the next round overwrites the buffer
 
         def hist(cutoff=None):
-            keep = counted if cutoff is None else counted & (idx.double() <= cutoff)
-            return torch.zeros(len(BASIN_IDS) * 12, dtype=torch.float64, device=p.dev).index_add_(0, key, keep.double())
-        return dict(rows=rows, count=p.n_accepted, bad=bad, hist=hist, unordered=self.unordered)
+            if cutoff is None:
+                return hist_full
+            return p.seed_hist(self.hist_cut, cutoff).double()
+        # stats[8]: storms whose step record overflowed (status -3) among the storms of this round
+        return dict(rows=self.packed[:cap], count=p.n_accepted, bad=self.stats[8:9], hist=hist, unordered=self.unordered)
 
 
 def rows_to_tuple(res, n_steps):

@@ -112,6 +112,15 @@ struct tcr_ctx {
     double *d_cell = nullptr; size_t cell_cap = 0; int cell_bins = 0;     // scratch of tcr_cell_order_dev
     uint8_t *d_probe = nullptr;                 // decision probe of the next tcr_integrate_dev (tcr_integrate_probe_host)
     int probe_cap = 0;
+    // rounds replayed from captured graphs (tcr_round_dev): the device copy of the round key the replayed kernels read, the
+    // graphs keyed by the bytes of their descriptor, and an epoch that every allocation / parameter change bumps (a graph
+    // holds the workspaces' addresses and the parameters by value)
+    RoundKey *d_round_key = nullptr;
+    uint64_t epoch = 0;
+    bool capturing = false;
+    struct RoundGraph { std::vector<uint8_t> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; bool failed = false; };
+    std::vector<RoundGraph> graphs;
+    int64_t n_replays = 0;
     // timing: four events per timed tcr_integrate_dev call since tcr_timing_enable(ctx, 1)
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -137,7 +146,9 @@ int fail(tcr_ctx *ctx, const char *fmt, const char *a = "", const char *b = "")
 template <typename T>
 int dev_alloc(tcr_ctx *ctx, T **p, size_t count)
 {
+    if (ctx && ctx->capturing) return fail(ctx, "internal: allocation while a round is being captured");
     HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T) + 256));
+    if (ctx) ++ctx->epoch;          // captured rounds hold addresses: they are re-captured (drop_graphs)
     return 0;
 }
 
@@ -379,6 +390,17 @@ void launch_integrate(const KArgsT<float> &a, bool affine, bool, bool split, uns
     launch_integrate_rp<float, false>(a, affine, split, waves, st);      // the decision probe is an fp64 instrument
 }
 
+// zeroes what a batch's kernels accumulate into: k_integrate's queue heads / parked counts / occupancy counters, and — when the
+// 2-day test is decided in flight — flags[0 .. n) and the count of storms accept test 1 is still open for
+__global__ __launch_bounds__(256) void k_batch_reset(unsigned long long *__restrict__ queue, int queue_words,
+                                                     unsigned long long *__restrict__ und_count, int32_t *__restrict__ flags, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < queue_words) queue[i] = 0ull;
+    if (i == 0 && und_count) *und_count = 0ull;
+    if (i < n) flags[i] = 0;
+}
+
 // ---- fp32 staging: float knots (+ reciprocal widths and the affine test in float arithmetic) and float
 // copies of the interleaved field layouts, converted on the device from the fp64 arrays already staged
 __global__ __launch_bounds__(256) void k_to_f32(const double *__restrict__ src, float *__restrict__ dst, size_t n)
@@ -587,7 +609,7 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
     host_eval_k<R>(ctx, EK, &affine);
 
     hipEvent_t *ev = nullptr;
-    if (ctx->timing && timing_events(ctx, &ev)) return -1;
+    if (ctx->timing && !ctx->capturing && timing_events(ctx, &ev)) return -1;
     if (ev) HIPCHK(ctx, hipEventRecord(ev[0], st));
     // Chain of launches with tail compaction (k_integrate): a pass parks the storms of waves that
     // fall under `thr` live lanes, the next pass needs at most waves*(thr-1)/64 waves for them.
@@ -633,10 +655,16 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
         if (prune_sample >= 0) {
             // storms still open for accept test 1 when they end: the list k_screen works through (flags of the others stay 0)
             a.und_list = ctx->d_und_list; a.und_count = ctx->d_und_count;
-            HIPCHK(ctx, hipMemsetAsync(ctx->d_und_count, 0, sizeof(unsigned long long), st));
-            HIPCHK(ctx, hipMemsetAsync(out.flags, 0, sizeof(int32_t) * (size_t)n, st));
         }
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, kQueueWords * sizeof(unsigned long long), st));
+        // one launch zeroes the work queue / pass counters and, with the in-flight 2-day test, flags[] and the open-storm
+        // count (three hipMemsetAsync until round 4: three fill kernels per batch, and as captured memset nodes of a
+        // replayed round they did not reliably clear flags[] — tests/test_round.py)
+        {
+            const int64_t words = prune_sample >= 0 ? n : 0;
+            const int64_t items = std::max<int64_t>(words, (int64_t)kQueueWords);
+            hipLaunchKernelGGL(k_batch_reset, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, ctx->d_queue, (int)kQueueWords,
+                               prune_sample >= 0 ? ctx->d_und_count : nullptr, out.flags, words);
+        }
         // (a segmented first pass can park any number of its storms)
         const size_t park_items = segmented ? (size_t)n : (size_t)waves * kWave;
         if (thr > 0 && grow(ctx, &ctx->d_park[0], &ctx->park_cap[0], park_items * kParkRec)) return -1;
@@ -752,7 +780,8 @@ int tcr_ctx_create(int device, tcr_ctx **out)
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->cu_count = prop.multiProcessorCount;
     if (hipMalloc(reinterpret_cast<void **>(&ctx->d_queue), kQueueWords * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&ctx->d_tc_count), 64) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void **>(&ctx->d_tc_count), 64) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&ctx->d_round_key), 64) != hipSuccess) {
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return fail(nullptr, "tcr_ctx_create: hipMalloc failed");
@@ -775,6 +804,8 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_mask_bits);
     (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_srec); (void)hipFree(ctx->d_vrec);
     for (auto &ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
+    for (auto &g : ctx->graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
+    (void)hipFree(ctx->d_round_key);
     (void)hipFree(ctx->d_cell); (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_seg_sids); (void)hipFree(ctx->d_screen_skip); (void)hipFree(ctx->d_und_list); (void)hipFree(ctx->d_und_count); (void)hipFree(ctx->d_tab);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -790,6 +821,7 @@ int tcr_params_set(tcr_ctx *ctx, const tcr_params *p)
     if (!(p->total_time > 0) || !(p->dt_out > 0)) return fail(ctx, "total_time and dt_out must be positive");
     ctx->prm = *p;
     ctx->have_prm = true;
+    ++ctx->epoch;
     // Periodic Fourier kernel when the series period is a whole number of output intervals
     // and the output times are exactly k*dt_out (np.linspace with an exact step).
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1348,8 +1380,10 @@ int tcr_init_m_host(tcr_ctx *ctx, const tcr_storms *in, double dvdt, double *m_o
     return 0;
 }
 
-int tcr_seed_dev(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t cand0,
-                 const tcr_seeds *out, void *stream_)
+extern "C++" {
+namespace {
+int seed_impl(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t cand0, const RoundKey *key,
+              const tcr_seeds *out, void *stream_)
 {
     if (ready(ctx, true)) return -1;
     if (!out) return fail(ctx, "tcr_seed_dev: NULL argument");
@@ -1360,10 +1394,18 @@ int tcr_seed_dev(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t c
     if (ctx->slots.size() < 12) return fail(ctx, "tcr_seed_dev: needs the 12 month slots staged");
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
     SeedArgs a{};
-    a.P = ctx->prm; a.D = dev_fields(ctx); a.seed = experiment_seed; a.year = year; a.cand0 = cand0; a.out = *out;
+    a.P = ctx->prm; a.D = dev_fields(ctx); a.seed = experiment_seed; a.year = year; a.cand0 = cand0; a.out = *out; a.key = key;
     hipLaunchKernelGGL(k_seed, dim3((unsigned)((out->n + 255) / 256)), dim3(256), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
     return 0;
+}
+}  // namespace
+}  // extern "C++"
+
+int tcr_seed_dev(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t cand0,
+                 const tcr_seeds *out, void *stream_)
+{
+    return seed_impl(ctx, experiment_seed, year, cand0, nullptr, out, stream_);
 }
 
 int tcr_seed_host(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t cand0, const tcr_seeds *out)
@@ -1453,9 +1495,10 @@ int tcr_cell_order_dev(tcr_ctx *ctx, const tcr_seeds *cand, int32_t *idx, int64_
     return 0;
 }
 
-int tcr_gather_seeds_dev(tcr_ctx *ctx, const tcr_seeds *src, const int32_t *idx, int64_t n_out,
-                         const int64_t *count, const tcr_seeds *dst, uint64_t experiment_seed, int32_t year,
-                         int64_t cand0, void *stream_)
+extern "C++" {
+namespace {
+int gather_impl(tcr_ctx *ctx, const tcr_seeds *src, const int32_t *idx, int64_t n_out, const int64_t *count,
+                const tcr_seeds *dst, uint64_t experiment_seed, int32_t year, int64_t cand0, const RoundKey *key, void *stream_)
 {
     if (!ctx) return -1;
     if (!ctx->have_prm) return fail(ctx, "tcr_params_set has not been called");
@@ -1465,24 +1508,34 @@ int tcr_gather_seeds_dev(tcr_ctx *ctx, const tcr_seeds *src, const int32_t *idx,
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
     GatherSeedArgs a{};
     a.src = *src; a.dst = *dst; a.idx = idx; a.n_out = n_out; a.phases_per_storm = 4 * ctx->prm.n_series;
-    a.seed = experiment_seed; a.year = year; a.cand0 = cand0; a.count = count;
+    a.seed = experiment_seed; a.year = year; a.cand0 = cand0; a.count = count; a.key = key;
     const int64_t threads = n_out * kGatherLanes;
     hipLaunchKernelGGL(k_gather_seeds, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
+}  // namespace
+}  // extern "C++"
 
-int tcr_stats_dev(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const tcr_tracks *t, uint64_t *out, void *stream_)
+int tcr_gather_seeds_dev(tcr_ctx *ctx, const tcr_seeds *src, const int32_t *idx, int64_t n_out,
+                         const int64_t *count, const tcr_seeds *dst, uint64_t experiment_seed, int32_t year,
+                         int64_t cand0, void *stream_)
+{
+    return gather_impl(ctx, src, idx, n_out, count, dst, experiment_seed, year, cand0, nullptr, stream_);
+}
+
+int tcr_stats_dev(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const tcr_tracks *t, uint64_t *out, int32_t n_out, void *stream_)
 {
     if (!ctx) return -1;
     if (!t || !out) return fail(ctx, "tcr_stats_dev: NULL argument");
+    if (n_out != 6 && n_out != 8 && n_out != TCR_N_STATS) return fail(ctx, "tcr_stats_dev: n_out must be 6, 8 or 10 (the capacity of out_dev in words)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (n <= 0) return 0;
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
     int64_t blocks = (n + 255) / 256;
     if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(k_stats, dim3((unsigned)blocks), dim3(256), 0, st, n, n_dev, t->n_valid, t->nfev, t->flags,
-                       reinterpret_cast<unsigned long long *>(out));
+    hipLaunchKernelGGL(k_stats, dim3((unsigned)blocks), dim3(256), 0, st, n, n_dev, t->n_valid, t->nfev, t->flags, t->status,
+                       reinterpret_cast<unsigned long long *>(out), (int)n_out);
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
@@ -1491,7 +1544,8 @@ extern "C++" {
 namespace {
 template <typename R, typename T>
 int pack_impl(tcr_ctx *ctx, const T *src, const int32_t *idx, const int64_t *count, int64_t cap, double *packed,
-              int64_t row_stride, void *stream_)
+              int64_t row_stride, void *stream_, const int32_t *cand_idx = nullptr, const int32_t *slot = nullptr,
+              const int32_t *basin_idx = nullptr, int64_t cand0 = 0, const RoundKey *key = nullptr)
 {
     if (!ctx) return -1;
     if (!ctx->have_prm) return fail(ctx, "tcr_params_set has not been called");
@@ -1504,6 +1558,11 @@ int pack_impl(tcr_ctx *ctx, const T *src, const int32_t *idx, const int64_t *cou
     a.idx = idx; a.count = count; a.cap = cap; a.ns = ctx->prm.n_steps; a.packed = packed;
     a.row_stride = row_stride > 0 ? row_stride : 9 * (int64_t)ctx->prm.n_steps;
     if (a.row_stride < 9 * (int64_t)ctx->prm.n_steps) return fail(ctx, "tcr_pack_tracks: row_stride < 9 * n_steps");
+    if (slot) {
+        if (!basin_idx) return fail(ctx, "tcr_pack_tracks_meta_dev: slot and basin_idx go together");
+        if (a.row_stride < 9 * (int64_t)ctx->prm.n_steps + 3) return fail(ctx, "tcr_pack_tracks_meta_dev: row_stride < 9 * n_steps + 3");
+        a.cand_idx = cand_idx; a.slot = slot; a.basin_idx = basin_idx; a.cand0 = cand0; a.key = key;
+    }
     hipLaunchKernelGGL(k_pack_tracks<R>, dim3((unsigned)cap), dim3(256), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
     return 0;
@@ -1521,6 +1580,157 @@ int tcr_pack_tracks_f32_dev(tcr_ctx *ctx, const tcr_tracks_f32 *src, const int32
                             int64_t cap, double *packed, int64_t row_stride, void *stream_)
 {
     return pack_impl<float>(ctx, src, idx, count, cap, packed, row_stride, stream_);
+}
+
+int tcr_pack_tracks_meta_dev(tcr_ctx *ctx, const tcr_tracks *src, int32_t f32, const int32_t *idx, const int64_t *count,
+                             int64_t cap, double *packed, int64_t row_stride, const int32_t *cand_idx, const int32_t *slot,
+                             const int32_t *basin_idx, int64_t cand0, void *stream_)
+{
+    if (ctx && (!slot || !basin_idx)) return fail(ctx, "tcr_pack_tracks_meta_dev: NULL argument");
+    if (f32) return pack_impl<float>(ctx, reinterpret_cast<const tcr_tracks_f32 *>(src), idx, count, cap, packed, row_stride, stream_,
+                                     cand_idx, slot, basin_idx, cand0);
+    return pack_impl<double>(ctx, src, idx, count, cap, packed, row_stride, stream_, cand_idx, slot, basin_idx, cand0);
+}
+
+extern "C++" {
+namespace {
+int seed_hist_impl(tcr_ctx *ctx, const tcr_seeds *cand, int64_t n, int64_t cand0, const RoundKey *key, const double *cutoff,
+                   int64_t *out, void *stream_)
+{
+    if (!ctx) return -1;
+    if (!cand || !cand->seed_flags || !cand->basin_idx || !cand->slot || !out) return fail(ctx, "tcr_seed_hist_dev: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    SeedHistArgs a{};
+    a.seed_flags = cand->seed_flags; a.basin_idx = cand->basin_idx; a.slot = cand->slot; a.n = n > 0 ? n : 0; a.cand0 = cand0;
+    a.key = key; a.cutoff = cutoff; a.out = reinterpret_cast<unsigned long long *>(out);
+    hipLaunchKernelGGL(k_seed_hist, dim3(1), dim3(1024), 0, st, a);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+// Everything a round enqueues (see tcr_round_dev in the header).  key != NULL: the replayable form — seed / year / cand0
+// are read on the device.
+int enqueue_round(tcr_ctx *ctx, const tcr_round *r, uint64_t seed, int32_t year, int64_t cand0, const RoundKey *key, void *st)
+{
+    tcr_seeds cand = r->cand, storms = r->storms;
+    cand.n = r->n_cand; storms.n = r->n_storms;
+    if (seed_impl(ctx, seed, year, cand0, key, &cand, st)) return -1;
+    if (tcr_compact_dev(ctx, r->n_cand, cand.seed_flags, 2, r->n_storms, r->cand_idx, r->n_passed, st)) return -1;
+    if (r->cell_deg > 0 && tcr_cell_order_dev(ctx, &cand, r->cand_idx, r->n_storms, r->n_passed, r->cell_deg, st)) return -1;
+    if (gather_impl(ctx, &cand, r->cand_idx, r->n_storms, r->n_passed, &storms, seed, year, cand0, key, st)) return -1;
+    tcr_storms in{};
+    in.n = r->n_storms; in.lon0 = storms.lon0; in.lat0 = storms.lat0; in.v0 = storms.v0; in.m0 = storms.m0; in.h_bl = storms.h_bl;
+    in.slot = storms.slot; in.phases = storms.phases; in.n_dev = r->exact_count ? r->n_passed : nullptr;
+    if (r->f32) {
+        if (ensure_f32(ctx, (hipStream_t)st)) return -1;
+        if (integrate_impl<float>(ctx, &in, tracks_of<float>(reinterpret_cast<const tcr_tracks_f32 *>(&r->tracks)), st)) return -1;
+    } else if (integrate_impl<double>(ctx, &in, tracks_of<double>(&r->tracks), st)) return -1;
+    if (r->stats && tcr_stats_dev(ctx, r->n_storms, r->n_passed, &r->tracks, r->stats, TCR_N_STATS, st)) return -1;
+    if (r->acc_idx) {
+        if (!r->n_accepted) return fail(ctx, "tcr_round_dev: acc_idx without n_accepted");
+        if (tcr_compact_dev(ctx, r->n_storms, r->tracks.flags, TCR_FLAG_ACCEPTED, r->n_storms, r->acc_idx, r->n_accepted, st)) return -1;
+        if (r->packed && r->pack_cap > 0) {
+            // the meta columns go with a record that has room for them (pack_stride >= 9 * n_steps + 3)
+            const bool meta = r->pack_stride >= 9 * (int64_t)ctx->prm.n_steps + 3;
+            const int32_t *ci = meta ? r->cand_idx : nullptr, *sl = meta ? storms.slot : nullptr, *bi = meta ? storms.basin_idx : nullptr;
+            if (r->f32 ? pack_impl<float>(ctx, reinterpret_cast<const tcr_tracks_f32 *>(&r->tracks), r->acc_idx, r->n_accepted, r->pack_cap,
+                                          r->packed, r->pack_stride, st, ci, sl, bi, cand0, key)
+                       : pack_impl<double>(ctx, &r->tracks, r->acc_idx, r->n_accepted, r->pack_cap, r->packed, r->pack_stride, st,
+                                           ci, sl, bi, cand0, key)) return -1;
+        }
+    }
+    if (r->seed_hist && seed_hist_impl(ctx, &cand, r->n_cand, cand0, key, nullptr, r->seed_hist, st)) return -1;
+    return 0;
+}
+
+void drop_graphs(tcr_ctx *ctx)
+{
+    for (auto &g : ctx->graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
+    ctx->graphs.clear();
+}
+}  // namespace
+}  // extern "C++"
+
+int tcr_seed_hist_dev(tcr_ctx *ctx, const tcr_seeds *cand, int64_t cand0, const double *cutoff, int64_t *out, void *stream_)
+{
+    return seed_hist_impl(ctx, cand, cand ? cand->n : 0, cand0, nullptr, cutoff, out, stream_);
+}
+
+int tcr_round_dev(tcr_ctx *ctx, const tcr_round *r, uint64_t seed, int32_t year, int64_t cand0, int32_t use_graph, void *stream_)
+{
+    if (ready(ctx, true)) return -1;
+    if (!r) return fail(ctx, "tcr_round_dev: NULL argument");
+    if (r->n_cand <= 0 || r->n_storms <= 0) return fail(ctx, "tcr_round_dev: n_cand and n_storms must be positive");
+    if (r->n_storms > r->n_cand) return fail(ctx, "tcr_round_dev: n_storms > n_cand");
+    if (!r->cand_idx || !r->n_passed || !r->cand.seed_flags || !r->cand.lon0 || !r->storms.lon0 || !r->storms.phases ||
+        !r->storms.basin_idx || !r->tracks.flags || !r->tracks.n_valid)
+        return fail(ctx, "tcr_round_dev: NULL buffer");
+    if (r->cell_deg != 0 && !(r->cell_deg >= 0.25 && r->cell_deg <= 90.0)) return fail(ctx, "tcr_round_dev: cell_deg must be 0 or in [0.25, 90]");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    if (!use_graph || ctx->d_probe) return enqueue_round(ctx, r, seed, year, cand0, nullptr, st);
+
+    // ---- replayed form
+    std::vector<uint8_t> key(sizeof(tcr_round) + sizeof(uint64_t) + sizeof(void *));
+    memcpy(key.data(), r, sizeof(tcr_round));
+    {   // the one run of padding bytes in the descriptor (behind tcr_tracks.tc_rows_only) must not take part in the comparison
+        constexpr size_t pad0 = offsetof(tcr_round, tracks) + offsetof(tcr_tracks, tc_rows_only) + sizeof(int32_t);
+        constexpr size_t pad1 = offsetof(tcr_round, tracks) + sizeof(tcr_tracks);
+        static_assert(pad1 >= pad0 && sizeof(tcr_seeds) == 80 && sizeof(tcr_round) == 376, "tcr_round layout changed: revisit the key");
+        memset(key.data() + pad0, 0, pad1 - pad0);
+    }
+    memcpy(key.data() + sizeof(tcr_round), &ctx->epoch, sizeof(uint64_t));
+    memcpy(key.data() + sizeof(tcr_round) + sizeof(uint64_t), &st, sizeof(void *));
+    tcr_ctx::RoundGraph *g = nullptr;
+    for (auto &c : ctx->graphs) if (c.key == key) { g = &c; break; }
+    if (!g) {
+        // First sight of this descriptor (or the context has allocated / changed parameters since): run the round directly
+        // — that is this call's result and it sizes every workspace — then capture the same enqueue for the calls to come.
+        if (!ctx->graphs.empty() && memcmp(ctx->graphs.front().key.data() + sizeof(tcr_round), &ctx->epoch, sizeof(uint64_t)) != 0)
+            drop_graphs(ctx);                    // graphs of an older epoch hold stale addresses
+        if (enqueue_round(ctx, r, seed, year, cand0, nullptr, st)) return -1;
+        memcpy(key.data() + sizeof(tcr_round), &ctx->epoch, sizeof(uint64_t));     // the direct run may have grown workspaces
+        ctx->graphs.emplace_back();
+        g = &ctx->graphs.back();
+        g->key = key;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { g->failed = true; (void)hipGetLastError(); return 0; }
+        ctx->capturing = true;
+        const int rc = enqueue_round(ctx, r, 0, 0, 0, ctx->d_round_key, st);
+        ctx->capturing = false;
+        hipGraph_t graph = nullptr;
+        const hipError_t e = hipStreamEndCapture(st, &graph);
+        if (rc || e != hipSuccess || !graph) {
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            g->failed = true;                    // this descriptor keeps the direct form; the round above has run
+            return 0;
+        }
+        if (const char *dot = getenv("TCR_GRAPH_DOT")) (void)hipGraphDebugDotPrint(graph, dot, 0);      // debugging aid
+        hipGraphExec_t exec = nullptr;
+        if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) {
+            (void)hipGraphDestroy(graph); (void)hipGetLastError();
+            g->failed = true;
+            return 0;
+        }
+        g->graph = graph; g->exec = exec;
+        return 0;
+    }
+    if (g->failed) return enqueue_round(ctx, r, seed, year, cand0, nullptr, st);
+    hipLaunchKernelGGL(k_set_round_key, dim3(1), dim3(1), 0, st, ctx->d_round_key, seed, year, cand0);
+    HIPCHK(ctx, hipGraphLaunch(g->exec, st));
+    ++ctx->n_replays;
+    return 0;
+}
+
+int tcr_round_graph_stats(tcr_ctx *ctx, int64_t *n_graphs, int64_t *n_replays)
+{
+    if (!ctx) return -1;
+    int64_t n = 0;
+    for (auto &g : ctx->graphs) n += g.exec ? 1 : 0;
+    if (n_graphs) *n_graphs = n;
+    if (n_replays) *n_replays = ctx->n_replays;
+    return 0;
 }
 
 }  // extern "C"

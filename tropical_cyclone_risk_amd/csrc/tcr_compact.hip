@@ -100,6 +100,7 @@ struct GatherSeedArgs {
     int32_t year;
     int64_t cand0;
     const int64_t *count;       // device scalar from tcr_compact_dev: rows >= *count are not valid (NULL: all are)
+    const RoundKey *key;        // NULL: seed / year / cand0 above (tcr_seed.hip)
 };
 
 // 16 lanes per output row (four rows per wave: the kernel is bound by its two dependent loads — idx[row], then
@@ -125,10 +126,13 @@ __global__ __launch_bounds__(256) void k_gather_seeds(GatherSeedArgs a)
         const double *sp = a.src.phases + (size_t)j * a.phases_per_storm;
         for (int k = lane; k < a.phases_per_storm; k += kGatherLanes) dp[k] = sp[k];
     } else {
+        const uint64_t seed = a.key ? a.key->seed : a.seed;
+        const int32_t year = a.key ? a.key->year : a.year;
+        const int64_t cand0 = a.key ? a.key->cand0 : a.cand0;
         // one Philox block yields the pair (2p, 2p + 1): a lane per pair, not per phase
         for (int p = lane; 2 * p < a.phases_per_storm; p += kGatherLanes) {
             double p0, p1;
-            uniform2_raw(a.seed, a.year, a.cand0 + j, 2u, (uint32_t)p, p0, p1);
+            uniform2_raw(seed, year, cand0 + j, 2u, (uint32_t)p, p0, p1);
             dp[2 * p] = p0;
             if (2 * p + 1 < a.phases_per_storm) dp[2 * p + 1] = p1;
         }
@@ -240,15 +244,28 @@ __global__ __launch_bounds__(256) void k_cell_rank(CellOrderArgs a)
 }
 
 // Sums over a finished batch (throughput accounting / round control): one atomic per workgroup.
+// n_out counters are written: 6 (the original six sums), 8 (+ short batch, storms counted) or 10 (+ [8] storms whose step
+// record overflowed, status -3; [9] storms the batch had no room for, max(*n_dev - n, 0)).
 __global__ __launch_bounds__(256) void k_stats(int64_t n, const int64_t *__restrict__ n_dev, const int32_t *__restrict__ n_valid,
                                                const int32_t *__restrict__ nfev, const int32_t *__restrict__ flags,
-                                               unsigned long long *__restrict__ out)
+                                               const int32_t *__restrict__ status, unsigned long long *__restrict__ out, int n_out)
 {
     const bool is_short = n_dev && *n_dev < n;         // the batch holds fewer storms than it was sized for
+    const int64_t dropped = (n_dev && *n_dev > n) ? *n_dev - n : 0;
     if (is_short) n = *n_dev;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n_out >= 8) {
         if (is_short) atomicAdd(out + 6, 1ull);
         atomicAdd(out + 7, (unsigned long long)(n > 0 ? n : 0));
+        if (n_out >= 10 && dropped > 0) atomicAdd(out + 9, (unsigned long long)dropped);
+    }
+    if (n_out >= 10 && status) {
+        unsigned long long bad = 0;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            bad += status[i] == TCR_STATUS_STEP_OVERFLOW ? 1 : 0;
+        const unsigned long long any = __ballot(bad != 0);
+        if (any) {                                  // rare: one atomic per lane that saw one
+            if (bad) atomicAdd(out + 8, bad);
+        }
     }
     __shared__ unsigned long long s[4][6];
     unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
@@ -284,6 +301,12 @@ struct PackArgsT {
     int ns;
     int64_t row_stride;         // doubles between packed rows (>= 9 * ns)
     double *packed;
+    // optional meta columns 9*ns .. 9*ns + 2 of a record (row_stride >= 9*ns + 3): global candidate index, month (1..12),
+    // genesis-basin index — what run_tracks keeps per track next to the rows (compute.py:206-208).  cand_idx maps a dense
+    // batch row to its position in the round's candidate block (NULL: the identity), cand0 / key give the block's first index.
+    const int32_t *cand_idx, *slot, *basin_idx;
+    int64_t cand0;
+    const RoundKey *key;
 };
 
 template <typename R>
@@ -299,6 +322,39 @@ __global__ __launch_bounds__(256) void k_pack_tracks(PackArgsT<R> a)
     for (int p = 0; p < 5; ++p)
         for (int i = threadIdx.x; i < ns; i += blockDim.x) dst[(size_t)p * ns + i] = (double)planes[p][j * ns + i];
     for (int i = threadIdx.x; i < ns * 4; i += blockDim.x) dst[(size_t)5 * ns + i] = (double)a.envw[j * ns * 4 + i];
+    if (a.slot && threadIdx.x == 0) {
+        const int64_t cand0 = a.key ? a.key->cand0 : a.cand0;
+        dst[(size_t)9 * ns] = (double)(cand0 + (a.cand_idx ? (int64_t)a.cand_idx[j] : (int64_t)j));
+        dst[(size_t)9 * ns + 1] = (double)(a.slot[j] + 1);
+        dst[(size_t)9 * ns + 2] = (double)a.basin_idx[j];
+    }
+}
+
+// n_seeds of a round (compute.py:165-167): candidates that count (seed_flags bit 0), per (genesis basin, month), optionally
+// only those whose global index is <= *cutoff (the candidate that completed the quota).  out[7 * 12] int64 is SET.
+struct SeedHistArgs {
+    const int32_t *seed_flags, *basin_idx, *slot;
+    int64_t n, cand0;
+    const RoundKey *key;
+    const double *cutoff;       // device scalar (a candidate index held as a double, as the survivor records hold it) or NULL
+    unsigned long long *out;
+};
+
+__global__ __launch_bounds__(1024) void k_seed_hist(SeedHistArgs a)
+{
+    __shared__ unsigned int h[TCR_N_BASINS * 12];
+    for (int i = threadIdx.x; i < TCR_N_BASINS * 12; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const int64_t cand0 = a.key ? a.key->cand0 : a.cand0;
+    const double cut = a.cutoff ? *a.cutoff : 0.0;
+    for (int64_t i = threadIdx.x; i < a.n; i += blockDim.x) {
+        if (!(a.seed_flags[i] & 1)) continue;
+        if (a.cutoff && !((double)(cand0 + i) <= cut)) continue;
+        const int b = a.basin_idx[i], m = a.slot[i];
+        if (b >= 0 && b < TCR_N_BASINS && m >= 0 && m < 12) atomicAdd(&h[b * 12 + m], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TCR_N_BASINS * 12; i += blockDim.x) a.out[i] = h[i];
 }
 
 }  // namespace tcr

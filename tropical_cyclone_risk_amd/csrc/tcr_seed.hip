@@ -17,6 +17,16 @@
 
 namespace tcr {
 
+// The key of a round of candidates.  Kernels take it by value; when a round is replayed from a captured graph
+// (tcr_round_dev) the arguments of its nodes are frozen, so the kernels read it through `key` — a device copy that a
+// one-thread launch in front of the graph refreshes — whenever that pointer is set.
+struct RoundKey {
+    uint64_t seed;
+    int64_t cand0;
+    int32_t year;
+    int32_t pad_;
+};
+
 struct SeedArgs {
     tcr_params P;
     DevFields D;
@@ -24,7 +34,13 @@ struct SeedArgs {
     int32_t year;
     int64_t cand0;
     tcr_seeds out;
+    const RoundKey *key;        // NULL: seed / year / cand0 above
 };
+
+__global__ void k_set_round_key(RoundKey *dst, uint64_t seed, int32_t year, int64_t cand0)
+{
+    dst->seed = seed; dst->cand0 = cand0; dst->year = year; dst->pad_ = 0;
+}
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t (&o)[4])
@@ -62,16 +78,6 @@ __device__ __forceinline__ double phase_at(uint64_t seed, int32_t year, int64_t 
     return (k & 1) ? p1 : p0;
 }
 
-__device__ __forceinline__ void uniform2(const SeedArgs &a, int64_t cand, uint32_t purpose, uint32_t idx,
-                                         double &u0, double &u1)
-{
-    uint32_t o[4];
-    const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32) ^ ((uint32_t)a.year * 0x9E3779B9u);
-    philox4x32_10((uint32_t)cand, (uint32_t)((uint64_t)cand >> 32), purpose, idx, k0, k1, o);
-    u0 = ((double)(o[0] >> 5) * 67108864.0 + (double)(o[1] >> 6)) / 9007199254740992.0;
-    u1 = ((double)(o[2] >> 5) * 67108864.0 + (double)(o[3] >> 6)) / 9007199254740992.0;
-}
-
 // The eight 0/1 mask planes (run basin + 7 basins) are staged as the bits of ONE byte per grid point, so a
 // candidate's nine mask lookups read four bytes instead of thirty-six.
 struct MaskCorners {
@@ -105,7 +111,9 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a)
     if (i >= a.out.n) return;
     const tcr_params &P = a.P;
     const DevFields &D = a.D;
-    const int64_t cand = a.cand0 + i;
+    const uint64_t seed = a.key ? a.key->seed : a.seed;
+    const int32_t year = a.key ? a.key->year : a.year;
+    const int64_t cand = (a.key ? a.key->cand0 : a.cand0) + i;
     const double deg = kPi / 180;
 
     // compute.py:140-145.  np.sign(-0.0) >= 0 is True, so a '0S' upper bound still
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a)
     const double lat_max = !(P.box[3] < 0) ? 45 : -3;
     const double y_min = sin(deg * lat_min), y_max = sin(deg * lat_max);
     double u0, u1;
-    uniform2(a, cand, 0u, 0u, u0, u1);
+    uniform2_raw(seed, year, cand, 0u, 0u, u0, u1);
     double lon = P.box[0] + (P.box[2] - P.box[0]) * u0;
     double lat = asin(y_min + (y_max - y_min) * u1) * 180 / kPi;
     Cell cx = locate(D.mg.ax, lon);
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a)
     MaskCorners mc = mask_corners(D.mg, D.mask_bits, cx, cy);
     while (mask_at(mc, 7, cx, cy) < 1e-2 && redraw < kMaxRedraw) {
         ++redraw;                                           // compute.py:146-148: uniform in lat
-        uniform2(a, cand, 0u, (uint32_t)redraw, u0, u1);
+        uniform2_raw(seed, year, cand, 0u, (uint32_t)redraw, u0, u1);
         lon = P.box[0] + (P.box[2] - P.box[0]) * u0;
         lat = P.box[1] + (P.box[3] - P.box[1]) * u1;
         cx = locate(D.mg.ax, lon);
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a)
         mc = mask_corners(D.mg, D.mask_bits, cx, cy);
     }
     double um, ul;
-    uniform2(a, cand, 1u, 0u, um, ul);
+    uniform2_raw(seed, year, cand, 1u, 0u, um, ul);
     int month = (int)(um * 12.0) + 1;                       // randint(1, 13)
     month = month > 12 ? 12 : month;
 
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a)
     }
     // initial state (compute.py:172-175)
     double n0, n1;
-    uniform2(a, cand, 1u, 1u, n0, n1);
+    uniform2_raw(seed, year, cand, 1u, 1u, n0, n1);
     const double z = sqrt(-2.0 * log(1.0 - n0)) * cos(2. * kPi * n1);   // Box–Muller N(0,1)
     // m_init_fx[month].ev(lon, lat) on the uncropped thermo grid (compute.py:111,173)
     const Cell rx = locate(D.rg.ax, lon);
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256) void k_seed(SeedArgs a)
     double *ph = a.out.phases + (size_t)i * 4 * N;
     for (int k = 0; k < 4 * N; k += 2) {
         double p0, p1;
-        uniform2(a, cand, 2u, (uint32_t)(k >> 1), p0, p1);
+        uniform2_raw(seed, year, cand, 2u, (uint32_t)(k >> 1), p0, p1);
         ph[k] = p0;
         if (k + 1 < 4 * N) ph[k + 1] = p1;
     }

@@ -97,9 +97,10 @@ class TCEngine:
         if rc != 0:
             raise _lib.TcrError(self.L.tcr_last_error(self.h).decode())
 
-    def grow_step_record(self, limit=4096):
-        """Double tcr_params.max_rk_steps (accepted RK45 steps recorded per storm; the workspaces follow at the next
-        integrate).  Returns False when the ABI's limit is reached."""
+    def grow_step_record(self, limit=1024):
+        """Double tcr_params.max_rk_steps (accepted RK45 steps recorded per storm; the workspaces — n x max_rk_steps x
+        ~400 B — follow at the next integrate).  Returns False when `limit` is reached (the ABI takes up to 4096; no storm of
+        the 40-year config 3 needs more than 128).  The value persists for the engine's later rounds and years."""
         cur = int(self.params.max_rk_steps) or 64
         if cur >= limit:
             return False

@@ -52,6 +52,7 @@ class DevicePipeline:
         self.acc_idx = z(self.B, dtype=I32)
         self.n_accepted = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.sort_storms = sort_storms
+        self._rounds = {}                     # tcr_round descriptors by their configuration (round())
 
     # raw pointers -----------------------------------------------------------
     @staticmethod
@@ -96,7 +97,7 @@ class DevicePipeline:
         if self.sort_storms:
             # Locality order (tcr_cell_order_dev): the selected candidates by the 2-degree cell of their genesis point, a
             # stable counting sort of the index list on the device — neighbours share an integrator wave and its cache
-            # lines (L2 misses of the integrator -20 %, step -5..7 %).  With it, dense order is no longer candidate order:
+            # lines (integrator L2 misses -20 %; 100 000-storm step, 8 streams: 1.371 -> 1.345 ms, profiles/r03_bench*.json).  With it, dense order is no longer candidate order:
             # `cand_idx` is the map back, and compute.accept_loop sorts the accepted rows by their candidate index.
             cs = self._seeds_struct(self.cand, self.n_cand)
             self.eng._ck(L.tcr_cell_order_dev(h, C.byref(cs), self.cand_idx.data_ptr(), n_take, self.n_passed.data_ptr(),
@@ -135,17 +136,77 @@ class DevicePipeline:
         self.n_done = n
 
     def add_stats(self, counters, n_dev=None):
-        """counters (uint64/int64 tensor [8]) += storm-steps, RHS evaluations, samples, accepted, is_tc storms,
-        samples of is_tc storms, 1 if the batch was short of storms (n_dev < n), storms counted.  n_dev: device int64
-        scalar, default the one integrate() was given."""
-        assert counters.numel() >= 8
+        """counters (uint64/int64 tensor [_lib.N_STATS = 10]) += storm-steps, RHS evaluations, samples, accepted, is_tc
+        storms, samples of is_tc storms, 1 if the batch was short of storms (n_dev < n), storms counted, storms whose step
+        record overflowed, passing seeds the batch had no room for (tcr_stats_dev).  n_dev: device int64 scalar, default
+        the one integrate() was given."""
+        assert counters.numel() >= _lib.N_STATS and counters.element_size() == 8
         so = self._tracks_struct()
         nd = n_dev if n_dev is not None else getattr(self, '_n_dev', None)
         self.eng._ck(self.eng.L.tcr_stats_dev(self.eng.h, self.n_done, nd.data_ptr() if nd is not None else None,
-                                              C.byref(so), counters.data_ptr(), C.c_void_p(self._stream())))
+                                              C.byref(so), counters.data_ptr(), _lib.N_STATS, C.c_void_p(self._stream())))
+
+    def round(self, year, cand0, n_cand=None, n_take=None, experiment_seed=None, exact_count=True, stats=None,
+              accepted=False, packed=None, pack_cap=0, seed_hist=None, graph=False):
+        """One round of the accept loop in ONE library call (tcr_round_dev): seed_round → select_passed → integrate
+        (→ add_stats → select_accepted → pack with the meta columns → n_seeds histogram), nothing returning to Python in
+        between; the same kernels in the same order as the separate methods, so the results are theirs.
+
+        exact_count: integrate min(n_take, n_passed) storms (n_dev); False: the round is sized so that n_take seeds pass.
+        stats: int64 tensor [_lib.N_STATS] added to.  accepted: also select the accepted tracks (acc_idx / n_accepted);
+        packed [cap, >= 9*ns + 3]: their survivor records + (candidate index, month, basin index).  seed_hist: int64 tensor
+        [7*12] set to the round's n_seeds contribution.  graph: replay the round from a captured hipGraph (one launch)."""
+        n_cand = self.C if n_cand is None else int(n_cand)
+        n_take = self.B if n_take is None else int(n_take)
+        assert n_cand <= self.C and n_take <= self.B
+        cfg = (n_cand, n_take, bool(exact_count), stats.data_ptr() if stats is not None else 0, bool(accepted),
+               packed.data_ptr() if packed is not None else 0, int(pack_cap), int(packed.stride(0)) if packed is not None else 0,
+               seed_hist.data_ptr() if seed_hist is not None else 0)
+        r = self._rounds.get(cfg)
+        if r is None:
+            if stats is not None:
+                assert stats.numel() >= _lib.N_STATS and stats.element_size() == 8
+            if seed_hist is not None:
+                assert seed_hist.numel() >= 84 and seed_hist.element_size() == 8
+            r = _lib.Round()
+            r.n_cand, r.n_storms = n_cand, n_take
+            r.cand, r.storms = self._seeds_struct(self.cand, n_cand), self._seeds_struct(self.storms, n_take)
+            r.cand_idx, r.n_passed = self.cand_idx.data_ptr(), self.n_passed.data_ptr()
+            r.cell_deg = 0.0 if not self.sort_storms else float(self.sort_storms if self.sort_storms is not True else 2.0)
+            r.exact_count, r.f32 = int(bool(exact_count)), int(self.dtype == 'f32')
+            r.tracks = self._tracks_struct()
+            r.stats = stats.data_ptr() if stats is not None else None
+            if accepted or packed is not None:
+                r.acc_idx, r.n_accepted = self.acc_idx.data_ptr(), self.n_accepted.data_ptr()
+            if packed is not None:
+                r.packed, r.pack_cap, r.pack_stride = packed.data_ptr(), int(pack_cap), int(packed.stride(0))
+            r.seed_hist = seed_hist.data_ptr() if seed_hist is not None else None
+            self._rounds[cfg] = r
+        seed = int(self.eng.nl.gpu_experiment_seed if experiment_seed is None else experiment_seed)
+        self.eng._ck(self.eng.L.tcr_round_dev(self.eng.h, C.byref(r), C.c_uint64(seed), int(year), int(cand0),
+                                              1 if graph else 0, C.c_void_p(self._stream())))
+        self.n_cand, self.n_storms, self.n_done = n_cand, n_take, n_take
+        self._round = (seed, int(year), int(cand0))
+        self._n_dev = self.n_passed if exact_count else None
+
+    def seed_hist(self, out, cutoff=None):
+        """n_seeds contribution (compute.py:165-167) of the last seeded round → out (int64 tensor [7*12], set); cutoff
+        (device float64 scalar): only candidates with global index <= cutoff (tcr_seed_hist_dev)."""
+        assert out.numel() >= 84 and out.element_size() == 8
+        cs = self._seeds_struct(self.cand, self.n_cand)
+        self.eng._ck(self.eng.L.tcr_seed_hist_dev(self.eng.h, C.byref(cs), int(self._round[2]),
+                                                  cutoff.data_ptr() if cutoff is not None else None, out.data_ptr(),
+                                                  C.c_void_p(self._stream())))
+        return out
+
+    def graph_stats(self):
+        g, r = C.c_int64(0), C.c_int64(0)
+        self.eng._ck(self.eng.L.tcr_round_graph_stats(self.eng.h, C.byref(g), C.byref(r)))
+        return dict(graphs=int(g.value), replays=int(r.value))
 
     def select_accepted(self):
-        """Indices (dense-batch order == candidate order) of accepted tracks → self.acc_idx."""
+        """Dense-batch rows of the accepted tracks, ascending → self.acc_idx (dense order is candidate order only without
+        the locality order: `cand_idx` maps a dense row to its candidate)."""
         self.eng._ck(self.eng.L.tcr_compact_dev(self.eng.h, self.n_done, self.tracks['flags'].data_ptr(),
                                                 _lib.FLAG_ACCEPTED, self.B, self.acc_idx.data_ptr(),
                                                 self.n_accepted.data_ptr(), C.c_void_p(self._stream())))
@@ -158,6 +219,16 @@ class DevicePipeline:
         self.eng._ck(fn(self.eng.h, C.byref(so), self.acc_idx.data_ptr(),
                         self.n_accepted.data_ptr(), int(cap), packed.data_ptr(),
                         int(packed.stride(0)), C.c_void_p(self._stream())))
+
+    def pack_accepted_meta(self, packed, cap, cand0):
+        """pack_accepted plus the three columns behind the rows: global candidate index, month, basin index
+        (tcr_pack_tracks_meta_dev); packed [cap, >= 9*ns + 3]."""
+        so = self._tracks_struct()
+        s = self.storms
+        self.eng._ck(self.eng.L.tcr_pack_tracks_meta_dev(
+            self.eng.h, C.byref(so), int(self.dtype == 'f32'), self.acc_idx.data_ptr(), self.n_accepted.data_ptr(), int(cap),
+            packed.data_ptr(), int(packed.stride(0)), self.cand_idx.data_ptr(), s['slot'].data_ptr(), s['basin_idx'].data_ptr(),
+            int(cand0), C.c_void_p(self._stream())))
 
     def host_tracks(self, n=None):
         """Copy the per-storm outputs of the last integrate() back as NumPy arrays."""
