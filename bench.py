@@ -57,6 +57,11 @@ def main():
     ap.add_argument('--graph', choices=('auto', 'on', 'off'), default='auto',
                     help='replay every step from a captured hipGraph (tcr_round_dev use_graph); auto: when a rank integrates '
                          'fewer than 50 000 storms per step')
+    ap.add_argument('--storms-per-lane', type=int, default=3,
+                    help='launch shape of batches that do not fill the chip (tcr_schedule_set): 1 = one integrator lane per storm, '
+                         '3 = a third of the waves, lanes take storms in turn (profiles/r04_small_batches.txt)')
+    ap.add_argument('--stage-trace', action='store_true', help='record a HIP event behind every stage of every (directly enqueued) round of '
+                    'the timed region and report the per-stage stream time under load (tcr_stage_trace_*; implies --graph off)')
     ap.add_argument('--staged', action='store_true', help="round 3's step: one library call per stage instead of tcr_round_dev")
     ap.add_argument('--basin', default='GL')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -85,7 +90,7 @@ def main():
     if args.streams is None:
         args.streams = 16 if (args.scaling == 'strong' and int(os.environ.get('WORLD_SIZE', '1')) > 1) else 8
     if args.streams > 4:
-        os.environ.setdefault('GPU_MAX_HW_QUEUES', str(min(args.streams, 16)))
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', str(min(args.streams, 32)))
 
     import numpy as np
     import torch
@@ -104,7 +109,8 @@ def main():
 
     env = synthetic.make_env('era5')
     n_str = max(1, args.streams)
-    engs = [TCEngine(args.basin, device=local).stage_env(env) for _ in range(n_str)]
+    # many batches in flight: batches that do not fill the chip run with lanes that take ~3 storms in turn (tcr_schedule_set)
+    engs = [TCEngine(args.basin, device=local).stage_env(env).schedule(args.storms_per_lane) for _ in range(n_str)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_str)]
     eng = engs[0]
     B = args.storms
@@ -136,7 +142,7 @@ def main():
     # storm-steps, nfev, samples, accepted, is_tc, is_tc samples, rounds with < B passing seeds, storms, step-record overflows,
     # passing seeds a batch had no room for (tcr_stats_dev)
     acc = torch.zeros(10, dtype=torch.int64, device=dev)
-    use_graph = args.graph == 'on' or (args.graph == 'auto' and B < 50_000)
+    use_graph = (args.graph == 'on' or (args.graph == 'auto' and B < 50_000)) and not args.stage_trace
     row = 9 * ns
     # N > 1: all-gather of every batch's final (accepted) tracks through distributed.DeferredRowGather:
     # nothing in a step waits on the host — batch k's count is read back only when batch k + n_str is
@@ -184,11 +190,14 @@ def main():
     D.barrier(); torch.cuda.synchronize()
     for e in engs:
         e.timing_enable(True)        # resets the event record: only the K timed steps count
+        if args.stage_trace:
+            e.stage_trace(True)
     if gather is not None:
         gather.rows_gathered = gather.rows_clipped = 0
     t0 = time.perf_counter()
     for k in range(w_eff, w_eff + args.steps):
         step(k)
+    t_issue = time.perf_counter() - t0            # host time to enqueue the K steps (the GPU runs behind it)
     drain()
     torch.cuda.synchronize(); D.barrier()
     dt = time.perf_counter() - t0
@@ -205,6 +214,16 @@ def main():
                 tot[kk] += m1[kk]
         return tot
     ms = sum_timings()              # (calls == 0 when the steps were graph replays: those record no events)
+    stage_ms = None
+    if args.stage_trace:
+        tot, nr = {}, 0
+        for e in engs:
+            d1, n1 = e.stage_trace_sum()
+            e.stage_trace(False)
+            nr += n1
+            for kk, v in d1.items():
+                tot[kk] = tot.get(kk, 0.0) + v
+        stage_ms = {kk: v / max(nr, 1) for kk, v in tot.items()}
     # SIMD time of the integrator chains as they ran INSIDE the timed region (the last batch of every stream: wave residency
     # summed from the waves' own wall-clock stamps): under load the waves of several batches share the CUs' address paths,
     # so this is what a chain costs the pipeline; `integrate_passes` below is the same for an isolated batch
@@ -348,12 +367,13 @@ def main():
                        'emitted_samples_per_step': emitted_total / (args.steps * world),
                        'storms_per_gpu': storms_total / (args.steps * world), 'candidates_per_round': C, 'seed_pass_rate': p_pass,
                        'n_steps_out': ns, 'rounds_short_of_storms': None if strong else n_short, 'streams': n_str,
-                       'hw_queues': int(os.environ.get('GPU_MAX_HW_QUEUES', '4')),
+                       'hw_queues': int(os.environ.get('GPU_MAX_HW_QUEUES', '4')), 'storms_per_lane': args.storms_per_lane,
                        'step_call': 'staged (one library call per stage)' if args.staged else ('tcr_round_dev, replayed from a hipGraph' if use_graph else 'tcr_round_dev, direct enqueue'),
                        'graph_replays': sum(p.graph_stats()['replays'] for p in pipes),
+                       'stage_ms_under_load': stage_ms,
                        'allgather': ('accepted tracks of every %s all-gathered once (26 kB records, RCCL, one collective per step, '
                                      '%d steps behind compute)' % ('ensemble' if strong else 'step', n_str)) if world > 1 else 'none (one GPU)',
-                       'warmup_effective': w_eff,
+                       'warmup_effective': w_eff, 'host_issue_ms_per_step': t_issue / args.steps * 1e3,
                        'storm_steps_per_storm': steps_total / storms_total,
                        'rhs_per_storm_step': nfev_total / max(steps_total, 1),
                        'accepted_fraction': accepted_total / storms_total, 'accepted_total': int(accepted_total),

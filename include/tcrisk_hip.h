@@ -182,6 +182,14 @@ int tcr_integrate_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out
  * 2-day test), TCR_EMIT_GRID_CAP (workgroup rows walking the list of storms that pass accept test 1). */
 int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in_dev, const tcr_tracks *out_dev, void *stream);
 
+/* Launch shape of batches that do not fill the chip (fewer than 64 storms per SIMD).  The reference has no counterpart: it
+ * integrates one storm at a time.  storms_per_lane = 1 (default): one integrator lane per storm, the shortest time to a
+ * single batch's results (its longest storm's ~300 sequential evaluations).  k > 1: n / (64 k) persistent waves whose lanes
+ * take ~k storms in turn from the batch's queue — about a third of the SIMD time per batch at k = 4 for a ~1.4x longer
+ * chain, which is what a caller with many batches in flight on other streams / contexts wants (bench.py, pipelined years).
+ * Results do not depend on it. */
+int tcr_schedule_set(tcr_ctx *ctx, int32_t storms_per_lane);
+
 /* The fp32 variant of the same path (BASELINE config 5; the reference itself is fp64 throughout, so this is a
  * documented departure with a stated tolerance, see DESIGN.md and profiles/r02_fp32_study.json): fields are
  * converted to fp32 on the device on first use, state / stage derivatives / right-hand side / dense output are
@@ -304,6 +312,15 @@ typedef struct {
  * replayed rounds.  A context is used from one stream at a time, as for every other entry point. */
 int tcr_round_dev(tcr_ctx *ctx, const tcr_round *round, uint64_t experiment_seed, int32_t year, int64_t cand0,
                   int32_t use_graph, void *stream);
+/* Stage trace of directly enqueued rounds (measurement aid; replayed rounds record nothing): with it enabled tcr_round_dev
+ * records a HIP event behind every stage, and tcr_stage_trace_sum returns, per stage, the summed time from the previous
+ * event of the stream to the stage's own — i.e. how long the stream took to get through that stage, waiting included —
+ * over the *n_rounds rounds since the trace was enabled (which also resets it). */
+enum { TCR_STAGE_START = 0, TCR_STAGE_SEED, TCR_STAGE_SELECT, TCR_STAGE_ORDER, TCR_STAGE_GATHER, TCR_STAGE_FOURIER,
+       TCR_STAGE_INTEGRATE, TCR_STAGE_SCREEN, TCR_STAGE_SELECT_TC, TCR_STAGE_DENSE, TCR_STAGE_EMIT, TCR_STAGE_FLAGS,
+       TCR_STAGE_STATS, TCR_STAGE_PACK, TCR_N_STAGES };
+int tcr_stage_trace_enable(tcr_ctx *ctx, int on);
+int tcr_stage_trace_sum(tcr_ctx *ctx, double ms[TCR_N_STAGES], int64_t *n_rounds);
 /* graphs this context holds / replays since it was created (test and measurement aid) */
 int tcr_round_graph_stats(tcr_ctx *ctx, int64_t *n_graphs, int64_t *n_replays);
 

@@ -138,3 +138,31 @@ def test_round_short_of_storms_and_over_capacity(golden_env, built_lib):
     rc = eng.L.tcr_stats_dev(eng.h, 1000, None, C.byref(q._tracks_struct()), st.data_ptr(), 7, None)
     assert rc != 0 and b'n_out' in eng.L.tcr_last_error(eng.h)
     eng.close()
+
+
+def test_results_do_not_depend_on_the_launch_shape(golden_env, built_lib):
+    """tcr_schedule_set (storms per integrator lane) changes how many persistent waves a batch that does not fill the chip
+    gets, never a storm: a round at 1, 3 and 8 storms per lane is bit-identical, direct and replayed (the graph is
+    re-captured when the shape changes)."""
+    import torch
+    from tropical_cyclone_risk_amd import _lib
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    from tropical_cyclone_risk_amd.pipeline import DevicePipeline
+    eng = TCEngine('GL', device=0).stage_env(golden_env)
+    n_cand, B, cap = 24000, 6000, 1500
+    p = DevicePipeline(eng, n_cand, B, sort_storms=2.0, tc_rows_only=True)
+    packed = torch.zeros(cap, 9 * eng.n_steps + 3, dtype=torch.float64, device=p.dev)
+    st = torch.zeros(_lib.N_STATS, dtype=torch.int64, device=p.dev)
+    ref = None
+    for spl in (1, 3, 8):
+        eng.schedule(spl)
+        for g in (False, True, True):
+            st.zero_(); packed.fill_(-7.0)
+            p.round(2005, 48000, n_cand, B, stats=st, accepted=True, packed=packed, pack_cap=cap, graph=g)
+            snap = _snapshot(p, packed, st, B)
+            if ref is None:
+                ref = snap
+            _same(ref, snap, (spl, g))
+    with pytest.raises(_lib.TcrError):
+        eng.schedule(0)
+    eng.close()

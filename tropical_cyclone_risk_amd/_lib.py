@@ -14,6 +14,7 @@ TCR_ABI_VERSION = 5
 TCR_NW, TCR_NCOV, TCR_MAX_SERIES, TCR_N_BASINS = 4, 10, 32, 7
 STATUS_GATED, STATUS_FINISHED, STATUS_EVENT, STATUS_STEP_FAIL, STATUS_STEP_OVERFLOW = -1, 0, 1, -2, -3
 FLAG_IS_TC, FLAG_ACCEPTED = 1, 2
+STAGES = ('start', 'seed', 'select', 'order', 'gather', 'fourier', 'integrate', 'screen', 'select_tc', 'dense', 'emit', 'flags', 'stats', 'pack')
 N_STATS = 10        # TCR_N_STATS: words of a tcr_stats_dev / tcr_round.stats counter block
 
 DP = C.POINTER(C.c_double)
@@ -30,7 +31,7 @@ EXPORTS = ('tcr_abi_version', 'tcr_ctx_create', 'tcr_ctx_destroy', 'tcr_last_err
            'tcr_potential_intensity_host', 'tcr_potential_intensity_dev', 'tcr_chi_rh_host',
            'tcr_integrate_probe_host', 'tcr_integrate_f32_dev', 'tcr_integrate_f32_host', 'tcr_pack_tracks_f32_dev',
            'tcr_wind_stats_f32_dev', 'tcr_wind_stats_f32_host', 'tcr_static_upload2', 'tcr_init_m_dev', 'tcr_init_m_host', 'tcr_cell_order_dev',
-           'tcr_round_dev', 'tcr_round_graph_stats', 'tcr_seed_hist_dev', 'tcr_pack_tracks_meta_dev')
+           'tcr_round_dev', 'tcr_round_graph_stats', 'tcr_schedule_set', 'tcr_stage_trace_enable', 'tcr_stage_trace_sum', 'tcr_seed_hist_dev', 'tcr_pack_tracks_meta_dev')
 
 
 class Grid(C.Structure):
@@ -175,6 +176,9 @@ def lib():
                                        C.POINTER(Seeds), C.c_uint64, C.c_int32, C.c_int64, C.c_void_p]
     L.tcr_stats_dev.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(Tracks), C.c_void_p, C.c_int32, C.c_void_p]
     L.tcr_round_dev.argtypes = [C.c_void_p, C.POINTER(Round), C.c_uint64, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]
+    L.tcr_schedule_set.argtypes = [C.c_void_p, C.c_int32]
+    L.tcr_stage_trace_enable.argtypes = [C.c_void_p, C.c_int]
+    L.tcr_stage_trace_sum.argtypes = [C.c_void_p, DP, C.POINTER(C.c_int64)]
     L.tcr_round_graph_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.tcr_seed_hist_dev.argtypes = [C.c_void_p, C.POINTER(Seeds), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tcr_pack_tracks_meta_dev.argtypes = [C.c_void_p, C.POINTER(Tracks), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,

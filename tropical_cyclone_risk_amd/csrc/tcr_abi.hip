@@ -83,7 +83,7 @@ struct tcr_ctx {
     size_t fs_cap = 0, srec_cap = 0;
     double *d_vrec = nullptr;                     // the v part of the step records, packed (k_integrate -> k_screen)
     size_t vrec_cap = 0;
-    int32_t *d_tiles = nullptr;
+    unsigned long long *d_tiles = nullptr;      // scratch of k_compact: ticket, generation, one word per tile (zeroed when allocated)
     size_t tiles_cap = 0;
     unsigned long long *d_queue = nullptr;      // work-queue heads and parked-storm counts of k_integrate's passes
     uint16_t *d_sidx = nullptr;                 // sample -> accepted-step map (k_dense -> k_emit)
@@ -115,6 +115,7 @@ struct tcr_ctx {
     // rounds replayed from captured graphs (tcr_round_dev): the device copy of the round key the replayed kernels read, the
     // graphs keyed by the bytes of their descriptor, and an epoch that every allocation / parameter change bumps (a graph
     // holds the workspaces' addresses and the parameters by value)
+    int storms_per_lane = 1;                    // tcr_schedule_set
     RoundKey *d_round_key = nullptr;
     uint64_t epoch = 0;
     bool capturing = false;
@@ -125,6 +126,11 @@ struct tcr_ctx {
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
+    // stage trace (tcr_stage_trace_enable): one event behind every stage of a directly enqueued round
+    bool stage_trace = false;
+    std::vector<hipEvent_t> st_pool;
+    std::vector<int> st_id;
+    size_t st_used = 0;
 };
 
 namespace {
@@ -284,6 +290,13 @@ unsigned integrate_waves(const tcr_ctx *ctx, int64_t n, int wps)
         if (v > 0) return (unsigned)(v < waves ? v : waves);
     }
     if (waves > simds) waves = (n >= simds * kWave * 4) ? 2 * simds : simds;
+    else if (ctx->storms_per_lane > 1) {
+        // a batch that does not fill the chip, on a context set up for throughput (tcr_schedule_set): fewer waves whose lanes
+        // take several storms in turn — the queue balances the lifetimes, so a batch costs a third of the SIMD time (lane
+        // utilisation 0.44 -> 0.8) and leaves SIMDs to the batches other streams have in flight, for a ~1.4x longer chain
+        const int64_t w = (n + (int64_t)kWave * ctx->storms_per_lane - 1) / ((int64_t)kWave * ctx->storms_per_lane);
+        waves = std::max<int64_t>(std::min<int64_t>(waves, 16), w);
+    }
     return (unsigned)(waves < 1 ? 1 : waves);
 }
 
@@ -354,6 +367,23 @@ struct DevBuf {
         return d;
     }
 };
+
+// stage trace: an event labelled with the stage that has just been enqueued (not while a round is being captured)
+int stage_mark(tcr_ctx *ctx, hipStream_t st, int id)
+{
+    if (!ctx->stage_trace || ctx->capturing) return 0;
+    if (ctx->st_used == ctx->st_pool.size()) {
+        const size_t old = ctx->st_pool.size();
+        ctx->st_pool.resize(old + 256, nullptr);
+        ctx->st_id.resize(old + 256, 0);
+        for (size_t i = old; i < ctx->st_pool.size(); ++i) HIPCHK(ctx, hipEventCreate(&ctx->st_pool[i]));
+    }
+    ctx->st_id[ctx->st_used] = id;
+    HIPCHK(ctx, hipEventRecord(ctx->st_pool[ctx->st_used], st));
+    ++ctx->st_used;
+    return 0;
+}
+#define STAGE(id) do { if (stage_mark(ctx, (hipStream_t)st, id)) return -1; } while (0)
 
 // per timed call: [0] start, [1] table (first segment) written, [2] integration chain done, [3] post-processing done,
 // [4], [5] around the table's second segment inside the chain (recorded back to back when there is none)
@@ -641,6 +671,7 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
         }
     }
     if (launch_fourier<R>(ctx, n, in->n_dev, in->phases, fs, st, segmented ? kFsFirst : kFsAll)) return -1;
+    STAGE(TCR_STAGE_FOURIER);
     if (ev) HIPCHK(ctx, hipEventRecord(ev[1], st));
     {
         KArgsT<R> a{};
@@ -696,6 +727,7 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
         }
         if (ev && !seg_events) { HIPCHK(ctx, hipEventRecord(ev[4], st)); HIPCHK(ctx, hipEventRecord(ev[5], st)); }
     }
+    STAGE(TCR_STAGE_INTEGRATE);
     if (ev) HIPCHK(ctx, hipEventRecord(ev[2], st));
     {
         EArgsT<R> a{};
@@ -718,7 +750,9 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
                 ctx->tc_idx_cap = (size_t)n;
             }
             hipLaunchKernelGGL(k_screen<R>, dim3((unsigned)((n + kScreenStorms - 1) / kScreenStorms)), dim3(kScreenThreads), 0, st, a);
+            STAGE(TCR_STAGE_SCREEN);
             if (tcr_compact_dev(ctx, n, out.flags, TCR_FLAG_IS_TC, n, ctx->d_tc_idx, ctx->d_tc_count, st)) return -1;
+            STAGE(TCR_STAGE_SELECT_TC);
             a.list = ctx->d_tc_idx; a.count = ctx->d_tc_count;
         }
         // k_dense, TC rows only: a bounded grid of waves walks the device-side list (one wave per storm otherwise)
@@ -726,6 +760,7 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
         if (const char *e = getenv("TCR_EMIT_GRID_CAP")) { const long v = atol(e); if (v > 0) cap = v; }     // tests: force several list entries per workgroup
         const unsigned gx = out.tc_rows_only ? (unsigned)std::min<int64_t>(n, cap) : (unsigned)n;
         hipLaunchKernelGGL(k_dense<R>, dim3(gx), dim3(kWave), 0, st, a, ctx->d_sidx);
+        STAGE(TCR_STAGE_DENSE);
         // TC rows only: a bounded grid walks the device-side list (all rows: one row of workgroups per storm)
         const unsigned ex = gx;
         if (out.tc_rows_only) {
@@ -744,8 +779,10 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
             if (affine) hipLaunchKernelGGL((k_emit<R, true, false>), dim3(ex, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
             else hipLaunchKernelGGL((k_emit<R, false, false>), dim3(ex, chunks), dim3(kPostThreads), 0, st, a, ctx->d_sidx);
         }
+        STAGE(TCR_STAGE_EMIT);
         hipLaunchKernelGGL(k_flags<R>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, n, out.n_valid,
                            out.status, out.v, out.flags, out.pad_state, a.list, a.count, a.n_dev);
+        STAGE(TCR_STAGE_FLAGS);
     }
     if (ev) HIPCHK(ctx, hipEventRecord(ev[3], st));
     HIPCHK(ctx, hipGetLastError());
@@ -804,6 +841,7 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_mask_bits);
     (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_srec); (void)hipFree(ctx->d_vrec);
     for (auto &ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : ctx->st_pool) if (ev) (void)hipEventDestroy(ev);
     for (auto &g : ctx->graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
     (void)hipFree(ctx->d_round_key);
     (void)hipFree(ctx->d_cell); (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_seg_sids); (void)hipFree(ctx->d_screen_skip); (void)hipFree(ctx->d_und_list); (void)hipFree(ctx->d_und_count); (void)hipFree(ctx->d_tab);
@@ -1440,19 +1478,15 @@ int tcr_compact_dev(tcr_ctx *ctx, int64_t n, const int32_t *flags, int32_t mask,
     if (!flags || !idx || !count || n < 0 || max_out < 0) return fail(ctx, "tcr_compact_dev: bad argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
-    const int64_t tiles = (n + kScanTile - 1) / kScanTile;
-    if ((size_t)tiles + 1 > ctx->tiles_cap) {
+    const int64_t tiles = std::max<int64_t>(1, (n + kScanTile - 1) / kScanTile);       // (n == 0: one tile writes *count = 0)
+    if ((size_t)tiles + 2 > ctx->tiles_cap) {
         if (ctx->d_tiles) HIPCHK(ctx, hipFree(ctx->d_tiles));
         ctx->d_tiles = nullptr; ctx->tiles_cap = 0;
         if (dev_alloc(ctx, &ctx->d_tiles, (size_t)tiles + 1024)) return -1;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_tiles, 0, sizeof(unsigned long long) * ((size_t)tiles + 1024), st));
         ctx->tiles_cap = (size_t)tiles + 1024;
     }
-    if (tiles > 0)
-        hipLaunchKernelGGL(k_compact_count, dim3((unsigned)tiles), dim3(kScanThreads), 0, st, n, flags, mask, ctx->d_tiles);
-    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, (int)tiles, ctx->d_tiles, count);
-    if (tiles > 0)
-        hipLaunchKernelGGL(k_compact_write, dim3((unsigned)tiles), dim3(kScanThreads), 0, st, n, flags, mask,
-                           ctx->d_tiles, max_out, idx);
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)tiles), dim3(kScanThreads), 0, st, n, flags, mask, max_out, idx, count, ctx->d_tiles, (int)tiles);
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
@@ -1488,7 +1522,7 @@ int tcr_cell_order_dev(tcr_ctx *ctx, const tcr_seeds *cand, int32_t *idx, int64_
     a.inv_cell = 1.0 / cell_deg;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_cell_key, dim3(blocks), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(kCellScanThreads), 0, st, a);
     hipLaunchKernelGGL(k_cell_scatter, dim3(blocks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_cell_rank, dim3((unsigned)((std::max<int64_t>(n, a.nbins + 1) + 255) / 256)), dim3(256), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
@@ -1609,16 +1643,42 @@ int seed_hist_impl(tcr_ctx *ctx, const tcr_seeds *cand, int64_t n, int64_t cand0
     return 0;
 }
 
+// scheduling probes (tools / DESIGN.md section 9, round 4): TCR_DUMMY_LAUNCHES=k empty one-wave kernels and TCR_DUMMY_SPIN_US=t, one wave
+// that spins for t microseconds, per round
+__global__ void k_probe_empty() {}
+__global__ void k_probe_store(unsigned long long *p) { if (threadIdx.x == 0) p[blockIdx.x * 16] = clock64(); }
+__global__ void k_probe_spin(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 // Everything a round enqueues (see tcr_round_dev in the header).  key != NULL: the replayable form — seed / year / cand0
 // are read on the device.
 int enqueue_round(tcr_ctx *ctx, const tcr_round *r, uint64_t seed, int32_t year, int64_t cand0, const RoundKey *key, void *st)
 {
     tcr_seeds cand = r->cand, storms = r->storms;
     cand.n = r->n_cand; storms.n = r->n_storms;
+    STAGE(TCR_STAGE_START);
     if (seed_impl(ctx, seed, year, cand0, key, &cand, st)) return -1;
+    STAGE(TCR_STAGE_SEED);
+    if (const char *e = getenv("TCR_DUMMY_LAUNCHES")) {
+        const char *m = getenv("TCR_DUMMY_MODE");
+        const int mode = m ? atoi(m) : 0;       // 0: one empty wave; 1: 50 empty workgroups of 256; 2: one wave, one store; 3: 50 x 256, a store each
+        for (long k = atol(e); k > 0; --k) {
+            if (mode == 0) hipLaunchKernelGGL(k_probe_empty, dim3(1), dim3(64), 0, (hipStream_t)st);
+            else if (mode == 1) hipLaunchKernelGGL(k_probe_empty, dim3(50), dim3(256), 0, (hipStream_t)st);
+            else if (mode == 2) hipLaunchKernelGGL(k_probe_store, dim3(1), dim3(64), 0, (hipStream_t)st, reinterpret_cast<unsigned long long *>(ctx->d_cell));
+            else hipLaunchKernelGGL(k_probe_store, dim3(50), dim3(256), 0, (hipStream_t)st, reinterpret_cast<unsigned long long *>(ctx->d_cell) + 4096);
+        }
+    }
+    if (const char *e = getenv("TCR_DUMMY_SPIN_US")) if (atol(e) > 0) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, (hipStream_t)st, 100ll * atol(e));
     if (tcr_compact_dev(ctx, r->n_cand, cand.seed_flags, 2, r->n_storms, r->cand_idx, r->n_passed, st)) return -1;
+    STAGE(TCR_STAGE_SELECT);
     if (r->cell_deg > 0 && tcr_cell_order_dev(ctx, &cand, r->cand_idx, r->n_storms, r->n_passed, r->cell_deg, st)) return -1;
+    STAGE(TCR_STAGE_ORDER);
     if (gather_impl(ctx, &cand, r->cand_idx, r->n_storms, r->n_passed, &storms, seed, year, cand0, key, st)) return -1;
+    STAGE(TCR_STAGE_GATHER);
     tcr_storms in{};
     in.n = r->n_storms; in.lon0 = storms.lon0; in.lat0 = storms.lat0; in.v0 = storms.v0; in.m0 = storms.m0; in.h_bl = storms.h_bl;
     in.slot = storms.slot; in.phases = storms.phases; in.n_dev = r->exact_count ? r->n_passed : nullptr;
@@ -1627,6 +1687,7 @@ int enqueue_round(tcr_ctx *ctx, const tcr_round *r, uint64_t seed, int32_t year,
         if (integrate_impl<float>(ctx, &in, tracks_of<float>(reinterpret_cast<const tcr_tracks_f32 *>(&r->tracks)), st)) return -1;
     } else if (integrate_impl<double>(ctx, &in, tracks_of<double>(&r->tracks), st)) return -1;
     if (r->stats && tcr_stats_dev(ctx, r->n_storms, r->n_passed, &r->tracks, r->stats, TCR_N_STATS, st)) return -1;
+    STAGE(TCR_STAGE_STATS);
     if (r->acc_idx) {
         if (!r->n_accepted) return fail(ctx, "tcr_round_dev: acc_idx without n_accepted");
         if (tcr_compact_dev(ctx, r->n_storms, r->tracks.flags, TCR_FLAG_ACCEPTED, r->n_storms, r->acc_idx, r->n_accepted, st)) return -1;
@@ -1641,6 +1702,7 @@ int enqueue_round(tcr_ctx *ctx, const tcr_round *r, uint64_t seed, int32_t year,
         }
     }
     if (r->seed_hist && seed_hist_impl(ctx, &cand, r->n_cand, cand0, key, nullptr, r->seed_hist, st)) return -1;
+    STAGE(TCR_STAGE_PACK);
     return 0;
 }
 
@@ -1720,6 +1782,41 @@ int tcr_round_dev(tcr_ctx *ctx, const tcr_round *r, uint64_t seed, int32_t year,
     hipLaunchKernelGGL(k_set_round_key, dim3(1), dim3(1), 0, st, ctx->d_round_key, seed, year, cand0);
     HIPCHK(ctx, hipGraphLaunch(g->exec, st));
     ++ctx->n_replays;
+    return 0;
+}
+
+int tcr_schedule_set(tcr_ctx *ctx, int32_t storms_per_lane)
+{
+    if (!ctx) return -1;
+    if (storms_per_lane < 1 || storms_per_lane > 64) return fail(ctx, "tcr_schedule_set: storms_per_lane must be in [1, 64]");
+    if (storms_per_lane != ctx->storms_per_lane) ++ctx->epoch;        // captured rounds hold the launch shape
+    ctx->storms_per_lane = storms_per_lane;
+    return 0;
+}
+
+int tcr_stage_trace_enable(tcr_ctx *ctx, int on)
+{
+    if (!ctx) return -1;
+    ctx->stage_trace = on != 0;
+    ctx->st_used = 0;
+    return 0;
+}
+
+int tcr_stage_trace_sum(tcr_ctx *ctx, double ms[TCR_N_STAGES], int64_t *n_rounds)
+{
+    if (!ctx || !ms) return -1;
+    for (int i = 0; i < TCR_N_STAGES; ++i) ms[i] = 0.0;
+    int64_t rounds = 0;
+    if (ctx->st_used) HIPCHK(ctx, hipEventSynchronize(ctx->st_pool[ctx->st_used - 1]));
+    for (size_t i = 0; i < ctx->st_used; ++i) {
+        const int id = ctx->st_id[i];
+        if (id == TCR_STAGE_START) { ++rounds; continue; }
+        if (i == 0 || id < 0 || id >= TCR_N_STAGES) continue;
+        float f = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&f, ctx->st_pool[i - 1], ctx->st_pool[i]));
+        ms[id] += f;
+    }
+    if (n_rounds) *n_rounds = rounds;
     return 0;
 }
 

@@ -15,56 +15,41 @@ constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;                       // items per thread
 constexpr int kScanTile = kScanThreads * kScanItems;
 
-// pass 1: per-tile count of selected items
-__global__ __launch_bounds__(kScanThreads) void k_compact_count(int64_t n, const int32_t *__restrict__ flags,
-                                                                 int32_t mask, int32_t *__restrict__ tile_count)
+// One launch (three until round 4: count, a 1024-thread scan workgroup, write).  A tile's workgroup counts its selected
+// items, publishes the count, adds up the counts of the tiles in front of it — a look-back over their published words, one
+// word per thread, no chain between tiles — and writes its indices at their ranks.  Small workgroups matter as much as the
+// saved launches: next to an integrator wave a SIMD has 88 registers left, so a 1024-thread workgroup (four waves per SIMD)
+// had to wait for a CU without integrator waves.
+//   state[0]      ticket counter: a workgroup's tile is its ticket, so every tile in front of it is already running
+//   state[1]      generation of the last finished launch
+//   state[2 + t]  (generation << 32) | count of tile t — valid for this launch when the generation matches
+// The last tile writes *total and leaves ticket = 0, generation + 1 behind for the next launch on this scratch (launches
+// that share a scratch are ordered by their stream).
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p)
 {
-    __shared__ int s[kScanThreads / 64];
-    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
-    int c = 0;
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        const int64_t i = base + k;
-        if (i < n && (flags[i] & mask)) ++c;
-    }
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) tile_count[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// pass 2: exclusive scan of the tile counts by one workgroup (tiles <= a few thousand)
-__global__ __launch_bounds__(1024) void k_compact_scan(int n_tiles, int32_t *__restrict__ tile_count,
-                                                        int64_t *__restrict__ total)
-{
-    __shared__ int s[1024];
-    int carry = 0;
-    for (int base = 0; base < n_tiles; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < n_tiles ? tile_count[i] : 0;
-        s[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
-            __syncthreads();
-            s[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < n_tiles) tile_count[i] = carry + s[threadIdx.x] - v;     // exclusive
-        const int tile_total = s[1023];
-        __syncthreads();
-        carry += tile_total;
-    }
-    if (threadIdx.x == 0) *total = carry;
-}
-
-// pass 3: write the indices of selected items at their rank (first max_out only)
-__global__ __launch_bounds__(kScanThreads) void k_compact_write(int64_t n, const int32_t *__restrict__ flags,
-                                                                 int32_t mask, const int32_t *__restrict__ tile_off,
-                                                                 int64_t max_out, int32_t *__restrict__ idx)
+__global__ __launch_bounds__(kScanThreads) void k_compact(int64_t n, const int32_t *__restrict__ flags, int32_t mask,
+                                                          int64_t max_out, int32_t *__restrict__ idx, int64_t *__restrict__ total,
+                                                          unsigned long long *__restrict__ state, int n_tiles)
 {
     __shared__ int s[kScanThreads];
-    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    __shared__ int s_tile;
+    __shared__ unsigned s_gen;
+    __shared__ long long s_prefix[kScanThreads / 64];
+    if (threadIdx.x == 0) {
+        s_tile = (int)__hip_atomic_fetch_add(state, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_gen = (unsigned)ld_agent(state + 1) + 1u;
+    }
+    __syncthreads();
+    const int tile = s_tile;
+    const unsigned gen = s_gen;
+    const int64_t base = (int64_t)tile * kScanTile + (int64_t)threadIdx.x * kScanItems;
     int c = 0;
     bool sel[kScanItems];
 #pragma unroll
@@ -81,7 +66,27 @@ __global__ __launch_bounds__(kScanThreads) void k_compact_write(int64_t n, const
         s[threadIdx.x] += t;
         __syncthreads();
     }
-    int64_t rank = (int64_t)tile_off[blockIdx.x] + s[threadIdx.x] - c;
+    const int tile_total = s[kScanThreads - 1];
+    if (threadIdx.x == 0) st_agent(state + 2 + tile, ((unsigned long long)gen << 32) | (unsigned)tile_total);
+    // look-back: the counts of tiles [0, tile), a word per thread
+    long long before = 0;
+    for (int p = threadIdx.x; p < tile; p += kScanThreads) {
+        unsigned long long w = ld_agent(state + 2 + p);
+        while ((unsigned)(w >> 32) != gen) { __builtin_amdgcn_s_sleep(1); w = ld_agent(state + 2 + p); }
+        before += (long long)(unsigned)w;
+    }
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
+    if ((threadIdx.x & 63) == 0) s_prefix[threadIdx.x >> 6] = before;
+    __syncthreads();
+    long long prefix = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / 64; ++w) prefix += s_prefix[w];
+    if (tile == n_tiles - 1 && threadIdx.x == 0) {
+        *total = prefix + tile_total;
+        st_agent(state, 0ull);                          // every ticket of this launch has been taken
+        st_agent(state + 1, (unsigned long long)gen);   // ... and every tile in front has read the generation (it published with it)
+    }
+    int64_t rank = prefix + s[threadIdx.x] - c;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k)
         if (sel[k]) {
@@ -179,37 +184,42 @@ __global__ __launch_bounds__(256) void k_cell_key(CellOrderArgs a)
     atomicAdd(a.hist + k, 1);
 }
 
-// exclusive scan of the cell counts by one workgroup: the counts are staged in LDS with coalesced loads (cells beyond the
-// LDS window are handled in further rounds with a carry), every thread owns a contiguous run of 16 cells, and the 1024 run
-// totals are scanned once per round
-constexpr int kCellScanRun = 16;
-constexpr int kCellScanWin = 1024 * kCellScanRun;
-__global__ __launch_bounds__(1024) void k_cell_scan(CellOrderArgs a)
+// exclusive scan of the cell counts by one workgroup of 256 threads (1024 until round 4: four waves per SIMD do not fit next to
+// an integrator wave, and under load the launch waited for a CU without one): the counts are staged in LDS with coalesced
+// loads (cells beyond the LDS window are handled in further rounds with a carry), every thread owns a contiguous run of 64
+// cells — rows padded by one word so that the 64 lanes of a wave walk 64 different banks — and the 256 run totals are scanned
+// once per round
+constexpr int kCellScanThreads = 256;
+constexpr int kCellScanRun = 64;
+constexpr int kCellScanWin = kCellScanThreads * kCellScanRun;
+__device__ __forceinline__ int cell_lds(int i) { return i + i / kCellScanRun; }
+__global__ __launch_bounds__(kCellScanThreads) void k_cell_scan(CellOrderArgs a)
 {
-    __shared__ int v[kCellScanWin];
-    __shared__ int s[1024];
+    __shared__ int v[kCellScanWin + kCellScanThreads];
+    __shared__ int s[kCellScanThreads];
     int carry = 0;
     for (int base = 0; base < a.nbins; base += kCellScanWin) {
-        for (int i = threadIdx.x; i < kCellScanWin; i += 1024) v[i] = (base + i < a.nbins) ? a.hist[base + i] : 0;
+        for (int i = threadIdx.x; i < kCellScanWin; i += kCellScanThreads) v[cell_lds(i)] = (base + i < a.nbins) ? a.hist[base + i] : 0;
         __syncthreads();
         int sum = 0;
-#pragma unroll
-        for (int j = 0; j < kCellScanRun; ++j) sum += v[threadIdx.x * kCellScanRun + j];
+        const int row = threadIdx.x * (kCellScanRun + 1);
+#pragma unroll 8
+        for (int j = 0; j < kCellScanRun; ++j) sum += v[row + j];
         s[threadIdx.x] = sum;
         __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
+        for (int off = 1; off < kCellScanThreads; off <<= 1) {
             const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
             __syncthreads();
             s[threadIdx.x] += t;
             __syncthreads();
         }
         int run = carry + s[threadIdx.x] - sum;          // exclusive offset of this thread's first cell
-#pragma unroll
-        for (int j = 0; j < kCellScanRun; ++j) { const int c = v[threadIdx.x * kCellScanRun + j]; v[threadIdx.x * kCellScanRun + j] = run; run += c; }
-        const int total = s[1023];
+#pragma unroll 8
+        for (int j = 0; j < kCellScanRun; ++j) { const int c = v[row + j]; v[row + j] = run; run += c; }
+        const int total = s[kCellScanThreads - 1];
         __syncthreads();
-        for (int i = threadIdx.x; i < kCellScanWin; i += 1024)
-            if (base + i < a.nbins) { a.hist[base + i] = v[i]; a.start[base + i] = v[i]; }
+        for (int i = threadIdx.x; i < kCellScanWin; i += kCellScanThreads)
+            if (base + i < a.nbins) { const int o = v[cell_lds(i)]; a.hist[base + i] = o; a.start[base + i] = o; }
         carry += total;
         __syncthreads();
     }
@@ -296,7 +306,7 @@ template <typename R>
 struct PackArgsT {
     const R *lon, *lat, *v, *m, *vmax, *envw;
     const int32_t *idx;
-    const int64_t *count;       // device scalar written by k_compact_scan
+    const int64_t *count;       // device scalar written by k_compact
     int64_t cap;
     int ns;
     int64_t row_stride;         // doubles between packed rows (>= 9 * ns)

@@ -1121,7 +1121,7 @@ __device__ __forceinline__ void dense_at(const double *__restrict__ srec_storm, 
 // make this kernel wait on memory ~60 % of the time, so the transcendental-heavy vmax math of
 // the same sample runs in its shadow (as a kernel of its own it cost 0.34 ms per 100k storms).
 template <typename R, bool AFFINE, bool LIST>
-__global__ __launch_bounds__(kPostThreads, (LIST ? TCR_EMIT_WPS : TCR_SHADOW_WPS)) void k_emit(EArgsT<R> a, const uint16_t *__restrict__ sidx)
+__global__ __launch_bounds__(kPostThreads, TCR_SHADOW_WPS) void k_emit(EArgsT<R> a, const uint16_t *__restrict__ sidx)
 {
     __shared__ EvalKT<R> K_lds;
     __shared__ const R *s_wind[kEmitSlotCache];

@@ -105,7 +105,9 @@ __device__ __forceinline__ double mask_at(const MaskCorners &c, int bit, const C
 
 constexpr int kMaxRedraw = 1 << 14;
 
-__global__ __launch_bounds__(256) void k_seed(SeedArgs a)
+// Register budget: at most 80 VGPRs (six waves per SIMD), so that a wave fits into the 88 registers an integrator wave of
+// another batch leaves on its SIMD; the unbudgeted kernel took 92 (96 allocated).
+__global__ __launch_bounds__(256, 6) void k_seed(SeedArgs a)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.out.n) return;

@@ -301,6 +301,22 @@ class TCEngine:
         self._ck(self.L.tcr_timing_sum(self.h, ms, C.byref(n)))
         return dict(fourier_ms=ms[0], integrate_ms=ms[1], post_ms=ms[2], calls=int(n.value))
 
+    def schedule(self, storms_per_lane=1):
+        """Launch shape of batches that do not fill the chip (tcr_schedule_set): 1 = lowest latency of one batch, ~4 =
+        throughput with many batches in flight.  Results do not depend on it."""
+        self._ck(self.L.tcr_schedule_set(self.h, int(storms_per_lane)))
+        return self
+
+    def stage_trace(self, on=True):
+        self._ck(self.L.tcr_stage_trace_enable(self.h, 1 if on else 0))
+
+    def stage_trace_sum(self):
+        """Per-stage stream time (ms, waiting included) summed over the directly enqueued rounds since stage_trace()."""
+        ms = (C.c_double * len(_lib.STAGES))()
+        n = C.c_int64(0)
+        self._ck(self.L.tcr_stage_trace_sum(self.h, ms, C.byref(n)))
+        return {k: ms[i] for i, k in enumerate(_lib.STAGES) if i}, int(n.value)
+
     def wind_stats(self, planes, day_start=None):
         """Monthly wind mean / covariance (env_wind.py:180-228) of 4 [n_samples, ...] planes -> [14, ...]."""
         from . import preprocess
