@@ -80,7 +80,7 @@ def test_config3_shape(golden_env, built_lib, tmp_path):
     t0 = time.perf_counter()
     fn = compute.run_downscaling('GL', env=env, nl=nl)
     wall = time.perf_counter() - t0
-    assert env.staged == list(range(1979, 1979 + n_years))
+    assert sorted(env.staged) == list(range(1979, 1979 + n_years))        # every year staged once (two years are in flight: any order)
     out = tio.read_tracks(fn)
     nv = _file_checks(out, nl, n_years, per_year)
     print('config 3: %d tracks in %.1f s (%.3f s per year), file %.2f GB, mean track %.0f h, %d storm-steps'

@@ -433,3 +433,49 @@ def test_wind_stats_host_logic():
         pp.pick_levels([1000, 500], 'hPa')
     dec = [datetime.datetime(2001, 12, 31, 12), datetime.datetime(2002, 1, 1)]
     assert list(pp.month_mask(dec, 2001, 12)) == [True, False]
+
+
+def test_track_file_writer_streams_the_same_file(tmp_path):
+    """io.TrackFileWriter (years handed over as they complete, in any order, rows written at their final place by a
+    background thread) leaves byte for byte the file io.write_tracks writes from the assembled years
+    (util/compute.py:233-264's Dataset in NetCDF-3), and the transform cache of TC_Basin returns what the uncached
+    selection returned."""
+    import types
+    from tropical_cyclone_risk_amd import io as tio, namelist
+    from tropical_cyclone_risk_amd.basins import BASIN_IDS, TC_Basin
+    if tio._try_xarray() is not None:
+        pytest.skip('xarray present: the file is NetCDF-4, written at close')
+    nl = types.SimpleNamespace(**{k: getattr(namelist, k) for k in dir(namelist) if not k.startswith('__')})
+    nl.start_year, nl.end_year, nl.tracks_per_year = 2000, 2004, 9
+    rng = np.random.default_rng(7)
+    years, ns, n = list(range(2000, 2005)), 361, 9
+
+    def year_tuple():
+        def plane():
+            a = rng.standard_normal((n, ns))
+            for r in range(n):
+                a[r, rng.integers(2, ns):] = np.nan
+            return a
+        env = rng.standard_normal((n, ns, 4))
+        return (plane(), plane(), plane(), plane(), plane(), env, rng.integers(1, 13, n).astype(float),
+                np.array([BASIN_IDS[i] for i in rng.integers(0, 7, n)], dtype='U2'), rng.integers(0, 50, (7, 12)).astype(float))
+    out = [year_tuple() for _ in years]
+    b = TC_Basin('GL', nl)
+    nl.output_directory, nl.exp_name = str(tmp_path), 'whole'
+    fn1 = tio.write_tracks(out, years, b, nl)
+    nl.exp_name = 'streamed'
+    w = tio.TrackFileWriter(years, b, nl)
+    for i in (3, 0, 4, 2, 1):
+        w.put(i, out[i])
+    fn2 = w.close()
+    assert open(fn1, 'rb').read() == open(fn2, 'rb').read()
+    got = tio.read_tracks(fn2)
+    assert np.array_equal(got['v_trks'][n:2 * n], out[1][2], equal_nan=True) and list(got['tc_basins'][:n]) == list(out[0][7])
+    # a year with the wrong number of tracks is an error at close, not a corrupt file
+    w = tio.TrackFileWriter(years, b, nl)
+    bad = tuple(x[:5] if i < 8 else x for i, x in enumerate(out[0]))
+    w.put(0, bad)
+    for i in range(1, 5):
+        w.put(i, out[i])
+    with pytest.raises(ValueError):
+        w.close()

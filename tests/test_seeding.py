@@ -176,7 +176,7 @@ def test_product_round_is_device_resident(golden_env, built_lib):
     rows = out['rows'][:n_acc].cpu().numpy()
     # (the round integrates in locality order; accept_loop sorts the accepted rows back by this candidate column)
     assert out['unordered'] and n_acc > 0 and len(np.unique(rows[:, width])) == n_acc and rows[:, width].min() >= 4096 and rows[:, width].max() < 8192
-    assert int(out['bad'].item()) == 0 and h.sum().item() > h2.sum().item() > 0
+    assert int(out['bad'].sum().item()) == 0 and h.sum().item() > h2.sum().item() > 0      # (step-record overflows, seeds without room)
     # the same round through the host-visible pieces: seeds, flags
     flags = rf.pipe.tracks['flags'][:4096].cpu().numpy()
     n_pass = int(rf.pipe.n_passed.item())

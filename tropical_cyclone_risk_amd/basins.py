@@ -57,19 +57,49 @@ class TC_Basin:
         return (np.concatenate((lon[~west], lon[west] + 360)),
                 np.concatenate((field[:, ~west], field[:, west]), axis=1))
 
+    def _crop_plan(self, lon, lat):
+        """Column / row selection of `transform_global_field` for one pair of axes: (lon_b, lat_b, ix, iy, sx, sy) with ix / iy
+        the source columns / rows in output order and sx / sy the equivalent slices when they are contiguous runs (else None).
+        Cached per axes: a year's 216 planes share two or three grids."""
+        lon = np.asarray(lon)
+        lat = np.asarray(lat)
+        cache = self.__dict__.setdefault('_plans', [])
+        for c_lon, c_lat, plan in cache:
+            if c_lon.shape == lon.shape and c_lat.shape == lat.shape and np.array_equal(c_lon, lon) and np.array_equal(c_lat, lat):
+                return plan
+        x0, y0, x1, y1 = self.get_bounds()
+        ix = np.arange(lon.size)
+        rot = lon
+        if lon[0] >= -_EPS and (x0 < 0 or x1 < 0):
+            east = lon >= (180 - _EPS)                                 # _to_pm180
+            ix = np.concatenate((ix[east], ix[~east]))
+            rot = np.concatenate((lon[east] - 360, lon[~east]))
+        elif (lon < 0).any() and x0 >= 0:
+            west = lon < -_EPS                                         # _to_0_360
+            ix = np.concatenate((ix[~west], ix[west]))
+            rot = np.concatenate((lon[~west], lon[west] + 360))
+        keep_x = (rot <= x1 + _EPS) & (rot >= x0 - _EPS)
+        keep_y = (lat >= y0 - _EPS) & (lat <= y1 + _EPS)
+        ix, iy = ix[keep_x], np.nonzero(keep_y)[0]
+
+        def as_slice(i):
+            return slice(int(i[0]), int(i[-1]) + 1) if i.size and np.array_equal(i, np.arange(i[0], i[0] + i.size)) else None
+        plan = (rot[keep_x], lat[keep_y], ix, iy, as_slice(ix), as_slice(iy))
+        cache.append((lon.copy(), lat.copy(), plan))
+        if len(cache) > 16:
+            del cache[0]
+        return plan
+
     def transform_global_field(self, lon, lat, field):
         """Rotate lon to the basin's sign convention, crop to box ±1e-5.
 
-        field is [lat, lon]; returns (lon_b, lat_b, field_b) (basins.py:57-75).
+        field is [lat, lon]; returns (lon_b, lat_b, field_b) (basins.py:57-75).  The selection is computed once per pair of
+        axes; a plane whose selection is a contiguous block comes back as a view of `field` (no copy).
         """
-        lon = np.asarray(lon)
-        lat = np.asarray(lat)
         field = np.asarray(field)
-        x0, y0, x1, y1 = self.get_bounds()
-        if lon[0] >= -_EPS and (x0 < 0 or x1 < 0):
-            lon, field = self._to_pm180(lon, field)
-        elif (lon < 0).any() and x0 >= 0:
-            lon, field = self._to_0_360(lon, field)
-        keep_x = (lon <= x1 + _EPS) & (lon >= x0 - _EPS)
-        keep_y = (lat >= y0 - _EPS) & (lat <= y1 + _EPS)
-        return lon[keep_x], lat[keep_y], field[keep_y][:, keep_x]
+        lon_b, lat_b, ix, iy, sx, sy = self._crop_plan(lon, lat)
+        if sx is not None and sy is not None:
+            return lon_b, lat_b, field[sy, sx]
+        if sy is not None:
+            return lon_b, lat_b, field[sy][:, ix]
+        return lon_b, lat_b, field[iy][:, ix]

@@ -65,7 +65,8 @@ def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000):
     round_fn(cand0, count) handles the candidates [cand0, cand0+count) of THIS rank and returns, on its device,
         rows   float64 [cap, 9*n_steps + 3]: survivor records (lon, lat, v, m, vmax, envw[ns][4]) of the accepted
                tracks in candidate order, then the columns global candidate index, month, basin index
-        count  int64 [1]: how many rows are valid;  bad int64 [1]: storms that overflowed their step record
+        count  int64 [1]: how many rows are valid;  bad int64 [1] or [2]: storms that overflowed their step record and
+               (optional) passing seeds that did not fit the round's storm capacity
         hist(cutoff=None) -> float64 [7*12]: candidates counting toward n_seeds (compute.py:165-167) per
                (basin, month), optionally only those with global index <= cutoff
     (or the host-array dict of `_legacy_round`).  Survivor rows never leave the device between the kernels
@@ -85,14 +86,25 @@ def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000):
             if 'rows' not in out:
                 out = _legacy_round(out, cand0, n_steps, torch)
             # ---- the one host synchronisation of the round: (accepted, overflowed) of every rank
-            pairs = D.allgather_ints(torch.cat([out['count'].reshape(1), out['bad'].reshape(1)]))
-            counts, bads = [p[0] for p in pairs], [p[1] for p in pairs]
-            if not sum(bads):
+            bad = out['bad'].reshape(-1)
+            if bad.numel() < 2:
+                bad = torch.cat([bad, torch.zeros(1, dtype=bad.dtype, device=bad.device)])
+            pairs = D.allgather_ints(torch.cat([out['count'].reshape(1), bad[:2]]))
+            counts, bads, drops = [p[0] for p in pairs], [p[1] for p in pairs], [p[2] for p in pairs]
+            if not (sum(bads) or sum(drops)):
                 break
-            # A storm needed more accepted RK steps than its step record holds (the reference's solve_ivp is unbounded).
-            # Decided collectively — the counts travelled in the all-gather — so every rank takes the same branch: the
-            # round function doubles the record and the round is integrated again (same candidates, same Philox
-            # streams: same results), or, if it cannot grow, every rank raises and none is left waiting in a collective.
+            # Decided collectively — the counts travelled in the all-gather — so every rank takes the same branch and none
+            # is left waiting in a collective.
+            if sum(drops):
+                # more seeds passed on some rank than its dense batch holds (GpuRound sizes the batch from the measured
+                # pass rate): every rank widens its batch to the whole candidate block and the round runs again — the same
+                # candidates, the same Philox streams, the same results
+                if not (hasattr(round_fn, 'grow_capacity') and round_fn.grow_capacity()):
+                    raise RuntimeError('%d passing seeds did not fit the round\'s storm capacity' % sum(drops))
+                continue
+            # A storm needed more accepted RK steps than its step record holds (the reference's solve_ivp is unbounded):
+            # the round function doubles the record and the round is integrated again, or, if it cannot grow, every rank
+            # raises.
             if not (hasattr(round_fn, 'grow') and round_fn.grow()):
                 raise RuntimeError('%d storms needed more accepted RK steps than the step record holds; raise '
                                    'namelist.gpu_max_rk_steps (tcr_params.max_rk_steps)' % sum(bads))
@@ -139,7 +151,7 @@ class GpuRound:
     (`namelist.gpu_round_graph`); the number of passing seeds, of accepted tracks and of overflowed step records stay
     device scalars, and nothing in a round synchronises with the host."""
 
-    def __init__(self, engine, year, per_rank, experiment_seed=None):
+    def __init__(self, engine, year, per_rank, experiment_seed=None, max_storms=None):
         import torch
         from . import _lib
         from .pipeline import DevicePipeline
@@ -150,12 +162,29 @@ class GpuRound:
         self.per_rank = int(per_rank)
         self.unordered = bool(getattr(engine.nl, 'gpu_locality_order', True))
         self.graph = bool(getattr(engine.nl, 'gpu_round_graph', True))
-        self.pipe = DevicePipeline(engine, per_rank, per_rank, tc_rows_only=True, dtype=getattr(engine.nl, 'gpu_dtype', 'f64'),
+        # The dense batch (rows, step records, forcing tables: ~63 kB per storm) is sized for the seeds that pass, not for
+        # the candidates: the pass rate is measured once on a throw-away block of candidates (18-28 % on the synthetic
+        # basins) and the batch gets 1.3x that + 1 024; a round in which more pass is run again at full width
+        # (`grow_capacity`, decided collectively in accept_loop).
+        if max_storms is None:
+            probe = DevicePipeline(engine, min(self.per_rank, 1 << 16), 64)
+            probe.seed_round(self.year, 10**15, experiment_seed=experiment_seed)
+            p_pass = float(((probe.cand['seed_flags'][:probe.n_cand] & 2) != 0).double().mean().item())
+            del probe
+            max_storms = int(self.per_rank * min(1.0, 1.3 * p_pass)) + 1024
+        self.B = int(min(self.per_rank, max(64, max_storms)))
+        self._build()
+
+    def _build(self):
+        from . import _lib
+        from .pipeline import DevicePipeline
+        torch, engine, per_rank = self.torch, self.eng, self.per_rank
+        self.pipe = DevicePipeline(engine, per_rank, self.B, tc_rows_only=True, dtype=getattr(engine.nl, 'gpu_dtype', 'f64'),
                                    sort_storms=self.unordered)
         dev = self.pipe.dev
         # survivor records: 26 kB per accepted track.  1-6 % of a round's candidates are accepted, so the buffer is sized
         # for a quarter of them (65 536 candidates: 0.43 GB instead of 1.7) and grows — `repack` — in the round that needs more
-        self.cap = max(1024, per_rank // 4)
+        self.cap = min(self.B, max(1024, per_rank // 4))
         self.packed = torch.zeros(self.cap, ROW_VARS * engine.n_steps + N_META, dtype=torch.float64, device=dev)
         self.stats = torch.zeros(_lib.N_STATS, dtype=torch.int64, device=dev)
         self.hist_round = torch.zeros(len(BASIN_IDS) * 12, dtype=torch.int64, device=dev)
@@ -166,13 +195,22 @@ class GpuRound:
         self.year = int(year)
         return self
 
+    def grow_capacity(self):
+        """A round had more passing seeds than the dense batch holds: widen it to the whole candidate block (then nothing can
+        be dropped).  False when it already is that wide."""
+        if self.B >= self.per_rank:
+            return False
+        self.B = self.per_rank
+        self._build()
+        return True
+
     def grow(self):
         """Double the per-storm step record (tcr_params.max_rk_steps).  False once it is at its limit, or when the records
         of a round (per_rank x max_rk_steps x ~400 B) would take more than half of the free HBM — the caller then raises
         the explicit 'raise gpu_max_rk_steps' error instead of running into an allocation failure."""
         cur = int(self.eng.params.max_rk_steps) or 64
         free = self.torch.cuda.mem_get_info(self.pipe.dev)[0] if self.pipe.dev.type == 'cuda' else 1 << 62
-        if self.per_rank * 2 * cur * 400 > free // 2:
+        if self.B * 2 * cur * 400 > free // 2:
             return False
         return self.eng.grow_step_record()
 
@@ -186,11 +224,15 @@ class GpuRound:
         self.pipe.pack_accepted_meta(self.packed, cap, cand0)
         return self.packed[:cap]
 
+    def release(self):
+        """Drop the device buffers (the engine's workspaces stay)."""
+        self.pipe = self.packed = None
+
     def __call__(self, cand0, count):
         p = self.pipe
         self.stats.zero_()
         cap = min(self.cap, count)
-        p.round(self.year, cand0, count, count, self.seed, exact_count=True, stats=self.stats, accepted=True,
+        p.round(self.year, cand0, count, min(self.B, count), self.seed, exact_count=True, stats=self.stats, accepted=True,
                 packed=self.packed, pack_cap=cap, seed_hist=self.hist_round, graph=self.graph)
         self._last = (cand0, count)
         hist_full = self.hist_round.double()          # a copy: the next round overwrites the buffer
@@ -199,8 +241,9 @@ class GpuRound:
             if cutoff is None:
                 return hist_full
             return p.seed_hist(self.hist_cut, cutoff).double()
-        # stats[8]: storms whose step record overflowed (status -3) among the storms of this round
-        return dict(rows=self.packed[:cap], count=p.n_accepted, bad=self.stats[8:9], hist=hist, unordered=self.unordered)
+        # stats[8]: storms whose step record overflowed (status -3) among the storms of this round; stats[9]: passing seeds
+        # that did not fit the dense batch
+        return dict(rows=self.packed[:cap], count=p.n_accepted, bad=self.stats[8:10], hist=hist, unordered=self.unordered)
 
 
 def rows_to_tuple(res, n_steps):
@@ -215,13 +258,19 @@ def rows_to_tuple(res, n_steps):
     return (tc_lon, tc_lat, tc_v, tc_m, tc_vmax, tc_env_wnds, tc_month, tc_basin, res['n_seeds'])
 
 
-def run_tracks(year, n_tracks, b, engine=None, env=None, nl=None, per_rank=None, info=None):
+def default_per_rank(nl, n_tracks):
+    """Candidates a rank seeds per round: enough for the quota in one or two rounds, at most namelist.gpu_candidate_round."""
+    return int(max(4096, min(nl.gpu_candidate_round, 64 * n_tracks)))
+
+
+def run_tracks(year, n_tracks, b, engine=None, env=None, nl=None, per_rank=None, info=None, round_fn=None):
     """Generate n_tracks TC tracks in basin b for one year (reference: compute.py:64-210).
 
     Returns (tc_lon, tc_lat, tc_v, tc_m, tc_vmax, tc_env_wnds, tc_month, tc_basin, n_seeds).
     ``engine`` is a staged TCEngine; if omitted one is built from ``env`` (a field set shaped
     like ``synthetic.SyntheticEnv``) on this rank's GPU.  ``info`` (a dict, optional) receives what the
     reference's loop keeps implicit: ``cand`` (global candidate index of every returned track) and ``rounds``.
+    ``round_fn``: a GpuRound of the same engine to reuse (its buffers and its captured round) for this year.
     """
     nl = nl or default_namelist
     basin_id = b.basin_id if isinstance(b, TC_Basin) else b
@@ -230,8 +279,11 @@ def run_tracks(year, n_tracks, b, engine=None, env=None, nl=None, per_rank=None,
         from .engine import TCEngine
         import os
         engine = TCEngine(basin_id, device=D.local_device(os.environ.get('LOCAL_RANK', '0')), nl=nl).stage_env(env)
-    per_rank = int(per_rank or max(4096, min(nl.gpu_candidate_round, 64 * n_tracks)))
-    rf = GpuRound(engine, year, per_rank)
+    if round_fn is not None:
+        rf, per_rank = round_fn.set_year(year), round_fn.per_rank
+    else:
+        per_rank = int(per_rank or default_per_rank(nl, n_tracks))
+        rf = GpuRound(engine, year, per_rank)
     res = accept_loop(rf, n_tracks, per_rank, engine.n_steps)
     if info is not None:
         info.update(cand=res['cand'], rounds=res['rounds'], per_rank=per_rank)
@@ -242,26 +294,78 @@ def run_tracks(year, n_tracks, b, engine=None, env=None, nl=None, per_rank=None,
 
 def run_downscaling(basin_id, env=None, nl=None, out_dir=None):
     """Run every year of the namelist for one basin and write the track file
-    (reference: compute.py:216-270).  Returns the output file name (rank 0) or None."""
+    (reference: compute.py:216-270).  Returns the output file name (rank 0) or None.
+
+    The reference hands the years to dask workers, one process per year (compute.py:223-230).  Here the years are
+    independent too — a year's tracks depend on (experiment seed, year) alone — and on one GPU
+    ``namelist.gpu_years_in_flight`` (default 3) of them are in flight: each worker thread owns a context with its own
+    month slots, stages its year's fields while the other's rounds run on the GPU, and reuses one set of round buffers
+    (and one captured round) for all its years; finished years go to a background writer that puts their rows at their
+    final place in the track file (`io.TrackFileWriter`), so the file is complete shortly after the last year.  With
+    several ranks (one per GPU) a year's candidate blocks are sharded over them and the years run one after another:
+    the per-round collectives must be issued in one order.
+    """
     from . import io as tio
     nl = nl or default_namelist
     import os
+    import threading
+    import torch
+    from . import _lib
     from .engine import TCEngine
+    _lib.lib()                 # (loaded once, before the worker threads)
     b = TC_Basin(basin_id, nl)
     if env is None:
         env = tio.load_env(nl)
     s = time.time()
-    eng = TCEngine(basin_id, device=D.local_device(os.environ.get('LOCAL_RANK', '0')), nl=nl).stage_env(env)
-    out = []
     years = list(range(nl.start_year, nl.end_year + 1))
-    for yr in years:
-        if hasattr(env, 'for_year'):
-            eng.stage_env(env.for_year(yr))
-        out.append(run_tracks(yr, nl.tracks_per_year, b, engine=eng, nl=nl))
-    eng.close()
+    yearly = hasattr(env, 'for_year')
+    device = D.local_device(os.environ.get('LOCAL_RANK', '0'))
+    n_workers = max(1, min(int(getattr(nl, 'gpu_years_in_flight', 3)), len(years))) if D.world() == 1 else 1
+    out = [None] * len(years)
+    writer = tio.TrackFileWriter(years, b, nl, out_dir) if (D.rank() == 0 and D.world() == 1) else None
+    errors = []
+
+    def work(w):
+        try:
+            dev = torch.device('cuda', device)
+            # (a worker's launches go to its own stream; the legacy default stream would order the workers behind each other)
+            stream = torch.cuda.Stream(device=dev) if n_workers > 1 else torch.cuda.current_stream(dev)
+            eng = TCEngine(basin_id, device=device, nl=nl)
+            eng.schedule(int(getattr(nl, 'gpu_storms_per_lane', 1 if n_workers == 1 else 2)))
+            if not yearly:
+                eng.stage_env(env)
+            rf = None
+            with torch.cuda.stream(stream):
+                for i in range(w, len(years), n_workers):
+                    if errors:
+                        break
+                    yr = years[i]
+                    if yearly:
+                        eng.stage_env(env.for_year(yr))
+                    if rf is None:
+                        rf = GpuRound(eng, yr, default_per_rank(nl, nl.tracks_per_year))
+                    out[i] = run_tracks(yr, nl.tracks_per_year, b, engine=eng, nl=nl, round_fn=rf)
+                    if writer is not None:
+                        writer.put(i, out[i])
+            if rf is not None:
+                rf.release()
+            eng.close()
+        except BaseException as e:          # re-raised by the caller's thread
+            errors.append(e)
+
+    if n_workers == 1:
+        work(0)
+    else:
+        threads = [threading.Thread(target=work, args=(w,), name='year-worker-%d' % w) for w in range(n_workers)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    if errors:
+        raise errors[0]
     fn = None
     if D.rank() == 0:
-        fn = tio.write_tracks(out, years, b, nl, out_dir)
+        fn = writer.close() if writer is not None else tio.write_tracks(out, years, b, nl, out_dir)
         print('Saved %s' % fn)
         print(time.time() - s)
     D.barrier()

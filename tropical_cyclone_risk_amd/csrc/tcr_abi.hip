@@ -116,6 +116,8 @@ struct tcr_ctx {
     // graphs keyed by the bytes of their descriptor, and an epoch that every allocation / parameter change bumps (a graph
     // holds the workspaces' addresses and the parameters by value)
     int storms_per_lane = 1;                    // tcr_schedule_set
+    double *h_stage = nullptr;                  // pinned staging buffer of the field uploads (two halves)
+    size_t h_stage_cap = 0;
     RoundKey *d_round_key = nullptr;
     uint64_t epoch = 0;
     bool capturing = false;
@@ -844,6 +846,7 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     for (auto &ev : ctx->st_pool) if (ev) (void)hipEventDestroy(ev);
     for (auto &g : ctx->graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
     (void)hipFree(ctx->d_round_key);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     (void)hipFree(ctx->d_cell); (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_seg_sids); (void)hipFree(ctx->d_screen_skip); (void)hipFree(ctx->d_und_list); (void)hipFree(ctx->d_und_count); (void)hipFree(ctx->d_tab);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -930,22 +933,38 @@ int tcr_fields_upload(tcr_ctx *ctx, int slot, const tcr_grid *wg, const double *
     if ((size_t)slot >= ctx->slots.size()) ctx->slots.resize(slot + 1);
     SlotStore &s = ctx->slots[slot];
     const size_t nw = (size_t)wg->nlon * wg->nlat, nt = (size_t)tg->nlon * tg->nlat;
-    {   // interleave the 14 wind planes; NaN -> 0 as _interp_basin_field does (bam_track.py:72-74)
-        std::vector<double> h(nw * kWindStride, 0.0);
-        for (int f = 0; f < 14; ++f) {
-            const double *src = f < 4 ? mean[f] : cov[f - 4];
-            if (!src) return fail(ctx, "tcr_fields_upload: NULL wind plane");
-            for (size_t i = 0; i < nw; ++i) { const double x = src[i]; h[i * kWindStride + f] = (x != x) ? 0.0 : x; }
+    for (int f = 0; f < 14; ++f)
+        if (!(f < 4 ? mean[f] : cov[f - 4])) return fail(ctx, "tcr_fields_upload: NULL wind plane");
+    // Interleave on the host into a pinned staging buffer (grid point outermost: one contiguous 128-byte record per point,
+    // fourteen streaming reads) and copy asynchronously; the thermo planes are interleaved into the buffer's other half
+    // while the wind copy is in flight.  (Round 3 walked the 8 MB destination fourteen times with a stride of 128 bytes and
+    // copied from pageable memory: 2.7 ms per month slot, the largest item of a 40-year run — profiles/r04_config3.json.)
+    const size_t need = nw * kWindStride + nt * kThermoStride;
+    if (need > ctx->h_stage_cap) {
+        if (ctx->h_stage) HIPCHK(ctx, hipHostFree(ctx->h_stage));
+        ctx->h_stage = nullptr; ctx->h_stage_cap = 0;
+        HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_stage), need * sizeof(double), hipHostMallocDefault));
+        ctx->h_stage_cap = need;
+    }
+    {   // NaN -> 0 as _interp_basin_field does (bam_track.py:72-74)
+        double *h = ctx->h_stage;
+        const double *src[14];
+        for (int f = 0; f < 14; ++f) src[f] = f < 4 ? mean[f] : cov[f - 4];
+        for (size_t i = 0; i < nw; ++i) {
+            double *o = h + i * kWindStride;
+            for (int f = 0; f < 14; ++f) { const double x = src[f][i]; o[f] = (x != x) ? 0.0 : x; }
+            o[14] = 0.0; o[15] = 0.0;
         }
-        if (!s.wind && dev_alloc(ctx, &s.wind, h.size())) return -1;
-        HIPCHK(ctx, hipMemcpy(s.wind, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+        if (!s.wind && dev_alloc(ctx, &s.wind, nw * kWindStride)) return -1;
+        HIPCHK(ctx, hipMemcpyAsync(s.wind, h, sizeof(double) * nw * kWindStride, hipMemcpyHostToDevice, ctx->stream));
     }
     {
-        std::vector<double> h(nt * kThermoStride);
+        double *h = ctx->h_stage + nw * kWindStride;
         for (size_t i = 0; i < nt; ++i) { h[i * 4] = vpot[i]; h[i * 4 + 1] = chi[i]; h[i * 4 + 2] = mld[i]; h[i * 4 + 3] = strat[i]; }
-        if (!s.thermo && dev_alloc(ctx, &s.thermo, h.size())) return -1;
-        HIPCHK(ctx, hipMemcpy(s.thermo, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+        if (!s.thermo && dev_alloc(ctx, &s.thermo, nt * kThermoStride)) return -1;
+        HIPCHK(ctx, hipMemcpyAsync(s.thermo, h, sizeof(double) * nt * kThermoStride, hipMemcpyHostToDevice, ctx->stream));
     }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     s.f32_stale = true;
     ctx->slots_dirty = true;
     return 0;

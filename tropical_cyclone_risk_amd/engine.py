@@ -167,15 +167,28 @@ class TCEngine:
         self._ck(self.L.tcr_masks_upload(self.h, C.byref(g), run.ctypes.data_as(_lib.U8P), arr))
 
     def stage_env(self, env, months=range(12)):
-        """Stage a ``synthetic.SyntheticEnv``-shaped object (12 monthly field sets)."""
-        self.stage_static(env.hlon, env.hlat, env.land, env.bathy, getattr(env, 'blon', None), getattr(env, 'blat', None))
+        """Stage a ``synthetic.SyntheticEnv``-shaped object (12 monthly field sets).  The static planes (land, bathymetry,
+        basin masks) do not change from year to year: they are staged again only when the environment hands over other
+        arrays than the ones already on the device."""
+        blon, blat = getattr(env, 'blon', None), getattr(env, 'blat', None)
+        static = (env.hlon, env.hlat, env.land, env.bathy, blon, blat)
+        if not self._same(getattr(self, '_staged_static', None), static):
+            self.stage_static(*static)
+            self._staged_static = static
         for mo in months:
             self.stage_month(mo, env.wlon, env.wlat, env.wnd_mean[mo], env.wnd_cov[mo], env.lon, env.lat,
                              env.vpot[mo], env.chi[mo], env.mld[mo], env.strat[mo], env.rh_mid[mo])
         if getattr(env, 'basin_masks', None):
-            self.stage_masks(getattr(env, 'mlon', env.hlon), getattr(env, 'mlat', env.hlat),
-                             env.basin_masks[self.basin.basin_id], env.basin_masks)
+            masks = (getattr(env, 'mlon', env.hlon), getattr(env, 'mlat', env.hlat), env.basin_masks[self.basin.basin_id], env.basin_masks)
+            staged = getattr(self, '_staged_masks', None)
+            if not (self._same(staged and staged[:3], masks[:3]) and all(masks[3][b] is staged[3][b] for b in BASIN_IDS)):
+                self.stage_masks(*masks)
+                self._staged_masks = masks[:3] + (dict(masks[3]),)
         return self
+
+    @staticmethod
+    def _same(a, b):
+        return a is not None and len(a) == len(b) and all(x is y for x, y in zip(a, b))
 
     # -------------------------------------------------------------- hot path
     def init_m(self, storms, dvdt=0.0):
