@@ -28,10 +28,14 @@ Only tests/ and __graft_entry__.smoke() import this.
 import numpy as np
 
 # Tiers on max |got - want| over a storm's hourly lon / lat / v / m / env winds / vmax, about 10x what was measured on
-# 20 000 storms per basin (profiles/r02_parity_study.json: p95 0.8-1.7e-12, p99 2-7e-11; the intensity equation
-# amplifies a perturbation while a storm intensifies, so the far tail grows with the ensemble exactly as the oracle's
-# own response to a one-ulp input change does — the study test bounds p99.9 / max by 10x that twin instead of TOL_ALL)
-TOL_ALL = 1e-6        # every sample of every storm (ensembles of up to a few thousand storms)
+# 20 000 storms per basin (profiles/r03_parity_study.json: p95 1.0-2.2e-12, p99 3-11e-11).  The intensity equation
+# amplifies a perturbation while a storm intensifies, so the far tail grows with the ensemble exactly as the oracle's own
+# response to a one-ulp input change does.  The bound on EVERY sample is therefore stated against that yardstick wherever
+# a replayer is at hand (every caller in tests/ and smoke()): max(TOL_ALL_FLOOR, 10 x the oracle's one-ulp twin's maximum
+# on the same storms) — the twin is only computed when a difference exceeds the floor; TOL_ALL is the fixed bound of a
+# comparison without a replayer.
+TOL_ALL_FLOOR = 1e-7  # every sample of every storm: passes without looking at the twin
+TOL_ALL = 1e-6        # every sample of every storm when there is no oracle twin to measure against
 TOL_99 = 1e-9         # 99 % of the storms: at most n // 100 + 1 storms above it
 TOL_95 = 2e-11        # 95 % of the storms: at most n // 20 + 2 storms above it
 # vmax (wind/tc_wind.py:6-21) contains the translation speed, a centred difference of hourly positions
@@ -73,7 +77,7 @@ def _subset(d, idx, keys):
 
 
 def check_tracks(tag, got, want, dec_got, dec_want, t0_want, t_s, counters=('status', 'n_valid', 'nfev'),
-                 flags=('is_tc', 'accepted'), names=('traj', 'envw', 'vmax'), verbose=True, tol_all=TOL_ALL,
+                 flags=('is_tc', 'accepted'), names=('traj', 'envw', 'vmax'), verbose=True, tol_all=None,
                  replay=None, replay_as='want', tol_99=TOL_99, tol_95=TOL_95):
     """Assert parity of `got` against `want` (dicts of arrays: traj [n,4,ns], envw [n,ns,4], vmax [n,ns],
     status, n_valid, nfev, is_tc, accepted ...) — every storm pointwise over its whole track.
@@ -88,9 +92,30 @@ def check_tracks(tag, got, want, dec_got, dec_want, t0_want, t_s, counters=('sta
     Without `replay` the storms with a differing decision are only prefix-checked and the summary says so
     (`unreplayed`); every caller in tests/ and smoke() passes one.
     Returns a summary dict (counts of storms per class, exposure among accepted storms, worst differences).
-    tol_all: the bound on every sample (TOL_ALL; the large-ensemble study passes its own, see
+    tol_all: the bound on every sample.  None (default): max(TOL_ALL_FLOOR, 10 x the oracle's own one-ulp twin on the same
+    storms — `replay.twin_max()`, c_oracle.replayer) per output, or TOL_ALL when `replay` offers no twin; a number: that
+    bound (the large-ensemble study passes inf and states its own bounds on the tail,
     tests/test_gpu_parity.py::test_parity_study_at_scale)."""
     n = len(want['n_valid'])
+    twin = {}
+
+    def limit(name):
+        """Bound on every sample of output `name` (vmax: the TIER_SCALE of the tiers)."""
+        sc = TIER_SCALE.get(name, 1.0)
+        if tol_all is not None:
+            return tol_all
+        if not hasattr(replay, 'twin_max'):
+            return sc * TOL_ALL
+        if not twin:
+            twin.update(replay.twin_max())
+            if verbose:
+                print('%s: a difference above %.0e — the oracle moves by %s when v0 changes by one ulp' % (tag, TOL_ALL_FLOOR, twin))
+        return max(sc * TOL_ALL_FLOOR, 10.0 * twin.get(name, 0.0))
+
+    def within(name, d):
+        if tol_all is None and d <= TIER_SCALE.get(name, 1.0) * TOL_ALL_FLOOR:
+            return True                                   # under the floor: no need to run the twin
+        return d <= limit(name)
     dec_got, dec_want = np.asarray(dec_got), np.asarray(dec_want)
     k = first_divergence(dec_got, dec_want)
     len_g = (dec_got != NOT_EVAL).sum(axis=1)
@@ -140,8 +165,8 @@ def check_tracks(tag, got, want, dec_got, dec_want, t0_want, t_s, counters=('sta
             d = np.abs(np.nan_to_num(a) - np.nan_to_num(b)).max()
             pref_worst = max(pref_worst, float(d))
             pref_max.append(float(d))
-            assert d <= tol_all, (tag, name, 'prefix of storm %d (first differing decision at evaluation %d, '
-                                  't = %.0f s, %d samples)' % (i, k[i], t0, n_pref), d)
+            assert within(name, d), (tag, name, 'prefix of storm %d (first differing decision at evaluation %d, '
+                                     't = %.0f s, %d samples)' % (i, k[i], t0, n_pref), d, limit(name))
         pref_samples += n_pref
     # ---- ... and the decision-forced replay: the whole track of every such storm, pointwise
     keys = tuple(counters) + tuple(flags) + tuple(names)
@@ -174,7 +199,7 @@ def check_tracks(tag, got, want, dec_got, dec_want, t0_want, t_s, counters=('sta
             print('%s %-5s pointwise over whole tracks: max %.3g  p99 %.3g  p95 %.3g   (n=%d, %d of them replayed)'
                   % (tag, name, worst[name], np.percentile(d, 99) if d.size else 0, np.percentile(d, 95) if d.size else 0,
                      d.size, replayed))
-        assert worst[name] <= tol_all, (tag, name, worst[name], int(np.nanargmax(per_storm[name])))
+        assert within(name, worst[name]), (tag, name, worst[name], int(np.nanargmax(per_storm[name])), limit(name))
         # the tiers as counts, at every ensemble size: at most 1 % (+1) of the storms above tol_99, 5 % (+2) above tol_95
         # (the additive slack only matters for the small curated golden sets, which over-sample intense storms)
         sc = TIER_SCALE.get(name, 1.0)

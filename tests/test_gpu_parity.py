@@ -6,15 +6,22 @@ Stated fp64 tolerance (oracle/parity.py).  The reference integrates adaptively, 
 summation-order differences are amplified along a trajectory, and its over-land test
 ``f_land.ev(lon, lat) == 1`` (intensity/coupled_fast.py:35-38) is decided by rounding in the
 interior of land ("flicker").  Every implementation therefore records the decision of every RHS
-evaluation (tcr_integrate_probe_host; the fixtures hold the reference's own decisions), and the bar is
-  * storms whose decision sequences agree (all clean storms and most exposed ones): discrete results
-    (status, n_valid, nfev, accepted / rejected step counts, accept flags) identical, |Δ| <= 1e-6 on
-    lon/lat/v/m/env winds/vmax for all, <= 1e-8 for 99 % and <= 1e-9 for 95 % of them (the Fourier
-    forcing table is evaluated from an exact one-period sin/cos table, which differs from NumPy by the
-    rounding of NumPy's own argument, ~1e-14);
-  * storms with a differing decision at evaluation k: every hourly sample emitted before the step
-    attempt that contains evaluation k agrees to the same tiers, and both tracks are at least that long.
-No storm is waved through; the exposed fraction among accepted storms is printed and checked.
+evaluation (tcr_integrate_probe_host; the fixtures hold the reference's own decisions), and the bar is,
+for EVERY storm and over its WHOLE track (none skipped, none prefix-only):
+  * storms whose decision sequences agree (all clean storms and ~92 % of the exposed ones): discrete results
+    (status, n_valid, nfev, accepted / rejected step counts, accept flags) identical and the pointwise tiers below;
+  * storms with a differing decision at evaluation k: the differing evaluation itself must be rounding-sensitive
+    (probe bit 2 at evaluation k), the samples before the step attempt that contains it agree, and the C oracle is
+    run again with the other side's decisions forced at its rounding-sensitive evaluations (decision-forced replay,
+    pinned to the reference by tests/golden/forced_*.npz) — after which the whole track is held to the same discrete
+    equalities and the same tiers; the replay must leave no differing decision and report 0 hard mismatches;
+  * tiers on the per-storm maximum over the hourly lon / lat / v / m / env winds (vmax: 5x), as counts: at most
+    n/20 + 2 storms above 2e-11, at most n/100 + 1 above 1e-9 (the curated golden sets and the run_tracks composition
+    state 1e-10 / 2e-10 for the 95 % tier, in the test, with the reason), and on EVERY sample
+    max(1e-7, 10 x the oracle's own response to a one-ulp change of v0 on the same storms) — the intensity equation
+    amplifies a last-bit difference while a storm intensifies, and the oracle's one-ulp twin is the yardstick for how far
+    (test_parity_study_at_scale runs that comparison on 4 000 storms per basin by default, TCR_PARITY_STUDY=<n> for more).
+The exposed fraction among accepted storms is printed and checked.
 """
 import os
 
@@ -494,9 +501,10 @@ def test_wind_stats_kernel_vs_oracle(built_lib):
     eng.close()
 
 
-@pytest.mark.skipif(not os.environ.get('TCR_PARITY_STUDY'), reason='opt-in: TCR_PARITY_STUDY=<storms per basin> writes gpurun_out/parity_study.json')
 def test_parity_study_at_scale(golden_env, built_lib):
-    """The parity tiers of this file on a large random ensemble per basin (profiles/r03_parity_study.json): every storm
+    """The parity tiers of this file on a large random ensemble per basin — 4 000 storms by default (about a minute),
+    TCR_PARITY_STUDY=<storms per basin> for the 20 000 of profiles/r03_parity_study.json; writes
+    gpurun_out/parity_study.json: every storm
     checked pointwise over its whole track against the C oracle — decision-identical storms directly, the others after
     the decision-forced replay; none skipped.  The intensity equation amplifies perturbations
     (an e-folding of hours while a storm intensifies), so over 20 000 fifteen-day tracks a last-bit difference of the
@@ -510,7 +518,7 @@ def test_parity_study_at_scale(golden_env, built_lib):
     from oracle import c_oracle, parity
     from tropical_cyclone_risk_amd import synthetic
     from tropical_cyclone_risk_amd.engine import TCEngine
-    n = int(os.environ['TCR_PARITY_STUDY'])
+    n = int(os.environ.get('TCR_PARITY_STUDY') or 4000)
     out = {'storms_per_basin': n,
            'd_gpu': 'per storm max |GPU - C oracle| over lon, lat, v, m of the hourly samples, ALL storms (the ones with a '
                     'differing land == 1 decision against the decision-forced replay; d_gpu_replayed_storms = those alone)',

@@ -1524,9 +1524,9 @@ int tcr_cell_order_dev(tcr_ctx *ctx, const tcr_seeds *cand, int32_t *idx, int64_
     const int nrow = (int)ceil(180.0 / cell_deg) + 1;
     a.nbins = a.ncol * nrow;
     if (a.nbins > (1 << 20)) return fail(ctx, "tcr_cell_order_dev: too many cells");
-    // scratch (int32): cell counters [nbins + 1] (zero between calls: k_cell_rank leaves them so), offsets [nbins + 1],
-    // then idx copy [n], key [n], tmp [n], tmp_key [n]
-    const size_t head = 2 * ((size_t)a.nbins + 1) + 6;
+    // scratch (int32): cell counters [nbins + 1] (zero between calls: k_cell_rank leaves them so), offsets [nbins + 1], the list
+    // of long cells [nbins + 2], then idx copy [n], key [n], tmp [n], tmp_key [n]
+    const size_t head = 3 * ((size_t)a.nbins + 1) + 8;
     const size_t words = head + 4 * (size_t)n;
     if ((words + 1) / 2 > ctx->cell_cap || ctx->cell_bins != a.nbins) {
         if (grow(ctx, &ctx->d_cell, &ctx->cell_cap, (words + 1) / 2 + 4096)) return -1;
@@ -1534,7 +1534,7 @@ int tcr_cell_order_dev(tcr_ctx *ctx, const tcr_seeds *cand, int32_t *idx, int64_
         ctx->cell_bins = a.nbins;
     }
     int32_t *w = reinterpret_cast<int32_t *>(ctx->d_cell);
-    a.hist = w; a.start = w + a.nbins + 1;
+    a.hist = w; a.start = w + a.nbins + 1; a.long_cells = w + 2 * (a.nbins + 1);
     int32_t *body = w + head;
     a.idx_in = body; a.key = body + n; a.tmp = body + 2 * n; a.tmp_key = body + 3 * n;
     a.lon0 = cand->lon0; a.lat0 = cand->lat0; a.idx_out = idx; a.count = count; a.n = n;
