@@ -422,17 +422,6 @@ void launch_integrate(const KArgsT<float> &a, bool affine, bool, bool split, uns
     launch_integrate_rp<float, false>(a, affine, split, waves, st);      // the decision probe is an fp64 instrument
 }
 
-// zeroes what a batch's kernels accumulate into: k_integrate's queue heads / parked counts / occupancy counters, and — when the
-// 2-day test is decided in flight — flags[0 .. n) and the count of storms accept test 1 is still open for
-__global__ __launch_bounds__(256) void k_batch_reset(unsigned long long *__restrict__ queue, int queue_words,
-                                                     unsigned long long *__restrict__ und_count, int32_t *__restrict__ flags, int64_t n)
-{
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < queue_words) queue[i] = 0ull;
-    if (i == 0 && und_count) *und_count = 0ull;
-    if (i < n) flags[i] = 0;
-}
-
 // ---- fp32 staging: float knots (+ reciprocal widths and the affine test in float arithmetic) and float
 // copies of the interleaved field layouts, converted on the device from the fp64 arrays already staged
 __global__ __launch_bounds__(256) void k_to_f32(const double *__restrict__ src, float *__restrict__ dst, size_t n)
@@ -566,8 +555,14 @@ bool fourier_on_matrix_cores(const tcr_ctx *ctx)
 // part = kFsRest: rows are the storms of the park list `park` (count on the device, at most n)
 template <typename R>
 int launch_fourier(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const double *phases, R *fs, hipStream_t st,
-                   FsPart part = kFsAll, const double *park = nullptr, const unsigned long long *park_count = nullptr)
+                   FsPart part = kFsAll, const double *park = nullptr, const unsigned long long *park_count = nullptr,
+                   const BatchReset *reset = nullptr)
 {
+    // the batch's counters are zeroed by the phase-factor kernel when there is one, else by a launch of their own
+    BatchReset z{};
+    if (reset) z = *reset;
+    if (reset && !(ctx->fs_period > 0 && fourier_on_matrix_cores(ctx)))
+        hipLaunchKernelGGL(k_batch_reset, dim3((unsigned)((std::max<int64_t>(z.n_flags, z.queue_words) + 255) / 256)), dim3(256), 0, st, z);
     const tcr_params &P = ctx->prm;
     if (ctx->fs_period > 0) {
         const size_t lds = sizeof(double2) * (size_t)ctx->fs_period;
@@ -591,7 +586,7 @@ int launch_fourier(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const double *
                 hipLaunchKernelGGL(k_park_sids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, park, park_count, n, ctx->d_seg_sids);
                 list = ctx->d_seg_sids;
             }
-            hipLaunchKernelGGL(k_phase_factors_frag, dim3((unsigned)std::min<int64_t>(tiles, 8192)), dim3(256), 0, st, P, n, n_dev, phases, p, list, park_count);
+            hipLaunchKernelGGL(k_phase_factors_frag, dim3((unsigned)std::min<int64_t>(tiles, 8192)), dim3(256), 0, st, P, n, n_dev, phases, p, list, park_count, z);
             const int groups = part == kFsAll ? kFsMfmaColGroups : 1;
             const unsigned wgs = (unsigned)std::min<int64_t>(tiles, std::max<int64_t>(1, (int64_t)ctx->cu_count * kFsMfmaWgsPerCu * (4 / kFsMfmaWaves) / groups));
             if (part == kFsRest)
@@ -614,8 +609,10 @@ int launch_fourier(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const double *
 }
 
 // The per-candidate body of run_tracks for a batch (see tcr_integrate_dev in the header), in precision R.
+// stats: optional device counter block (TCR_N_STATS words) the batch's sums are added to by k_flags (tcr_round_dev)
 template <typename R>
-int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, void *stream_)
+int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, void *stream_, uint64_t *stats = nullptr,
+                   const int64_t *stats_n_dev = nullptr)
 {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int64_t n = in->n;
@@ -672,7 +669,12 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
             if (!ctx->d_und_count && dev_alloc(ctx, &ctx->d_und_count, (size_t)1)) return -1;
         }
     }
-    if (launch_fourier<R>(ctx, n, in->n_dev, in->phases, fs, st, segmented ? kFsFirst : kFsAll)) return -1;
+    {
+        BatchReset z{};
+        z.queue = ctx->d_queue; z.queue_words = (int)kQueueWords;
+        if (prune_sample >= 0) { z.und_count = ctx->d_und_count; z.flags = out.flags; z.n_flags = n; }
+        if (launch_fourier<R>(ctx, n, in->n_dev, in->phases, fs, st, segmented ? kFsFirst : kFsAll, nullptr, nullptr, &z)) return -1;
+    }
     STAGE(TCR_STAGE_FOURIER);
     if (ev) HIPCHK(ctx, hipEventRecord(ev[1], st));
     {
@@ -689,15 +691,9 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
             // storms still open for accept test 1 when they end: the list k_screen works through (flags of the others stay 0)
             a.und_list = ctx->d_und_list; a.und_count = ctx->d_und_count;
         }
-        // one launch zeroes the work queue / pass counters and, with the in-flight 2-day test, flags[] and the open-storm
-        // count (three hipMemsetAsync until round 4: three fill kernels per batch, and as captured memset nodes of a
-        // replayed round they did not reliably clear flags[] — tests/test_round.py)
-        {
-            const int64_t words = prune_sample >= 0 ? n : 0;
-            const int64_t items = std::max<int64_t>(words, (int64_t)kQueueWords);
-            hipLaunchKernelGGL(k_batch_reset, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, ctx->d_queue, (int)kQueueWords,
-                               prune_sample >= 0 ? ctx->d_und_count : nullptr, out.flags, words);
-        }
+        // (the work queue / pass counters and, with the in-flight 2-day test, flags[] and the open-storm count were zeroed by
+        // the batch's first kernel — BatchReset; three hipMemsetAsync until round 4, which as captured memset nodes of a
+        // replayed round did not reliably clear flags[]: tests/test_round.py)
         // (a segmented first pass can park any number of its storms)
         const size_t park_items = segmented ? (size_t)n : (size_t)waves * kWave;
         if (thr > 0 && grow(ctx, &ctx->d_park[0], &ctx->park_cap[0], park_items * kParkRec)) return -1;
@@ -760,7 +756,9 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
         // k_dense, TC rows only: a bounded grid of waves walks the device-side list (one wave per storm otherwise)
         int64_t cap = kEmitGridCap;
         if (const char *e = getenv("TCR_EMIT_GRID_CAP")) { const long v = atol(e); if (v > 0) cap = v; }     // tests: force several list entries per workgroup
-        const unsigned gx = out.tc_rows_only ? (unsigned)std::min<int64_t>(n, cap) : (unsigned)n;
+        // (a batch of at most two grid caps gets a row of workgroups per storm: no overflow launch — a dispatch costs a small
+        // batch more than 12 000 workgroups that find nothing to do)
+        const unsigned gx = (out.tc_rows_only && n > 2 * cap) ? (unsigned)cap : (unsigned)n;
         hipLaunchKernelGGL(k_dense<R>, dim3(gx), dim3(kWave), 0, st, a, ctx->d_sidx);
         STAGE(TCR_STAGE_DENSE);
         // TC rows only: a bounded grid walks the device-side list (all rows: one row of workgroups per storm)
@@ -783,7 +781,8 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
         }
         STAGE(TCR_STAGE_EMIT);
         hipLaunchKernelGGL(k_flags<R>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, n, out.n_valid,
-                           out.status, out.v, out.flags, out.pad_state, a.list, a.count, a.n_dev);
+                           out.status, out.v, out.flags, out.pad_state, out.tc_rows_only ? 1 : 0, a.n_dev, out.nfev,
+                           reinterpret_cast<unsigned long long *>(stats), stats_n_dev);
         STAGE(TCR_STAGE_FLAGS);
     }
     if (ev) HIPCHK(ctx, hipEventRecord(ev[3], st));
@@ -1703,9 +1702,9 @@ int enqueue_round(tcr_ctx *ctx, const tcr_round *r, uint64_t seed, int32_t year,
     in.slot = storms.slot; in.phases = storms.phases; in.n_dev = r->exact_count ? r->n_passed : nullptr;
     if (r->f32) {
         if (ensure_f32(ctx, (hipStream_t)st)) return -1;
-        if (integrate_impl<float>(ctx, &in, tracks_of<float>(reinterpret_cast<const tcr_tracks_f32 *>(&r->tracks)), st)) return -1;
-    } else if (integrate_impl<double>(ctx, &in, tracks_of<double>(&r->tracks), st)) return -1;
-    if (r->stats && tcr_stats_dev(ctx, r->n_storms, r->n_passed, &r->tracks, r->stats, TCR_N_STATS, st)) return -1;
+        if (integrate_impl<float>(ctx, &in, tracks_of<float>(reinterpret_cast<const tcr_tracks_f32 *>(&r->tracks)), st, r->stats, r->n_passed)) return -1;
+    } else if (integrate_impl<double>(ctx, &in, tracks_of<double>(&r->tracks), st, r->stats, r->n_passed)) return -1;
+    // (the stats of tcr_stats_dev are accumulated by the batch's last kernel, k_flags)
     STAGE(TCR_STAGE_STATS);
     if (r->acc_idx) {
         if (!r->n_accepted) return fail(ctx, "tcr_round_dev: acc_idx without n_accepted");

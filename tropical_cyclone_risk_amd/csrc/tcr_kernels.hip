@@ -251,10 +251,34 @@ constexpr int kFsMfmaMaxSamples = 24 * 16;
 // i = series * 4 + storm_in_tile, k = 2 * harmonic + (0: weight * cos 2 pi x, 1: weight * sin 2 pi x); zero padding.
 // list != NULL: row r of the product is storm list[r], r < *list_count (the second segment of the table, written only for
 // the storms the first integration pass parked); otherwise row r is storm r.
+// What a batch's kernels accumulate into, zeroed by the first kernel of the batch that runs anyway (k_phase_factors_frag;
+// k_batch_reset when the forcing table takes another path): k_integrate's queue heads / parked counts / occupancy counters
+// and — when the 2-day test is decided in flight — flags[0 .. n_flags) and the count of storms accept test 1 is still open for.
+struct BatchReset {
+    unsigned long long *queue;
+    int queue_words;
+    unsigned long long *und_count;
+    int32_t *flags;
+    int64_t n_flags;
+};
+__device__ __forceinline__ void batch_reset(const BatchReset &z, int64_t i, int64_t stride)
+{
+    if (!z.queue) return;
+    for (int64_t k = i; k < z.queue_words; k += stride) z.queue[k] = 0ull;
+    if (i == 0 && z.und_count) *z.und_count = 0ull;
+    for (int64_t k = i; k < z.n_flags; k += stride) z.flags[k] = 0;
+}
+__global__ __launch_bounds__(256) void k_batch_reset(BatchReset z)
+{
+    batch_reset(z, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+}
+
 __global__ __launch_bounds__(256) void k_phase_factors_frag(tcr_params P, int64_t n, const int64_t *__restrict__ n_dev,
                                                             const double *__restrict__ phases, double *__restrict__ frag,
-                                                            const int64_t *__restrict__ list, const unsigned long long *__restrict__ list_count)
+                                                            const int64_t *__restrict__ list, const unsigned long long *__restrict__ list_count,
+                                                            BatchReset z)
 {
+    batch_reset(z, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
     const int N = P.n_series;
     const int64_t ne = list ? (int64_t)*list_count : n_eff(n, n_dev);
     const int64_t tiles = (ne + 3) / 4;
@@ -965,6 +989,7 @@ struct EArgsT {
 using EArgs = EArgsT<double>;
 static_assert(sizeof(EvalKT<double>) % 8 == 0 && sizeof(EvalKT<float>) % 8 == 0, "EvalK is copied to LDS in eight-byte words");
 constexpr int kBitAny15 = 1 << 8, kBitVmax = 1 << 9;     // scratch bits in flags[] between the kernels
+constexpr int kBitListed = 1 << 10;                       // ... and, TC-rows-only: the storm is on the list k_dense / k_emit walked (k_flags finalises exactly these)
 #ifndef TCR_POST_THREADS
 #define TCR_POST_THREADS 128
 #endif
@@ -1012,7 +1037,7 @@ __global__ __launch_bounds__(kWave) void k_dense(EArgsT<R> a, uint16_t *__restri
         const int n = a.n_valid[sid];
         int nst = a.n_accept[sid];
         nst = nst < a.max_rk_steps ? nst : a.max_rk_steps;
-        if (threadIdx.x == 0) a.flags[sid] = 0;
+        if (threadIdx.x == 0) a.flags[sid] = a.list ? kBitListed : 0;
         constexpr int REC = step_rec_doubles<R>();
         typedef typename VecT<R, 4>::type V4;
         const int c = threadIdx.x & 3;
@@ -1347,39 +1372,77 @@ __global__ __launch_bounds__(kScreenThreads, TCR_SHADOW_WPS) void k_screen(EArgs
     if (on && l == 0) a.flags[sid] = (any15 && pass2d) ? TCR_FLAG_IS_TC : 0;
 }
 
+// One thread per storm of the batch.  TC-rows-only mode (tc_list): the storms k_screen passed (exactly the
+// entries of the list k_dense / k_emit walked, marked kBitListed by k_dense) are finalised, the others keep their 0.  stats != NULL: the sums of
+// tcr_stats_dev over the batch are accumulated by the same launch (a round needs no k_stats dispatch; counters as there).
 template <typename R>
 __global__ __launch_bounds__(256) void k_flags(tcr_params P, int64_t n_storms, const int32_t *__restrict__ n_valid,
                                                const int32_t *__restrict__ status, const R *__restrict__ pv,
                                                int32_t *__restrict__ flags, int32_t *__restrict__ pad_state,
-                                               const int32_t *__restrict__ list, const int64_t *__restrict__ count,
-                                               const int64_t *__restrict__ n_dev)
+                                               int tc_list, const int64_t *__restrict__ n_dev,
+                                               const int32_t *__restrict__ nfev, unsigned long long *__restrict__ stats,
+                                               const int64_t *__restrict__ stats_n_dev)
 {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (list ? *count : n_storms)) return;
-    if (!list && gid >= n_eff(n_storms, n_dev)) { flags[gid] = 0; return; }
-    const int64_t sid = list ? (int64_t)list[gid] : gid;
-    const int ns = P.n_steps;
-    const int n = n_valid[sid];
-    if (pad_state) pad_state[sid] = n;         // every k_emit block of the row has read the old value
-    const int bits = flags[sid];
-    int fl = 0;
-    if (n > 0 && status[sid] != TCR_STATUS_GATED) {
-        // np.interp(2 d, res.t, v) (compute.py:186-188)
-        const double step_out = P.total_time / (double)(ns - 1);
-        const double t2d = 2 * 86400.0;
-        const R *v = pv + (size_t)sid * ns;
-        double v2d;
-        if (t2d >= ts_at(P, n - 1)) v2d = (double)v[n - 1];
-        else {
-            const int j = (int)floor(t2d / step_out);
-            v2d = interp_v2d<R>(v[j], v[j + 1], ts_at(P, j), ts_at(P, j + 1), t2d);
+    const int64_t ne = n_eff(n_storms, n_dev);
+    int fl = 0, n = 0;
+    const bool exists = gid < ne;
+    if (gid < n_storms) {
+        const int bits = exists ? flags[gid] : 0;
+        const bool work = exists && (!tc_list || (bits & kBitListed));
+        const int64_t sid = gid;
+        n = exists ? n_valid[sid] : 0;
+        if (work) {
+            const int ns = P.n_steps;
+            if (pad_state) pad_state[sid] = n;         // every k_emit block of the row has read the old value
+            if (n > 0 && status[sid] != TCR_STATUS_GATED) {
+                // np.interp(2 d, res.t, v) (compute.py:186-188)
+                const double step_out = P.total_time / (double)(ns - 1);
+                const double t2d = 2 * 86400.0;
+                const R *v = pv + (size_t)sid * ns;
+                double v2d;
+                if (t2d >= ts_at(P, n - 1)) v2d = (double)v[n - 1];
+                else {
+                    const int j = (int)floor(t2d / step_out);
+                    v2d = interp_v2d<R>(v[j], v[j + 1], ts_at(P, j), ts_at(P, j + 1), t2d);
+                }
+                if ((bits & kBitAny15) && v2d >= P.v_2d_thresh) {
+                    fl |= TCR_FLAG_IS_TC;
+                    if (n > 1 && (bits & kBitVmax)) fl |= TCR_FLAG_ACCEPTED;
+                }
+            }
         }
-        if ((bits & kBitAny15) && v2d >= P.v_2d_thresh) {
-            fl |= TCR_FLAG_IS_TC;
-            if (n > 1 && (bits & kBitVmax)) fl |= TCR_FLAG_ACCEPTED;
-        }
+        if (work || !tc_list || !exists) flags[gid] = fl;          // (TC-rows-only: storms off the list already hold 0)
     }
-    flags[sid] = fl;
+    if (!stats) return;
+    // ---- tcr_stats_dev's sums (k_stats), same counters, over the first min(n, *stats_n_dev) storms
+    const int64_t nc = n_eff(n_storms, stats_n_dev);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (stats_n_dev && *stats_n_dev < n_storms) atomicAdd(stats + 6, 1ull);
+        atomicAdd(stats + 7, (unsigned long long)(nc > 0 ? nc : 0));
+        if (stats_n_dev && *stats_n_dev > n_storms) atomicAdd(stats + 9, (unsigned long long)(*stats_n_dev - n_storms));
+    }
+    unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, bad = 0;
+    if (gid < nc) {
+        if (!exists) n = n_valid[gid];
+        a0 = n > 1 ? n - 1 : 0; a1 = nfev[gid]; a2 = n;
+        a3 = (fl & TCR_FLAG_ACCEPTED) ? 1 : 0; a4 = (fl & TCR_FLAG_IS_TC) ? 1 : 0; a5 = (fl & TCR_FLAG_IS_TC) ? n : 0;
+        bad = status[gid] == TCR_STATUS_STEP_OVERFLOW ? 1 : 0;
+    }
+    __shared__ unsigned long long sh[4][7];
+    for (int off = 32; off > 0; off >>= 1) {
+        a0 += __shfl_down(a0, off); a1 += __shfl_down(a1, off); a2 += __shfl_down(a2, off); a3 += __shfl_down(a3, off);
+        a4 += __shfl_down(a4, off); a5 += __shfl_down(a5, off); bad += __shfl_down(bad, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        sh[w][0] = a0; sh[w][1] = a1; sh[w][2] = a2; sh[w][3] = a3; sh[w][4] = a4; sh[w][5] = a5; sh[w][6] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const unsigned long long v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+        if (v) atomicAdd(stats + (threadIdx.x < 6 ? threadIdx.x : 8), v);
+    }
 }
 
 // Coupled_FAST._init_m(y, dvdt) (intensity/coupled_fast.py:153-173): the inner-core moisture gen_track(m=None) starts
