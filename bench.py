@@ -407,18 +407,19 @@ def measured_traffic(kernel, storms, rows, dtype='f64', order='cells'):
     """(HBM bytes per batch, source) of a kernel from the committed rocprofv3 --pmc runs of this same workload
     (tools/collect_profiles.sh; counters are collected in separate passes from timing, as MI355X_MICROARCH.md
     prescribes, so they cannot be measured inside this process).  Only valid for the profiled size."""
-    fn = os.path.join(ROOT, 'profiles', 'r03_pmc_hbm.json')
-    if storms != 100_000 or dtype != 'f64' or not os.path.exists(fn):
+    fn = next((f for f in (os.path.join(ROOT, 'profiles', 'r04_pmc_hbm.json'), os.path.join(ROOT, 'profiles', 'r03_pmc_hbm.json')) if os.path.exists(f)), '')
+    tag = 'profiles/' + os.path.basename(fn)
+    if storms != 100_000 or dtype != 'f64' or not fn:
         return None, None
     try:
         d = json.load(open(fn))
         if d.get('rows') != rows or d.get('order', 'cells') != order:
             return None, None
         if kernel == '*':          # every kernel of a step
-            return d['step_total']['hbm_bytes_per_batch'], 'profiles/r03_pmc_hbm.json: sum over the kernels of a step'
+            return d['step_total']['hbm_bytes_per_batch'], tag + ': sum over the kernels of a step'
         for name, v in d['kernels'].items():
             if kernel in name:
-                return v['hbm_bytes_per_batch'], 'profiles/r03_pmc_hbm.json: rocprofv3 --pmc, separate passes, %s' % d.get('command', '')
+                return v['hbm_bytes_per_batch'], tag + ': rocprofv3 --pmc, separate passes, %s' % d.get('command', '')
     except Exception:
         pass
     return None, None

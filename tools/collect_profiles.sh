@@ -3,15 +3,24 @@
 #   bash tools/collect_profiles.sh r02 [tc|all]
 # Timing (kernel-trace/stats) and counters (--pmc) are separate rocprofv3 runs, as MI355X_MICROARCH.md prescribes.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROWS=${2:-tc}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
-# 1. the bench line itself (default flags, as the driver runs it)
-timeout 900 python bench.py --rows $ROWS > "$OUT/bench.json" 2> "$OUT/bench.err"
+# 1. the bench line itself: with the driver's flags (--steps 20 --warmup 5) and with the script's own defaults (40 steps)
+timeout 900 python bench.py --rows $ROWS --steps 20 --warmup 5 > "$OUT/bench_driver_flags.json" 2> "$OUT/bench.err"
+timeout 900 python bench.py --rows $ROWS --no-cpu-baseline > "$OUT/bench.json" 2>> "$OUT/bench.err"
 tail -c 600 "$OUT/bench.json"
+# 1b. small batches (a rank's share of a sharded 100 000-storm ensemble at N = 2 / 4 / 8) and where a batch's time goes under load
+for B in 50000 25000 12500; do
+  timeout 600 python bench.py --no-cpu-baseline --scaling weak --storms $B --streams 16 --steps 240 --warmup 32 2>/dev/null | tail -1 > "$OUT/bench_small_$B.json"
+done
+for cfg in "12500 1 60" "12500 4 120" "12500 16 240" "100000 1 10" "100000 8 40"; do
+  set -- $cfg
+  timeout 600 python bench.py --no-cpu-baseline --scaling weak --storms $1 --streams $2 --steps $3 --warmup 8 --stage-trace 2>/dev/null | tail -1 > "$OUT/stage_trace_${1}_streams$2.json"
+done
 # 2. per-kernel timing, one stream and the default eight
 for s in 1 8; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats$s" -o s -- \
