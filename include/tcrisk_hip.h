@@ -228,7 +228,10 @@ int tcr_compact_dev(tcr_ctx *ctx, int64_t n, const int32_t *flags_dev, int32_t m
  * the candidates' genesis points (latitude row major, stable: candidate order within a cell), so that the storms
  * tcr_gather_seeds_dev then places next to each other, and the integrator runs in one wave, read the same parts of the
  * fields.  Per-storm results do not depend on the order of a batch; a caller that needs candidate order (the accept loop
- * of run_tracks) sorts the few accepted rows back by their candidate index. */
+ * of run_tracks) sorts the few accepted rows back by their candidate index.  Cells that hold many entries (large cells over
+ * a small basin; NaN positions, which all sort into cell 0) are sorted as segments, so the worst case stays O(n log^2 n).
+ * Like every entry point it works in scratch owned by the context: one stream per context at a time.  (The scan kernel
+ * holds 66 KB of LDS: gfx950-class parts.) */
 int tcr_cell_order_dev(tcr_ctx *ctx, const tcr_seeds *cand_dev, int32_t *idx_dev, int64_t n, const int64_t *count_dev,
                        double cell_deg, void *stream);
 /* dense storm batch dst[r] = src[idx[r]], r < min(n_out, *count_dev) (count_dev, the device scalar

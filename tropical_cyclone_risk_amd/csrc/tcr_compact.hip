@@ -224,7 +224,14 @@ __global__ __launch_bounds__(kCellScanThreads) void k_cell_scan(CellOrderArgs a)
     if (threadIdx.x == 0) n_long = 0;
     int carry = 0;
     for (int base = 0; base < a.nbins; base += kCellScanWin) {
-        for (int i = threadIdx.x; i < kCellScanWin; i += kCellScanThreads) v[cell_lds(i)] = (base + i < a.nbins) ? a.hist[base + i] : 0;
+        // (loads in batches of sixteen before the LDS stores: one memory round trip per batch, not per word)
+        for (int i0 = threadIdx.x; i0 < kCellScanWin; i0 += 16 * kCellScanThreads) {
+            int t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int i = i0 + u * kCellScanThreads; t[u] = (i < kCellScanWin && base + i < a.nbins) ? a.hist[base + i] : 0; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int i = i0 + u * kCellScanThreads; if (i < kCellScanWin) v[cell_lds(i)] = t[u]; }
+        }
         __syncthreads();
         int sum = 0;
         const int row = threadIdx.x * (kCellScanRun + 1);
