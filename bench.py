@@ -70,7 +70,7 @@ def main():
                          'candidate: candidate order')
     ap.add_argument('--streams', type=int, default=None,
                     help='HIP streams the steps are round-robined over (each with its own context and buffers): '
-                         'the low-occupancy tail of one batch overlaps the next batch.  Default 8; 16 for the small '
+                         'the low-occupancy tail of one batch overlaps the next batch.  Default 12; 16 for the small '
                          'per-rank batches of --scaling strong at N > 1 (with as many hardware queues, see below)')
     ap.add_argument('--cpu-budget', type=float, default=12.0)
     ap.add_argument('--traffic', type=float, default=None,
@@ -86,9 +86,11 @@ def main():
     # per-rank batches of a sharded ensemble need more of them in flight than that (measured on one MI355X, 12 500 storms
     # per batch: 0.57 ms per step with 4 streams / 4 queues at any stream count, 0.44 with 8 / 8, 0.38 with 16 / 16;
     # at 100 000 storms per batch 8 streams on 8 queues are 3.5 % faster than 4 on 4 — 1.31 against 1.36 ms per step — and 12 on 12
-    # no better; mismatched counts, e.g. 4 streams on 8 queues, are 30 % slower).  Must be set before the HIP runtime starts.
+    # no better; mismatched counts, e.g. 4 streams on 8 queues, are 30 % slower.  Round 4, once every small kernel fits next to an
+    # integrator wave: 8 / 10 / 12 / 16 streams give 1.41 / 1.37 / 1.37 / 1.39 ms per step over the driver's 20 steps and 1.355 / 1.348 /
+    # 1.326 / 1.32 over 40 — 12 is the default).  Must be set before the HIP runtime starts.
     if args.streams is None:
-        args.streams = 16 if (args.scaling == 'strong' and int(os.environ.get('WORLD_SIZE', '1')) > 1) else 8
+        args.streams = 16 if (args.scaling == 'strong' and int(os.environ.get('WORLD_SIZE', '1')) > 1) else 12
     if args.streams > 4:
         os.environ.setdefault('GPU_MAX_HW_QUEUES', str(min(args.streams, 32)))
 
