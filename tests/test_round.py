@@ -166,3 +166,44 @@ def test_results_do_not_depend_on_the_launch_shape(golden_env, built_lib):
     with pytest.raises(_lib.TcrError):
         eng.schedule(0)
     eng.close()
+
+
+def test_compaction_single_launch_against_numpy(golden_env, built_lib):
+    """tcr_compact_dev (one kernel since round 4: ticket, published tile counts, look-back) against NumPy for sizes around the
+    tile boundaries, several masks, clipping at max_out, an empty input, and many calls in a row on the same scratch (the
+    generation tag of the tile words)."""
+    import torch
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    eng = TCEngine('NA', device=0).stage_env(golden_env)
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(3)
+    L, h = eng.L, eng.h
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    for n in (0, 1, 63, 2047, 2048, 2049, 4096, 100_003, 515_001, 7, 2048 * 3):
+        flags_h = rng.integers(0, 8, size=max(n, 1)).astype(np.int32)
+        flags = torch.from_numpy(flags_h).to(dev)
+        idx = torch.full((max(n, 1),), -1, dtype=torch.int32, device=dev)
+        for mask, max_out in ((2, n), (1, n), (4, max(1, n // 10)), (7, n), (8, n)):
+            idx.fill_(-1)
+            eng._ck(L.tcr_compact_dev(h, n, flags.data_ptr(), mask, max_out, idx.data_ptr(), count.data_ptr(), None))
+            torch.cuda.synchronize()
+            want = np.nonzero(flags_h[:n] & mask)[0]
+            assert int(count.item()) == len(want), (n, mask)
+            k = min(len(want), max_out)
+            got = idx[:n].cpu().numpy() if n else np.zeros(0, np.int32)
+            assert np.array_equal(got[:k], want[:k]), (n, mask, max_out)
+            assert (got[k:] == -1).all(), (n, mask, max_out)              # nothing written beyond the clipped count
+    # back to back without a host sync in between (stream order alone separates the launches that share the scratch)
+    n = 300_000
+    flags_h = rng.integers(0, 4, size=n).astype(np.int32)
+    flags = torch.from_numpy(flags_h).to(dev)
+    outs = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3)]
+    counts = torch.zeros(3, dtype=torch.int64, device=dev)
+    for rep in range(40):
+        for j, mask in enumerate((1, 2, 3)):
+            eng._ck(L.tcr_compact_dev(h, n, flags.data_ptr(), mask, n, outs[j].data_ptr(), counts[j:].data_ptr(), None))
+    torch.cuda.synchronize()
+    for j, mask in enumerate((1, 2, 3)):
+        want = np.nonzero(flags_h & mask)[0]
+        assert int(counts[j].item()) == len(want) and np.array_equal(outs[j][:len(want)].cpu().numpy(), want)
+    eng.close()
