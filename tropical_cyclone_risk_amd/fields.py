@@ -203,14 +203,24 @@ def _climatology(fn, var, lon_t, lat_t):
     return np.stack(out)
 
 
-def load_year_env(year, nl=None, files=None):
-    """One year's 12 monthly field sets from the reference's files (see the module docstring)."""
+def load_year_env(year, nl=None, files=None, cache=None):
+    """One year's 12 monthly field sets from the reference's files (see the module docstring).  `cache` (a dict the caller
+    keeps between years, e.g. FileEnvironment's): the parsed files and everything that does not depend on the year — land,
+    bathymetry, basin masks, ocean climatologies — are read once, and the static arrays of consecutive years are the SAME
+    objects, which is how `TCEngine.stage_env` knows not to stage them again."""
     nl = nl or _default_namelist
     fl = default_files(nl)
     fl.update(files or {})
+    cache = {} if cache is None else cache
+
+    def opened(key):
+        k = ('file', fl[key])
+        if k not in cache:
+            cache[k] = _Dataset(fl[key])
+        return cache[k]
 
     # ---- thermo record of the year (compute.py:66-85)
-    ds = _Dataset(fl['thermo'])
+    ds = opened('thermo')
     ta = TimeAxis(ds['time'], ds.attrs['time'])
     keep = (ta.t >= ta.at(year - 1, 12, 31)) & (ta.t <= ta.at(year, 12, 31))
     tt = ta.t[keep]
@@ -226,7 +236,7 @@ def load_year_env(year, nl=None, files=None):
         vpot_all, rh_all, chi_all = vpot_all[:, ::-1], rh_all[:, ::-1], chi_all[:, ::-1]
 
     # ---- wind statistics (bam_track.py:76-91)
-    dw = _Dataset(fl['env_wnd'])
+    dw = opened('env_wnd')
     tw = TimeAxis(dw['time'], dw.attrs['time'])
     wlon = np.asarray(dw['lon'], dtype=np.float64)
     wlat = np.asarray(dw['lat'], dtype=np.float64)
@@ -245,6 +255,22 @@ def load_year_env(year, nl=None, files=None):
         mean.append(np.stack([get(n) for n in MEAN_NAMES]))
         cov.append(np.stack([get(cov_name(i, j)) for (i, j) in TRIL]))
 
+    skey = ('static', fl['mld'], fl['strat'], fl['land'], fl['bathy'], fl['basin_dir'], lon.tobytes(), lat.tobytes())
+    if skey not in cache:
+        cache[skey] = _load_static(fl, lon, lat)
+    mld, strat, hlon, hlat, land, bathy, blon, blat, same_static, masks, mgrid = cache[skey]
+    env = SyntheticEnv(lon=lon, lat=lat, wlon=wlon, wlat=wlat, wnd_mean=np.stack(mean), wnd_cov=np.stack(cov),
+                       vpot=np.stack(vpot), chi=np.stack(chi), mld=mld, strat=strat, rh_mid=np.stack(rh_mid),
+                       hlon=hlon, hlat=hlat, land=land, bathy=bathy, basin_masks=masks, seed=0, shape='files')
+    if mgrid is not None and not (np.array_equal(mgrid[0], hlon) and np.array_equal(mgrid[1], hlat)):
+        env.mlon, env.mlat = mgrid
+    if not same_static:                  # land.nc and bathymetry.nc each keep their own grid (intensity/geo.py:9-34)
+        env.blon, env.blat = blon, blat
+    return env
+
+
+def _load_static(fl, lon, lat):
+    """What does not depend on the year: ocean climatologies on the thermo grid, land, bathymetry, basin masks."""
     mld = _climatology(fl['mld'], 'mixed_layer', lon, lat)
     strat = _climatology(fl['strat'], 'strat', lon, lat)
 
@@ -272,30 +298,29 @@ def load_year_env(year, nl=None, files=None):
         elif not (np.array_equal(g[0], mgrid[0]) and np.array_equal(g[1], mgrid[1])):
             raise NotImplementedError('basin masks on different grids')
         masks[b] = mask_b
-    env = SyntheticEnv(lon=lon, lat=lat, wlon=wlon, wlat=wlat, wnd_mean=np.stack(mean), wnd_cov=np.stack(cov),
-                       vpot=np.stack(vpot), chi=np.stack(chi), mld=mld, strat=strat, rh_mid=np.stack(rh_mid),
-                       hlon=hlon, hlat=hlat, land=land, bathy=bathy, basin_masks=masks, seed=0, shape='files')
-    if mgrid is not None and not (np.array_equal(mgrid[0], hlon) and np.array_equal(mgrid[1], hlat)):
-        env.mlon, env.mlat = mgrid
-    if not same_static:                  # land.nc and bathymetry.nc each keep their own grid (intensity/geo.py:9-34)
-        env.blon, env.blat = blon, blat
-    return env
+    return mld, strat, hlon, hlat, land, bathy, blon, blat, same_static, masks, mgrid
 
 
 class FileEnvironment:
-    """All years of an experiment: `for_year(y)` loads (and caches the last) year; attribute access
-    falls through to the first year so that it can be staged like a single-year environment."""
+    """All years of an experiment: `for_year(y)` loads a year (the parsed files and the static planes are kept between
+    years; the last few years' environments too); attribute access falls through to the first year so that it can be staged
+    like a single-year environment.  Safe to call from the worker threads of `compute.run_downscaling`."""
 
     def __init__(self, nl=None, files=None):
+        import threading
         self.nl = nl or _default_namelist
         self.files = files
-        self._year, self._env = None, None
+        self._cache, self._years, self._lock = {}, {}, threading.Lock()
 
     def for_year(self, year):
-        if self._year != year:
-            self._env = load_year_env(year, self.nl, self.files)
-            self._year = year
-        return self._env
+        with self._lock:
+            env = self._years.get(year)
+            if env is None:
+                env = load_year_env(year, self.nl, self.files, cache=self._cache)
+                self._years[year] = env
+                while len(self._years) > 4:
+                    del self._years[next(iter(self._years))]
+            return env
 
     def __getattr__(self, k):
         if k.startswith('_') or k in ('nl', 'files'):
