@@ -17,12 +17,12 @@ tail -c 600 "$OUT/bench.json"
 for B in 50000 25000 12500; do
   timeout 600 python bench.py --no-cpu-baseline --scaling weak --storms $B --streams 16 --steps 240 --warmup 32 2>/dev/null | tail -1 > "$OUT/bench_small_$B.json"
 done
-for cfg in "12500 1 60" "12500 4 120" "12500 16 240" "100000 1 10" "100000 8 40"; do
+for cfg in "12500 1 60" "12500 4 120" "12500 16 240" "100000 1 10" "100000 12 48"; do
   set -- $cfg
   timeout 600 python bench.py --no-cpu-baseline --scaling weak --storms $1 --streams $2 --steps $3 --warmup 8 --stage-trace 2>/dev/null | tail -1 > "$OUT/stage_trace_${1}_streams$2.json"
 done
-# 2. per-kernel timing, one stream and the default eight
-for s in 1 8; do
+# 2. per-kernel timing, one stream and the default twelve
+for s in 1 12; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats$s" -o s -- \
       python bench.py --steps 10 --warmup 2 --streams $s --rows $ROWS --no-cpu-baseline > /dev/null 2>&1
   cp "$(find "$OUT/stats$s" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_streams$s.csv"
