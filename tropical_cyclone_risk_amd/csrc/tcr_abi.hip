@@ -588,7 +588,11 @@ int launch_fourier(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const double *
             }
             hipLaunchKernelGGL(k_phase_factors_frag, dim3((unsigned)std::min<int64_t>(tiles, 8192)), dim3(256), 0, st, P, n, n_dev, phases, p, list, park_count, z);
             const int groups = part == kFsAll ? kFsMfmaColGroups : 1;
-            const unsigned wgs = (unsigned)std::min<int64_t>(tiles, std::max<int64_t>(1, (int64_t)ctx->cu_count * kFsMfmaWgsPerCu * (4 / kFsMfmaWaves) / groups));
+            // workgroups per launch: TCR_FS_WGS=<total> overrides (scheduling experiment: a workgroup's two 191-register waves
+            // keep integrator waves of other batches off their SIMDs)
+            int64_t want = (int64_t)ctx->cu_count * kFsMfmaWgsPerCu * (4 / kFsMfmaWaves) / groups;
+            if (const char *e = getenv("TCR_FS_WGS")) { const long v = atol(e); if (v > 0) want = std::max<long>(1, v / groups); }
+            const unsigned wgs = (unsigned)std::min<int64_t>(tiles, std::max<int64_t>(1, want));
             if (part == kFsRest)
                 hipLaunchKernelGGL((k_fourier_mfma<R, true>), dim3(wgs, groups), dim3(64 * kFsMfmaWaves), 0, st, P, n, n_dev, ctx->fs_period,
                                    ctx->d_sc_table, p, fs, 1, list, park_count);
