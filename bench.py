@@ -171,8 +171,11 @@ def main():
                 pipe.pack_accepted(buf, cap)
                 gather.submit(pipe.n_accepted)
         elif gather is not None:
+            # (the pack goes into one of the gather's rotating buffers: kept outside the round, whose captured graph is keyed
+            # by its buffers — one graph per pipe instead of one per (pipe, buffer))
             buf = gather.buffer()
-            pipe.round(year, cand0, C, B, exact_count=strong, stats=acc, accepted=True, packed=buf, pack_cap=cap, graph=graph)
+            pipe.round(year, cand0, C, B, exact_count=strong, stats=acc, accepted=True, graph=graph)
+            pipe.pack_accepted(buf, cap)
             gather.submit(pipe.n_accepted)
         else:
             pipe.round(year, cand0, C, B, exact_count=strong, stats=acc, graph=graph)
