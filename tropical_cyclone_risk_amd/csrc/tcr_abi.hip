@@ -1773,6 +1773,7 @@ int tcr_round_dev(tcr_ctx *ctx, const tcr_round *r, uint64_t seed, int32_t year,
         // — that is this call's result and it sizes every workspace — then capture the same enqueue for the calls to come.
         if (!ctx->graphs.empty() && memcmp(ctx->graphs.front().key.data() + sizeof(tcr_round), &ctx->epoch, sizeof(uint64_t)) != 0)
             drop_graphs(ctx);                    // graphs of an older epoch hold stale addresses
+        if (ctx->graphs.size() >= 64) drop_graphs(ctx);       // a caller that keeps changing its buffers: start over rather than grow
         if (enqueue_round(ctx, r, seed, year, cand0, nullptr, st)) return -1;
         memcpy(key.data() + sizeof(tcr_round), &ctx->epoch, sizeof(uint64_t));     // the direct run may have grown workspaces
         ctx->graphs.emplace_back();
