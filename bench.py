@@ -376,8 +376,10 @@ def main():
                        'step_call': 'staged (one library call per stage)' if args.staged else ('tcr_round_dev, replayed from a hipGraph' if use_graph else 'tcr_round_dev, direct enqueue'),
                        'graph_replays': sum(p.graph_stats()['replays'] for p in pipes),
                        'stage_ms_under_load': stage_ms,
-                       'allgather': ('accepted tracks of every %s all-gathered once (26 kB records, RCCL, one collective per step, '
-                                     '%d steps behind compute)' % ('ensemble' if strong else 'step', n_str)) if world > 1 else 'none (one GPU)',
+                       'allgather': ('accepted tracks of every %s all-gathered once (26 kB records, backend %s, one collective per step, '
+                                     '%d steps behind compute)' % ('ensemble' if strong else 'step',
+                                                                   {'nccl': 'nccl = RCCL'}.get(torch.distributed.get_backend(), torch.distributed.get_backend()),
+                                                                   n_str)) if world > 1 else 'none (one GPU)',
                        'warmup_effective': w_eff, 'host_issue_ms_per_step': t_issue / args.steps * 1e3,
                        'storm_steps_per_storm': steps_total / storms_total,
                        'rhs_per_storm_step': nfev_total / max(steps_total, 1),
