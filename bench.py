@@ -22,8 +22,8 @@ total of a run is bit-for-bit the same at every N (tests/test_seeding.py checks 
 --scaling weak: per-GPU work is fixed — B storms per rank and step, every step's accepted tracks all-gathered.
 
 A step is ONE library call per rank (tcr_round_dev: seed → select → locality order → forcing table → integrate →
-post-processing → stats [→ select accepted → pack]); --graph replays it from a captured hipGraph (default: for batches
-of fewer than 50 000 storms per rank, where the host's launch rate is what bounds the step).
+post-processing → stats [→ select accepted → pack]); --graph on replays it from a captured hipGraph (off by default: it halves
+the host time per step and changes no GPU time).
 
 A storm-step is one hourly output interval of one live storm.
 Inputs (fields) are resident in HBM before the timed region; candidates are drawn
@@ -54,9 +54,10 @@ def main():
     ap.add_argument('--storms', type=int, default=100_000, help='weak: storms integrated per GPU per step; strong: storms per '
                                                                 'ensemble (= per step), sharded over the GPUs')
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='strong')
-    ap.add_argument('--graph', choices=('auto', 'on', 'off'), default='auto',
+    ap.add_argument('--graph', choices=('auto', 'on', 'off'), default='off',
                     help='replay every step from a captured hipGraph (tcr_round_dev use_graph); auto: when a rank integrates '
-                         'fewer than 50 000 storms per step')
+                         'fewer than 50 000 storms per step.  Off by default: the replay halves the host time per step '
+                         '(0.08 -> 0.04 ms) and changes no GPU time (profiles/r04_small_batches.txt)')
     ap.add_argument('--storms-per-lane', type=int, default=3,
                     help='launch shape of batches that do not fill the chip (tcr_schedule_set): 1 = one integrator lane per storm, '
                          '3 = a third of the waves, lanes take storms in turn (profiles/r04_small_batches.txt)')

@@ -312,7 +312,14 @@ typedef struct {
  * is keyed by the descriptor's bytes; it is dropped whenever the context allocates or its parameters change.  seed / year /
  * cand0 reach the replayed kernels through a device-side key that a one-thread launch refreshes in front of the graph.
  * The TCR_* scheduling knobs are read when the graph is captured.  Timing events (tcr_timing_enable) are not recorded by
- * replayed rounds.  A context is used from one stream at a time, as for every other entry point. */
+ * replayed rounds.  A context is used from one stream at a time, as for every other entry point.
+ * Capture is a process-wide affair in HIP: while a round is being captured (its first use), a legacy-default-stream
+ * operation on ANY thread of the process — a synchronous hipMemcpy, a torch op on the default stream — fails there ("would
+ * make the legacy stream depend on a capturing blocking stream") and invalidates the capture here; the descriptor then keeps
+ * the direct form and no error is returned for it.  The library's own synchronous copies (field staging, host entry
+ * points) go through the context's stream for that reason (tools/capture_race_probe.py: 3 700 captures next to threads
+ * that stage fields, allocate and grow workspaces, no error); a caller that captures keeps its other threads off the
+ * default stream.  The replay saves ~40 us of host time per round and no GPU time. */
 int tcr_round_dev(tcr_ctx *ctx, const tcr_round *round, uint64_t experiment_seed, int32_t year, int64_t cand0,
                   int32_t use_graph, void *stream);
 /* Stage trace of directly enqueued rounds (measurement aid; replayed rounds record nothing): with it enabled tcr_round_dev

@@ -274,3 +274,60 @@ def _deferred_worker(rank, world, port, q):
     D.barrier()
     import torch.distributed as dist
     dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# years sharded over the ranks (compute.run_downscaling with at least as many years as ranks)
+def _year_tuple(i, T, ns):
+    rng = np.random.default_rng(77 + i)
+    from tropical_cyclone_risk_amd.basins import BASIN_IDS
+    def plane():
+        a = rng.standard_normal((T, ns))
+        a[:, ns - 1 - i % 3:] = np.nan
+        return a
+    return (plane(), plane(), plane(), plane(), plane(), rng.standard_normal((T, ns, 4)), rng.integers(1, 13, T).astype(float),
+            np.array([BASIN_IDS[k] for k in rng.integers(0, 7, T)], dtype='U2'), rng.integers(0, 90, (7, 12)).astype(float))
+
+
+def _years_worker(rank, world, port, n_years, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import types
+    import torch
+    from tropical_cyclone_risk_amd import compute, distributed as D
+    D.init_from_env(backend='gloo')
+    T, ns = 5, 361
+    nl = types.SimpleNamespace(tracks_per_year=T, total_track_time_days=15, output_interval_s=3600)
+    years = list(range(2000, 2000 + n_years))
+    mine = list(range(rank, n_years, world))
+    out = [None] * n_years
+    for i in mine:
+        out[i] = _year_tuple(i, T, ns)
+    res = compute._allgather_years(out, mine, years, nl, torch.device('cpu'))
+    ok = all(all(np.array_equal(a, b, equal_nan=(a.dtype.kind == 'f')) for a, b in zip(res[i], _year_tuple(i, T, ns))) for i in range(n_years))
+    # the single-rank form of the accept loop (distributed.Local) runs without touching the process group
+    loc = compute.accept_loop(fake_round, 12, 64, NS, ops=D.Local)
+    q.put((rank, ok, loc['cand']))
+    D.barrier()
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_years', [2, 5])
+def test_year_sharded_allgather_of_final_tracks(n_years):
+    """Years sharded over two ranks (gloo): the all-gather of the final tracks hands every rank every year's 9-tuple,
+    bit for bit, also when the ranks hold different numbers of years; and a rank working a year on its own
+    (distributed.Local) gets the sequential loop's tracks."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_years_worker, args=(r, 2, port, n_years, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = [q.get(timeout=180) for _ in ps]
+    for p in ps:
+        p.join(60)
+    _, cands, _ = sequential(12)
+    for rank, ok, cand in got:
+        assert ok, rank
+        assert np.array_equal(cand, cands)

@@ -228,9 +228,13 @@ def test_run_tracks_from_reference_files(golden_env, built_lib, tmp_path):
 
 
 @pytest.mark.gpu
-def test_run_py_is_rank_count_invariant(built_lib, tmp_path):
+@pytest.mark.parametrize('n_years', [1, 3])
+def test_run_py_is_rank_count_invariant(built_lib, tmp_path, n_years):
     """`run.py GL --synthetic` under torchrun with two ranks (sharing this GPU, gloo as the collective
-    backend) writes the same track file as a single process: candidate-index sharding + ordered accept loop."""
+    backend) writes the same track file as a single process.  One year: its candidate blocks are sharded over the ranks
+    (candidate-index sharding + ordered accept loop, an all-gather per round).  Three years: the YEARS are sharded — rank r
+    works years r, r + 2 on its own — and the final tracks are all-gathered once (what the reference's one-process-per-year
+    fan-out, util/compute.py:223-242, becomes)."""
     import subprocess
     import sys
     from tropical_cyclone_risk_amd import io as tio
@@ -238,8 +242,8 @@ def test_run_py_is_rank_count_invariant(built_lib, tmp_path):
     out = {}
     for tag, world in (('one', 1), ('two', 2)):
         nlf = tmp_path / ('nl_%s.py' % tag)
-        nlf.write_text("start_year = 2001\nend_year = 2001\ntracks_per_year = 24\noutput_directory = %r\nexp_name = %r\n"
-                       % (str(tmp_path), tag))
+        nlf.write_text("start_year = 2001\nend_year = %d\ntracks_per_year = 24\noutput_directory = %r\nexp_name = %r\n"
+                       % (2000 + n_years, str(tmp_path), tag))
         env = dict(os.environ, TCR_DIST_BACKEND='gloo')
         cmd = [sys.executable, os.path.join(root, 'run.py'), 'GL', '--synthetic', '--namelist', str(nlf)]
         if world > 1:
@@ -247,10 +251,10 @@ def test_run_py_is_rank_count_invariant(built_lib, tmp_path):
                    '--master-addr', '127.0.0.1', '--master-port', '29517'] + cmd[1:]
         r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        out[tag] = tio.read_tracks(str(tmp_path / tag / 'tracks_GL_era5_200101_200112.nc'))
-    for k in ('lon_trks', 'lat_trks', 'v_trks', 'm_trks', 'vmax_trks', 'u250_trks', 'tc_month', 'tc_basins', 'seeds_per_month'):
+        out[tag] = tio.read_tracks(str(tmp_path / tag / ('tracks_GL_era5_200101_%d12.nc' % (2000 + n_years))))
+    for k in ('lon_trks', 'lat_trks', 'v_trks', 'm_trks', 'vmax_trks', 'u250_trks', 'tc_month', 'tc_basins', 'tc_years', 'seeds_per_month'):
         assert np.array_equal(out['one'][k], out['two'][k], equal_nan=(out['one'][k].dtype.kind == 'f')), k
-    assert out['one']['lon_trks'].shape == (24, 361)
+    assert out['one']['lon_trks'].shape == (24 * n_years, 361)
 
 
 @pytest.mark.gpu
@@ -292,7 +296,7 @@ def test_bench_multi_rank_path(built_lib, tmp_path):
     Both scaling modes: weak (B storms per rank and step) and strong (BASELINE config 4 as worded: one ensemble per step,
     its candidate block sharded over the ranks, accepted tracks gathered once per ensemble) — in strong mode the set of
     storms of an ensemble does not depend on the rank count, so the integer totals of a run must be identical at
-    world 1 and world 2."""
+    world 1 and world 2.  (The strong-mode runs replay their steps from captured hipGraphs, the weak-mode runs enqueue directly.)"""
     import json
     import subprocess
     import sys
@@ -304,7 +308,7 @@ def test_bench_multi_rank_path(built_lib, tmp_path):
             cmd = [sys.executable] + (['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr',
                                        '127.0.0.1', '--master-port', '29531'] if world > 1 else []) + \
                   [os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', '4', '--warmup', '1', '--storms', str(storms),
-                   '--streams', '2', '--no-cpu-baseline', '--scaling', mode]
+                   '--streams', '2', '--no-cpu-baseline', '--scaling', mode] + (['--graph', 'on'] if mode == 'strong' else [])
             r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
             assert r.returncode == 0, r.stderr[-2000:]
             out[mode, world] = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])

@@ -58,7 +58,7 @@ def _legacy_round(out, cand0, n_steps, torch):
                 bad=torch.tensor([int(out.get('bad', 0))], dtype=torch.int64, device=dev), hist=hist)
 
 
-def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000):
+def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000, ops=None):
     """Order-preserving accept loop over rounds of candidates (backend-agnostic: RCCL on the GPUs, gloo in the
     CPU tests).
 
@@ -73,9 +73,11 @@ def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000):
     and the collective; the loop synchronises with the host ONCE per round — to read the per-rank (count,
     overflow) pairs that size the all-gather — and the result is copied to the host once, at the end.
     Returns dict(rows [n_tracks, 9*n_steps], month, basin_idx, cand, n_seeds [7, 12], rounds); every rank
-    returns the same result.
+    returns the same result.  ops: the collectives (default: the process group's, `distributed`; `distributed.Local` when
+    this rank works the whole year on its own).
     """
     import torch
+    D = ops or globals()['D']          # ops = distributed.Local: this rank works the year on its own (years sharded over the ranks)
     W, rk = D.world(), D.rank()
     width = ROW_VARS * n_steps
     got, total, hist_full, last = [], 0, None, None
@@ -147,8 +149,8 @@ def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000):
 class GpuRound:
     """round_fn backed by the device pipeline.  A round — seed → select → locality order → integrate → stats → select
     accepted → pack (+ candidate index / month / basin columns) → n_seeds histogram — is ONE library call
-    (`DevicePipeline.round` = tcr_round_dev), replayed from a captured hipGraph after its first use
-    (`namelist.gpu_round_graph`); the number of passing seeds, of accepted tracks and of overflowed step records stay
+    (`DevicePipeline.round` = tcr_round_dev), optionally replayed from a captured hipGraph after its first use
+    (`namelist.gpu_round_graph`, off by default: it saves host time only); the number of passing seeds, of accepted tracks and of overflowed step records stay
     device scalars, and nothing in a round synchronises with the host."""
 
     def __init__(self, engine, year, per_rank, experiment_seed=None, max_storms=None):
@@ -161,7 +163,7 @@ class GpuRound:
         self.seed = experiment_seed
         self.per_rank = int(per_rank)
         self.unordered = bool(getattr(engine.nl, 'gpu_locality_order', True))
-        self.graph = bool(getattr(engine.nl, 'gpu_round_graph', True))
+        self.graph = bool(getattr(engine.nl, 'gpu_round_graph', False))
         # The dense batch (rows, step records, forcing tables: ~63 kB per storm) is sized for the seeds that pass, not for
         # the candidates: the pass rate is measured once on a throw-away block of candidates (18-28 % on the synthetic
         # basins) and the batch gets 1.3x that + 1 024; a round in which more pass is run again at full width
@@ -263,7 +265,7 @@ def default_per_rank(nl, n_tracks):
     return int(max(4096, min(nl.gpu_candidate_round, 64 * n_tracks)))
 
 
-def run_tracks(year, n_tracks, b, engine=None, env=None, nl=None, per_rank=None, info=None, round_fn=None):
+def run_tracks(year, n_tracks, b, engine=None, env=None, nl=None, per_rank=None, info=None, round_fn=None, ops=None):
     """Generate n_tracks TC tracks in basin b for one year (reference: compute.py:64-210).
 
     Returns (tc_lon, tc_lat, tc_v, tc_m, tc_vmax, tc_env_wnds, tc_month, tc_basin, n_seeds).
@@ -271,6 +273,7 @@ def run_tracks(year, n_tracks, b, engine=None, env=None, nl=None, per_rank=None,
     like ``synthetic.SyntheticEnv``) on this rank's GPU.  ``info`` (a dict, optional) receives what the
     reference's loop keeps implicit: ``cand`` (global candidate index of every returned track) and ``rounds``.
     ``round_fn``: a GpuRound of the same engine to reuse (its buffers and its captured round) for this year.
+    ``ops``: `distributed.Local` to work the year on this rank alone (see `accept_loop`).
     """
     nl = nl or default_namelist
     basin_id = b.basin_id if isinstance(b, TC_Basin) else b
@@ -284,7 +287,7 @@ def run_tracks(year, n_tracks, b, engine=None, env=None, nl=None, per_rank=None,
     else:
         per_rank = int(per_rank or default_per_rank(nl, n_tracks))
         rf = GpuRound(engine, year, per_rank)
-    res = accept_loop(rf, n_tracks, per_rank, engine.n_steps)
+    res = accept_loop(rf, n_tracks, per_rank, engine.n_steps, ops=ops)
     if info is not None:
         info.update(cand=res['cand'], rounds=res['rounds'], per_rank=per_rank)
     if own:
@@ -320,9 +323,16 @@ def run_downscaling(basin_id, env=None, nl=None, out_dir=None):
     years = list(range(nl.start_year, nl.end_year + 1))
     yearly = hasattr(env, 'for_year')
     device = D.local_device(os.environ.get('LOCAL_RANK', '0'))
-    n_workers = max(1, min(int(getattr(nl, 'gpu_years_in_flight', 3)), len(years))) if D.world() == 1 else 1
+    W, rk = D.world(), D.rank()
+    # Several ranks: with at least as many years as ranks the YEARS are sharded (rank r works years r, r + W, ... on its own —
+    # what the reference's one-process-per-year fan-out is — and the final tracks are all-gathered once); with fewer years
+    # a year's candidate blocks are sharded and the years run one after another.
+    shard_years = W > 1 and len(years) >= W and bool(getattr(nl, 'gpu_shard_years', True))
+    mine = list(range(rk, len(years), W)) if shard_years else list(range(len(years)))
+    ops = D.Local if shard_years else None
+    n_workers = max(1, min(int(getattr(nl, 'gpu_years_in_flight', 3)), len(mine))) if (W == 1 or shard_years) else 1
     out = [None] * len(years)
-    writer = tio.TrackFileWriter(years, b, nl, out_dir) if (D.rank() == 0 and D.world() == 1) else None
+    writer = tio.TrackFileWriter(years, b, nl, out_dir) if (rk == 0 and W == 1) else None
     errors = []
 
     def work(w):
@@ -336,7 +346,7 @@ def run_downscaling(basin_id, env=None, nl=None, out_dir=None):
                 eng.stage_env(env)
             rf = None
             with torch.cuda.stream(stream):
-                for i in range(w, len(years), n_workers):
+                for i in mine[w::n_workers]:
                     if errors:
                         break
                     yr = years[i]
@@ -344,7 +354,9 @@ def run_downscaling(basin_id, env=None, nl=None, out_dir=None):
                         eng.stage_env(env.for_year(yr))
                     if rf is None:
                         rf = GpuRound(eng, yr, default_per_rank(nl, nl.tracks_per_year))
-                    out[i] = run_tracks(yr, nl.tracks_per_year, b, engine=eng, nl=nl, round_fn=rf)
+                        if n_workers > 1:
+                            rf.graph = False         # stream capture does not tolerate the other workers' field uploads (tcrisk_hip.h)
+                    out[i] = run_tracks(yr, nl.tracks_per_year, b, engine=eng, nl=nl, round_fn=rf, ops=ops)
                     if writer is not None:
                         writer.put(i, out[i])
             if rf is not None:
@@ -361,12 +373,52 @@ def run_downscaling(basin_id, env=None, nl=None, out_dir=None):
             t.start()
         for t in threads:
             t.join()
-    if errors:
+    if shard_years:
+        # every rank reaches the collective, also after a failure of its own (the others must not wait for ever)
+        failed = D.sum_over_ranks(1.0 if errors else 0.0, torch.device('cuda', device))
+        if errors:
+            raise errors[0]
+        if failed:
+            raise RuntimeError('run_downscaling: %d rank(s) failed' % int(failed))
+        out = _allgather_years(out, mine, years, nl, torch.device('cuda', device))
+    elif errors:
         raise errors[0]
     fn = None
-    if D.rank() == 0:
+    if rk == 0:
         fn = writer.close() if writer is not None else tio.write_tracks(out, years, b, nl, out_dir)
         print('Saved %s' % fn)
         print(time.time() - s)
     D.barrier()
     return fn
+
+
+def _allgather_years(out, mine, years, nl, dev):
+    """The all-gather of final tracks for year-sharded runs (`north_star`: "storms shard trivially across the GPUs with an
+    RCCL all-gather of final tracks"): every rank packs its years' 9-tuples into one device block — per year the rows
+    [tracks, 9 x n_steps], month and basin index per track, n_seeds [7 x 12] — one collective moves everything, and the
+    per-year tuples are rebuilt in year order on every rank."""
+    import torch
+    W = D.world()
+    T = int(nl.tracks_per_year)
+    k_max = -(-len(years) // W)
+    ns = out[mine[0]][0].shape[1] if mine else int(nl.total_track_time_days * 24 * 3600 / nl.output_interval_s) + 1
+    width = ROW_VARS * ns + 2
+    n_b = len(BASIN_IDS) * 12
+    block = torch.zeros(k_max, T * width + n_b, dtype=torch.float64)
+    for j, i in enumerate(mine):
+        t9 = out[i]
+        rows = np.concatenate([t9[0], t9[1], t9[2], t9[3], t9[4], t9[5].reshape(T, ns * 4), t9[6][:, None],
+                               np.array([BASIN_IDS.index(x) for x in t9[7]], dtype=np.float64)[:, None]], axis=1)
+        block[j, :T * width] = torch.from_numpy(np.ascontiguousarray(rows)).reshape(-1)
+        block[j, T * width:] = torch.from_numpy(np.asarray(t9[8], dtype=np.float64).reshape(-1))
+    got, counts = D.allgather_year_blocks(block.to(dev), len(mine), dev)
+    got = got.cpu().numpy()
+    res = [None] * len(years)
+    for r in range(W):
+        for j in range(counts[r]):
+            i = r + j * W
+            rows = got[r, j, :T * width].reshape(T, width)
+            tc = [rows[:, k * ns:(k + 1) * ns].copy() for k in range(5)]
+            res[i] = (tc[0], tc[1], tc[2], tc[3], tc[4], rows[:, 5 * ns:9 * ns].reshape(T, ns, 4).copy(), rows[:, 9 * ns].copy(),
+                      np.array([BASIN_IDS[int(x)] for x in rows[:, 9 * ns + 1]], dtype='U2'), got[r, j, T * width:].reshape(len(BASIN_IDS), 12).copy())
+    return res

@@ -151,6 +151,16 @@ int fail(tcr_ctx *ctx, const char *fmt, const char *a = "", const char *b = "")
         if (e_ != hipSuccess) return fail(ctx, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+// Synchronous copies go through the context's own stream, never the legacy default stream: a legacy-stream operation
+// fails ("would make the legacy stream depend on a capturing blocking stream") whenever ANY thread of the process is
+// capturing a round (tcr_round_dev use_graph), and invalidates that capture.
+inline hipError_t copy_sync(hipStream_t st, void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    if (!bytes) return hipSuccess;
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+
 template <typename T>
 int dev_alloc(tcr_ctx *ctx, T **p, size_t count)
 {
@@ -187,10 +197,10 @@ int stage_grid(tcr_ctx *ctx, GridStore &g, const tcr_grid *in, const char *what)
     for (int i = 0; i + 1 < in->nlat; ++i) rlat[i] = 1.0 / (in->lat[i + 1] - in->lat[i]);
     if (dev_alloc(ctx, &g.d_lon, in->nlon) || dev_alloc(ctx, &g.d_lat, in->nlat) ||
         dev_alloc(ctx, &g.d_rlon, in->nlon) || dev_alloc(ctx, &g.d_rlat, in->nlat)) return -1;
-    HIPCHK(ctx, hipMemcpy(g.d_lon, g.lon.data(), sizeof(double) * in->nlon, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(g.d_lat, g.lat.data(), sizeof(double) * in->nlat, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(g.d_rlon, rlon.data(), sizeof(double) * (in->nlon - 1), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(g.d_rlat, rlat.data(), sizeof(double) * (in->nlat - 1), hipMemcpyHostToDevice));
+    HIPCHK(ctx, copy_sync(ctx->stream, g.d_lon, g.lon.data(), sizeof(double) * in->nlon, hipMemcpyHostToDevice));
+    HIPCHK(ctx, copy_sync(ctx->stream, g.d_lat, g.lat.data(), sizeof(double) * in->nlat, hipMemcpyHostToDevice));
+    HIPCHK(ctx, copy_sync(ctx->stream, g.d_rlon, rlon.data(), sizeof(double) * (in->nlon - 1), hipMemcpyHostToDevice));
+    HIPCHK(ctx, copy_sync(ctx->stream, g.d_rlat, rlat.data(), sizeof(double) * (in->nlat - 1), hipMemcpyHostToDevice));
     g.affine_lon = axis_is_affine(g.lon);
     g.affine_lat = axis_is_affine(g.lat);
     g.set = true;
@@ -234,7 +244,7 @@ int sync_slots(tcr_ctx *ctx)
         h[i].wind = ctx->slots[i].wind; h[i].thermo = ctx->slots[i].thermo; h[i].rh = ctx->slots[i].rh;
         h[i].wind32 = ctx->slots[i].wind32; h[i].thermo32 = ctx->slots[i].thermo32;
     }
-    if (n) HIPCHK(ctx, hipMemcpy(ctx->d_slots, h.data(), sizeof(DevSlot) * n, hipMemcpyHostToDevice));
+    if (n) HIPCHK(ctx, copy_sync(ctx->stream, ctx->d_slots, h.data(), sizeof(DevSlot) * n, hipMemcpyHostToDevice));
     ctx->slots_dirty = false;
     return 0;
 }
@@ -442,8 +452,8 @@ int grid_f32(tcr_ctx *ctx, GridStore &g, const char *what)
         std::vector<float> r(n - 1);
         for (int i = 0; i + 1 < n; ++i) r[i] = 1.0f / (x32[i + 1] - x32[i]);
         if (dev_alloc(ctx, d_x, (size_t)n) || dev_alloc(ctx, d_rx, (size_t)n)) return -1;
-        HIPCHK(ctx, hipMemcpy(*d_x, x32.data(), sizeof(float) * n, hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(*d_rx, r.data(), sizeof(float) * (n - 1), hipMemcpyHostToDevice));
+        HIPCHK(ctx, copy_sync(ctx->stream, *d_x, x32.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+        HIPCHK(ctx, copy_sync(ctx->stream, *d_rx, r.data(), sizeof(float) * (n - 1), hipMemcpyHostToDevice));
         *affine = axis_is_affine(x32);
         return 0;
     };
@@ -883,7 +893,7 @@ int tcr_params_set(tcr_ctx *ctx, const tcr_params *p)
         if (ctx->d_sc_table) HIPCHK(ctx, hipFree(ctx->d_sc_table));
         ctx->d_sc_table = nullptr;
         if (dev_alloc(ctx, &ctx->d_sc_table, (size_t)iper)) return -1;
-        HIPCHK(ctx, hipMemcpy(ctx->d_sc_table, tab.data(), sizeof(double2) * iper, hipMemcpyHostToDevice));
+        HIPCHK(ctx, copy_sync(ctx->stream, ctx->d_sc_table, tab.data(), sizeof(double2) * iper, hipMemcpyHostToDevice));
         ctx->fs_period = iper;
     }
     return 0;
@@ -905,14 +915,14 @@ int tcr_static_upload2(tcr_ctx *ctx, const tcr_grid *lg, const double *land, con
         std::vector<double> h(np * kStaticStride);
         for (size_t i = 0; i < np; ++i) { h[i * 2] = land[i]; h[i * 2 + 1] = bathy[i]; }
         if (!ctx->d_stat && dev_alloc(ctx, &ctx->d_stat, h.size())) return -1;
-        HIPCHK(ctx, hipMemcpy(ctx->d_stat, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+        HIPCHK(ctx, copy_sync(ctx->stream, ctx->d_stat, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
     } else {
         if (stage_grid(ctx, ctx->bg, bg, "bathymetry")) return -1;
         const size_t nb = (size_t)bg->nlon * bg->nlat;
         if (!ctx->d_land && dev_alloc(ctx, &ctx->d_land, np)) return -1;
         if (!ctx->d_bathy && dev_alloc(ctx, &ctx->d_bathy, nb)) return -1;
-        HIPCHK(ctx, hipMemcpy(ctx->d_land, land, sizeof(double) * np, hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(ctx->d_bathy, bathy, sizeof(double) * nb, hipMemcpyHostToDevice));
+        HIPCHK(ctx, copy_sync(ctx->stream, ctx->d_land, land, sizeof(double) * np, hipMemcpyHostToDevice));
+        HIPCHK(ctx, copy_sync(ctx->stream, ctx->d_bathy, bathy, sizeof(double) * nb, hipMemcpyHostToDevice));
         ctx->split_static = true;
     }
     ctx->stat32_stale = true;
@@ -984,7 +994,7 @@ int tcr_rh_upload(tcr_ctx *ctx, int slot, const tcr_grid *rg, const double *rh_m
     SlotStore &s = ctx->slots[slot];
     const size_t nr = (size_t)rg->nlon * rg->nlat;
     if (!s.rh && dev_alloc(ctx, &s.rh, nr)) return -1;
-    HIPCHK(ctx, hipMemcpy(s.rh, rh_mid, sizeof(double) * nr, hipMemcpyHostToDevice));
+    HIPCHK(ctx, copy_sync(ctx->stream, s.rh, rh_mid, sizeof(double) * nr, hipMemcpyHostToDevice));
     ctx->slots_dirty = true;
     return 0;
 }
@@ -1005,7 +1015,7 @@ int tcr_masks_upload(tcr_ctx *ctx, const tcr_grid *mg, const uint8_t *run_mask,
     }
     for (size_t i = 0; i < np; ++i) bits[i] |= (uint8_t)((run_mask[i] ? 1u : 0u) << 7);
     if (!ctx->d_mask_bits && dev_alloc(ctx, &ctx->d_mask_bits, np)) return -1;
-    HIPCHK(ctx, hipMemcpy(ctx->d_mask_bits, bits.data(), np, hipMemcpyHostToDevice));
+    HIPCHK(ctx, copy_sync(ctx->stream, ctx->d_mask_bits, bits.data(), np, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -1057,7 +1067,7 @@ int tcr_integrate_pass_stats(tcr_ctx *ctx, int64_t *out, int max_passes)
     if (!ctx || !out) return -1;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     unsigned long long h[kQueueWords];
-    HIPCHK(ctx, hipMemcpy(h, ctx->d_queue, sizeof(h), hipMemcpyDeviceToHost));
+    HIPCHK(ctx, copy_sync(ctx->stream, h, ctx->d_queue, sizeof(h), hipMemcpyDeviceToHost));
     int np = 0;
     for (int p = 0; p < kMaxPasses && p < max_passes; ++p) {
         if (h[2 * kMaxPasses + 4 * p] == 0 && h[p] == 0) break;
@@ -1131,7 +1141,7 @@ int integrate_host_impl(tcr_ctx *ctx, const tcr_storms *in, const T *out)
     if (integrate_impl<R>(ctx, &di, dout, ctx->stream)) return -1;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 #define D2H(field, count, TT) \
-    if (out->field) HIPCHK(ctx, hipMemcpy(out->field, dout.field, (count) * sizeof(TT), hipMemcpyDeviceToHost))
+    if (out->field) HIPCHK(ctx, copy_sync(ctx->stream, out->field, dout.field, (count) * sizeof(TT), hipMemcpyDeviceToHost))
     D2H(lon, n * ns, R); D2H(lat, n * ns, R); D2H(v, n * ns, R); D2H(m, n * ns, R);
     D2H(vmax, n * ns, R); D2H(envw, n * ns * 4, R);
     D2H(n_valid, n, int32_t); D2H(status, n, int32_t); D2H(flags, n, int32_t); D2H(nfev, n, int32_t);
@@ -1163,12 +1173,12 @@ int tcr_integrate_probe_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_track
     const size_t bytes = (size_t)in->n * (size_t)cap;
     uint8_t *d = B.get<uint8_t>(bytes);
     if (!d) return fail(ctx, "tcr_integrate_probe_host: device allocation failed");
-    HIPCHK(ctx, hipMemset(d, 0xff, bytes));
+    HIPCHK(ctx, hipMemsetAsync(d, 0xff, bytes, ctx->stream)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->d_probe = d; ctx->probe_cap = cap;
     const int rc = tcr_integrate_host(ctx, in, out);
     ctx->d_probe = nullptr; ctx->probe_cap = 0;
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpy(dec, d, bytes, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, copy_sync(ctx->stream, dec, d, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1205,9 +1215,9 @@ int tcr_entropy_table_upload(tcr_ctx *ctx, int32_t np, int32_t ns, const double 
     ctx->d_tab = nullptr;
     const size_t n = (size_t)np + ns + (size_t)np * ns;
     if (dev_alloc(ctx, &ctx->d_tab, n)) return -1;
-    HIPCHK(ctx, hipMemcpy(ctx->d_tab, p, sizeof(double) * np, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(ctx->d_tab + np, s, sizeof(double) * ns, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(ctx->d_tab + np + ns, T, sizeof(double) * (size_t)np * ns, hipMemcpyHostToDevice));
+    HIPCHK(ctx, copy_sync(ctx->stream, ctx->d_tab, p, sizeof(double) * np, hipMemcpyHostToDevice));
+    HIPCHK(ctx, copy_sync(ctx->stream, ctx->d_tab + np, s, sizeof(double) * ns, hipMemcpyHostToDevice));
+    HIPCHK(ctx, copy_sync(ctx->stream, ctx->d_tab + np + ns, T, sizeof(double) * (size_t)np * ns, hipMemcpyHostToDevice));
     ctx->tab_np = np; ctx->tab_ns = ns;
     return 0;
 }
@@ -1375,9 +1385,9 @@ int tcr_probe_rhs_host(tcr_ctx *ctx, int slot, double h_bl, const double *Fs, in
 #undef PROBE_RHS
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipMemcpy(dydt, d_dy, sizeof(double) * n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(envw, d_w, sizeof(double) * n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(alpha, d_al, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, copy_sync(ctx->stream, dydt, d_dy, sizeof(double) * n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, copy_sync(ctx->stream, envw, d_w, sizeof(double) * n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, copy_sync(ctx->stream, alpha, d_al, sizeof(double) * n, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1436,7 +1446,7 @@ int tcr_init_m_host(tcr_ctx *ctx, const tcr_storms *in, double dvdt, double *m_o
         return fail(ctx, "tcr_init_m_host: device allocation failed");
     if (init_m_launch(ctx, &d, dvdt, d_out, ctx->stream)) return -1;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipMemcpy(m_out, d_out, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, copy_sync(ctx->stream, m_out, d_out, sizeof(double) * n, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1486,7 +1496,7 @@ int tcr_seed_host(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t 
     if (tcr_seed_dev(ctx, experiment_seed, year, cand0, &d, ctx->stream)) return -1;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 #define D2H(field, count, T) \
-    if (out->field) HIPCHK(ctx, hipMemcpy(out->field, d.field, (count) * sizeof(T), hipMemcpyDeviceToHost))
+    if (out->field) HIPCHK(ctx, copy_sync(ctx->stream, out->field, d.field, (count) * sizeof(T), hipMemcpyDeviceToHost))
     D2H(lon0, n, double); D2H(lat0, n, double); D2H(v0, n, double); D2H(m0, n, double); D2H(h_bl, n, double);
     D2H(slot, n, int32_t); D2H(phases, n * 4 * N, double); D2H(basin_idx, n, int32_t); D2H(seed_flags, n, int32_t);
 #undef D2H
@@ -1779,15 +1789,28 @@ int tcr_round_dev(tcr_ctx *ctx, const tcr_round *r, uint64_t seed, int32_t year,
         ctx->graphs.emplace_back();
         g = &ctx->graphs.back();
         g->key = key;
+        // Capture.  HIP's capture state is fragile against the rest of the process: a legacy-stream operation on ANY thread
+        // while this stream captures (a synchronous hipMemcpy of another context's field upload, say) fails there with
+        // "would make the legacy stream depend on a capturing blocking stream" and invalidates the capture here.  Whatever
+        // happens, the stream must leave capture mode and the sticky error must be cleared; the descriptor then keeps the
+        // direct form (this call's round has already run).
         if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { g->failed = true; (void)hipGetLastError(); return 0; }
         ctx->capturing = true;
         const int rc = enqueue_round(ctx, r, 0, 0, 0, ctx->d_round_key, st);
         ctx->capturing = false;
         hipGraph_t graph = nullptr;
-        const hipError_t e = hipStreamEndCapture(st, &graph);
+        hipError_t e = hipStreamEndCapture(st, &graph);
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+            hipGraph_t junk = nullptr;                      // still (invalidly) capturing: end it once more
+            (void)hipStreamEndCapture(st, &junk);
+            if (junk) (void)hipGraphDestroy(junk);
+            e = hipErrorStreamCaptureInvalidated;
+        }
+        for (int k = 0; k < 4 && hipGetLastError() != hipSuccess; ++k) {}
         if (rc || e != hipSuccess || !graph) {
             if (graph) (void)hipGraphDestroy(graph);
-            (void)hipGetLastError();
+            ctx->err.clear();
             g->failed = true;                    // this descriptor keeps the direct form; the round above has run
             return 0;
         }
@@ -1802,6 +1825,8 @@ int tcr_round_dev(tcr_ctx *ctx, const tcr_round *r, uint64_t seed, int32_t year,
         return 0;
     }
     if (g->failed) return enqueue_round(ctx, r, seed, year, cand0, nullptr, st);
+    // (the fp32 copies of re-staged fields are refreshed here: the captured enqueue found them up to date and holds no conversion)
+    if (r->f32 && ensure_f32(ctx, st)) return -1;
     hipLaunchKernelGGL(k_set_round_key, dim3(1), dim3(1), 0, st, ctx->d_round_key, seed, year, cand0);
     HIPCHK(ctx, hipGraphLaunch(g->exec, st));
     ++ctx->n_replays;

@@ -200,6 +200,49 @@ class DeferredRowGather:
             self._retire(self.launched[0])
 
 
+class Local:
+    """The collectives of the accept loop for a rank that works a whole year on its own (years sharded over the ranks:
+    `compute.run_downscaling`): world 1, rank 0, nothing leaves the rank."""
+
+    @staticmethod
+    def world():
+        return 1
+
+    @staticmethod
+    def rank():
+        return 0
+
+    @staticmethod
+    def round_block(round_idx, per_rank, rank_=None, world_=None):
+        return int(round_idx) * int(per_rank)
+
+    @staticmethod
+    def allgather_ints(vec):
+        return [[int(x) for x in vec.tolist()]]
+
+    @staticmethod
+    def allgather_rows(rows, count, counts=None, async_op=False, concat=True):
+        return rows[:counts[0]], counts
+
+    @staticmethod
+    def allreduce_sum_(t):
+        return t
+
+
+def allgather_year_blocks(block, n_mine, device):
+    """All-gather of the final tracks when the YEARS are sharded over the ranks: `block` [k_max, ...] holds this rank's
+    `n_mine` finished years (k_max = the most any rank has, so every rank contributes the same shape).  Returns
+    (gathered [world, k_max, ...], counts per rank) — one collective over the whole result, device to device."""
+    w = world()
+    cnt = torch.tensor([int(n_mine)], dtype=torch.int64, device=device)
+    counts = allgather_counts(cnt)
+    if w == 1:
+        return block.unsqueeze(0), counts
+    recv = torch.empty((w,) + tuple(block.shape), dtype=block.dtype, device=block.device)
+    dist.all_gather_into_tensor(recv.view(w * block.shape[0], -1), block.contiguous().view(block.shape[0], -1))
+    return recv, counts
+
+
 class _null:
     def __enter__(self):
         return self
