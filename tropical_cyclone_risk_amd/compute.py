@@ -382,6 +382,8 @@ def run_downscaling(basin_id, env=None, nl=None, out_dir=None):
             raise RuntimeError('run_downscaling: %d rank(s) failed' % int(failed))
         out = _allgather_years(out, mine, years, nl, torch.device('cuda', device))
     elif errors:
+        if writer is not None:
+            writer.abort()
         raise errors[0]
     fn = None
     if rk == 0:

@@ -173,6 +173,18 @@ class TrackFileWriter:
         if self.streaming:
             self.q.put((year_index, tuple9))
 
+    def abort(self):
+        """Stop the writer thread and remove the partial file (a year failed)."""
+        if not self.streaming:
+            return
+        self.q.put(None)
+        self.thread.join()
+        self.f.close()
+        try:
+            os.remove(self.fn)
+        except OSError:
+            pass
+
     def close(self):
         """Finish the file; returns its name."""
         if not self.streaming:
