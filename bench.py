@@ -145,6 +145,7 @@ def main():
     # storm-steps, nfev, samples, accepted, is_tc, is_tc samples, rounds with < B passing seeds, storms, step-record overflows,
     # passing seeds a batch had no room for (tcr_stats_dev)
     acc = torch.zeros(10, dtype=torch.int64, device=dev)
+    n_exp = int(args.storms / world) if strong else 0      # strong: a rank's batch has 25 % + 2048 rows to spare
     use_graph = (args.graph == 'on' or (args.graph == 'auto' and B < 50_000)) and not args.stage_trace
     row = 9 * ns
     # N > 1: all-gather of every batch's final (accepted) tracks through distributed.DeferredRowGather:
@@ -175,11 +176,11 @@ def main():
             # (the pack goes into one of the gather's rotating buffers: kept outside the round, whose captured graph is keyed
             # by its buffers — one graph per pipe instead of one per (pipe, buffer))
             buf = gather.buffer()
-            pipe.round(year, cand0, C, B, exact_count=strong, stats=acc, accepted=True, graph=graph)
+            pipe.round(year, cand0, C, B, exact_count=strong, stats=acc, accepted=True, graph=graph, n_expected=n_exp)
             pipe.pack_accepted(buf, cap)
             gather.submit(pipe.n_accepted)
         else:
-            pipe.round(year, cand0, C, B, exact_count=strong, stats=acc, graph=graph)
+            pipe.round(year, cand0, C, B, exact_count=strong, stats=acc, graph=graph, n_expected=n_exp)
 
     def drain():
         if gather is not None:

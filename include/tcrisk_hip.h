@@ -306,6 +306,8 @@ typedef struct {
                                    tcr_pack_tracks_meta_dev when pack_stride >= 9 * n_steps + 3), or NULL */
     int64_t pack_cap, pack_stride;
     int64_t *seed_hist;         /* [7][12] the round's n_seeds contribution (tcr_seed_hist_dev, no cutoff), or NULL */
+    int64_t n_expected;         /* 0, or how many seeds the caller expects to pass (<= n_storms): the integrator's launch is
+                                   shaped for that many storms instead of the batch's capacity; never changes a result */
 } tcr_round;
 /* use_graph != 0: the round is captured into a hipGraph the first time a (ctx, descriptor) pair is seen and replayed from
  * then on — one graph launch instead of ~30 kernel launches, which is what bounds small rounds.  The graph

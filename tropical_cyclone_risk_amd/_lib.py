@@ -84,7 +84,8 @@ class Round(C.Structure):
                 ('cand_idx', C.c_void_p), ('n_passed', C.c_void_p), ('cell_deg', C.c_double),
                 ('exact_count', C.c_int32), ('f32', C.c_int32), ('tracks', Tracks),
                 ('stats', C.c_void_p), ('acc_idx', C.c_void_p), ('n_accepted', C.c_void_p),
-                ('packed', C.c_void_p), ('pack_cap', C.c_int64), ('pack_stride', C.c_int64), ('seed_hist', C.c_void_p)]
+                ('packed', C.c_void_p), ('pack_cap', C.c_int64), ('pack_stride', C.c_int64), ('seed_hist', C.c_void_p),
+                ('n_expected', C.c_int64)]
 
 
 class TcrError(RuntimeError):

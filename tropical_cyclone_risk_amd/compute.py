@@ -174,7 +174,9 @@ class GpuRound:
             p_pass = float(((probe.cand['seed_flags'][:probe.n_cand] & 2) != 0).double().mean().item())
             del probe
             max_storms = int(self.per_rank * min(1.0, 1.3 * p_pass)) + 1024
+            self.n_expected = int(self.per_rank * p_pass)
         self.B = int(min(self.per_rank, max(64, max_storms)))
+        self.n_expected = int(getattr(self, 'n_expected', 0))
         self._build()
 
     def _build(self):
@@ -235,7 +237,8 @@ class GpuRound:
         self.stats.zero_()
         cap = min(self.cap, count)
         p.round(self.year, cand0, count, min(self.B, count), self.seed, exact_count=True, stats=self.stats, accepted=True,
-                packed=self.packed, pack_cap=cap, seed_hist=self.hist_round, graph=self.graph)
+                packed=self.packed, pack_cap=cap, seed_hist=self.hist_round, graph=self.graph,
+                n_expected=min(self.n_expected, self.B))
         self._last = (cand0, count)
         hist_full = self.hist_round.double()          # a copy: the next round overwrites the buffer
 

@@ -626,7 +626,7 @@ int launch_fourier(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const double *
 // stats: optional device counter block (TCR_N_STATS words) the batch's sums are added to by k_flags (tcr_round_dev)
 template <typename R>
 int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, void *stream_, uint64_t *stats = nullptr,
-                   const int64_t *stats_n_dev = nullptr)
+                   const int64_t *stats_n_dev = nullptr, int64_t n_expected = 0)
 {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int64_t n = in->n;
@@ -657,7 +657,8 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
     // Chain of launches with tail compaction (k_integrate): a pass parks the storms of waves that
     // fall under `thr` live lanes, the next pass needs at most waves*(thr-1)/64 waves for them.
     const int wps = std::is_same<R, double>::value ? TCR_INT_WPS : TCR_INT_WPS_F32;
-    unsigned waves = integrate_waves(ctx, n, wps);
+    // (n_expected: how many of the n rows the caller expects to hold storms — a round's dense batch has capacity to spare)
+    unsigned waves = integrate_waves(ctx, (n_expected > 0 && n_expected < n) ? n_expected : n, wps);
     const int thr = park_threshold(ctx, waves, wps);
     // With a chain, the forcing table is written in two segments: samples [0, 192) for every storm now, the rest after the
     // first pass and only for the storms that pass parks — the pass parks a storm (its lane takes the next one) as soon as
@@ -687,6 +688,7 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
         BatchReset z{};
         z.queue = ctx->d_queue; z.queue_words = (int)kQueueWords;
         if (prune_sample >= 0) { z.und_count = ctx->d_und_count; z.flags = out.flags; z.n_flags = n; }
+        if (out.tc_rows_only) z.tc_count = reinterpret_cast<unsigned long long *>(ctx->d_tc_count);
         if (launch_fourier<R>(ctx, n, in->n_dev, in->phases, fs, st, segmented ? kFsFirst : kFsAll, nullptr, nullptr, &z)) return -1;
     }
     STAGE(TCR_STAGE_FOURIER);
@@ -761,10 +763,10 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
                 if (dev_alloc(ctx, &ctx->d_tc_idx, (size_t)n)) return -1;
                 ctx->tc_idx_cap = (size_t)n;
             }
+            a.tc_list = ctx->d_tc_idx; a.tc_count = reinterpret_cast<unsigned long long *>(ctx->d_tc_count);
             hipLaunchKernelGGL(k_screen<R>, dim3((unsigned)((n + kScreenStorms - 1) / kScreenStorms)), dim3(kScreenThreads), 0, st, a);
             STAGE(TCR_STAGE_SCREEN);
-            if (tcr_compact_dev(ctx, n, out.flags, TCR_FLAG_IS_TC, n, ctx->d_tc_idx, ctx->d_tc_count, st)) return -1;
-            STAGE(TCR_STAGE_SELECT_TC);
+            STAGE(TCR_STAGE_SELECT_TC);          // (the list is k_screen's own since round 4: no compaction launch)
             a.list = ctx->d_tc_idx; a.count = ctx->d_tc_count;
         }
         // k_dense, TC rows only: a bounded grid of waves walks the device-side list (one wave per storm otherwise)
@@ -1503,8 +1505,11 @@ int tcr_seed_host(tcr_ctx *ctx, uint64_t experiment_seed, int32_t year, int64_t 
     return 0;
 }
 
-int tcr_compact_dev(tcr_ctx *ctx, int64_t n, const int32_t *flags, int32_t mask, int64_t max_out,
-                    int32_t *idx, int64_t *count, void *stream_)
+extern "C++" {
+namespace {
+// cell != NULL: the selection's cell keys and counts are produced on the way (k_compact<true>), for cell_order_impl(key_done)
+int compact_impl(tcr_ctx *ctx, int64_t n, const int32_t *flags, int32_t mask, int64_t max_out,
+                 int32_t *idx, int64_t *count, void *stream_, const CellOrderArgs *cell)
 {
     if (!ctx) return -1;
     if (!flags || !idx || !count || n < 0 || max_out < 0) return fail(ctx, "tcr_compact_dev: bad argument");
@@ -1518,21 +1523,29 @@ int tcr_compact_dev(tcr_ctx *ctx, int64_t n, const int32_t *flags, int32_t mask,
         HIPCHK(ctx, hipMemsetAsync(ctx->d_tiles, 0, sizeof(unsigned long long) * ((size_t)tiles + 1024), st));
         ctx->tiles_cap = (size_t)tiles + 1024;
     }
-    hipLaunchKernelGGL(k_compact, dim3((unsigned)tiles), dim3(kScanThreads), 0, st, n, flags, mask, max_out, idx, count, ctx->d_tiles, (int)tiles);
+    if (cell) hipLaunchKernelGGL(k_compact<true>, dim3((unsigned)tiles), dim3(kScanThreads), 0, st, n, flags, mask, max_out, idx, count, ctx->d_tiles, (int)tiles, *cell);
+    else hipLaunchKernelGGL(k_compact<false>, dim3((unsigned)tiles), dim3(kScanThreads), 0, st, n, flags, mask, max_out, idx, count, ctx->d_tiles, (int)tiles, CellOrderArgs{});
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
+}  // namespace
+}  // extern "C++"
 
-int tcr_cell_order_dev(tcr_ctx *ctx, const tcr_seeds *cand, int32_t *idx, int64_t n, const int64_t *count,
-                       double cell_deg, void *stream_)
+int tcr_compact_dev(tcr_ctx *ctx, int64_t n, const int32_t *flags, int32_t mask, int64_t max_out,
+                    int32_t *idx, int64_t *count, void *stream_)
 {
-    if (!ctx) return -1;
+    return compact_impl(ctx, n, flags, mask, max_out, idx, count, stream_, nullptr);
+}
+
+extern "C++" {
+namespace {
+// scratch and arguments of the locality order of idx[0 .. min(n, *count))
+int cell_order_args(tcr_ctx *ctx, const tcr_seeds *cand, int32_t *idx, int64_t n, const int64_t *count, double cell_deg,
+                    hipStream_t st, CellOrderArgs &a)
+{
     if (!cand || !cand->lon0 || !cand->lat0 || !idx || n < 0) return fail(ctx, "tcr_cell_order_dev: bad argument");
     if (!(cell_deg >= 0.25 && cell_deg <= 90.0)) return fail(ctx, "tcr_cell_order_dev: cell_deg must be in [0.25, 90]");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (n == 0) return 0;
-    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
-    CellOrderArgs a{};
+    a = CellOrderArgs{};
     a.ncol = (int)ceil(360.0 / cell_deg);
     const int nrow = (int)ceil(180.0 / cell_deg) + 1;
     a.nbins = a.ncol * nrow;
@@ -1552,13 +1565,34 @@ int tcr_cell_order_dev(tcr_ctx *ctx, const tcr_seeds *cand, int32_t *idx, int64_
     a.idx_in = body; a.key = body + n; a.tmp = body + 2 * n; a.tmp_key = body + 3 * n;
     a.lon0 = cand->lon0; a.lat0 = cand->lat0; a.idx_out = idx; a.count = count; a.n = n;
     a.inv_cell = 1.0 / cell_deg;
+    return 0;
+}
+
+// key_done: the keys and cell counts came with the compaction (k_compact<true>)
+int cell_order_launch(tcr_ctx *ctx, const CellOrderArgs &a, bool key_done, hipStream_t st)
+{
+    const int64_t n = a.n;
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_cell_key, dim3(blocks), dim3(256), 0, st, a);
+    if (!key_done) hipLaunchKernelGGL(k_cell_key, dim3(blocks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(kCellScanThreads), 0, st, a);
     hipLaunchKernelGGL(k_cell_scatter, dim3(blocks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_cell_rank, dim3((unsigned)((std::max<int64_t>(n, a.nbins + 1) + 255) / 256)), dim3(256), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
     return 0;
+}
+}  // namespace
+}  // extern "C++"
+
+int tcr_cell_order_dev(tcr_ctx *ctx, const tcr_seeds *cand, int32_t *idx, int64_t n, const int64_t *count,
+                       double cell_deg, void *stream_)
+{
+    if (!ctx) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    CellOrderArgs a{};
+    if (cell_order_args(ctx, cand, idx, n, count, cell_deg, st, a)) return -1;
+    if (n == 0) return 0;
+    return cell_order_launch(ctx, a, false, st);
 }
 
 extern "C++" {
@@ -1705,9 +1739,18 @@ int enqueue_round(tcr_ctx *ctx, const tcr_round *r, uint64_t seed, int32_t year,
         }
     }
     if (const char *e = getenv("TCR_DUMMY_SPIN_US")) if (atol(e) > 0) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, (hipStream_t)st, 100ll * atol(e));
-    if (tcr_compact_dev(ctx, r->n_cand, cand.seed_flags, 2, r->n_storms, r->cand_idx, r->n_passed, st)) return -1;
-    STAGE(TCR_STAGE_SELECT);
-    if (r->cell_deg > 0 && tcr_cell_order_dev(ctx, &cand, r->cand_idx, r->n_storms, r->n_passed, r->cell_deg, st)) return -1;
+    if (r->cell_deg > 0) {
+        // locality order: with many cells the keys and cell counts are produced by the compaction itself (one launch less)
+        CellOrderArgs ca{};
+        if (cell_order_args(ctx, &cand, r->cand_idx, r->n_storms, r->n_passed, r->cell_deg, (hipStream_t)st, ca)) return -1;
+        const bool fused = ca.nbins > kCellLdsBins;
+        if (compact_impl(ctx, r->n_cand, cand.seed_flags, 2, r->n_storms, r->cand_idx, r->n_passed, st, fused ? &ca : nullptr)) return -1;
+        STAGE(TCR_STAGE_SELECT);
+        if (cell_order_launch(ctx, ca, fused, (hipStream_t)st)) return -1;
+    } else {
+        if (compact_impl(ctx, r->n_cand, cand.seed_flags, 2, r->n_storms, r->cand_idx, r->n_passed, st, nullptr)) return -1;
+        STAGE(TCR_STAGE_SELECT);
+    }
     STAGE(TCR_STAGE_ORDER);
     if (gather_impl(ctx, &cand, r->cand_idx, r->n_storms, r->n_passed, &storms, seed, year, cand0, key, st)) return -1;
     STAGE(TCR_STAGE_GATHER);
@@ -1716,8 +1759,8 @@ int enqueue_round(tcr_ctx *ctx, const tcr_round *r, uint64_t seed, int32_t year,
     in.slot = storms.slot; in.phases = storms.phases; in.n_dev = r->exact_count ? r->n_passed : nullptr;
     if (r->f32) {
         if (ensure_f32(ctx, (hipStream_t)st)) return -1;
-        if (integrate_impl<float>(ctx, &in, tracks_of<float>(reinterpret_cast<const tcr_tracks_f32 *>(&r->tracks)), st, r->stats, r->n_passed)) return -1;
-    } else if (integrate_impl<double>(ctx, &in, tracks_of<double>(&r->tracks), st, r->stats, r->n_passed)) return -1;
+        if (integrate_impl<float>(ctx, &in, tracks_of<float>(reinterpret_cast<const tcr_tracks_f32 *>(&r->tracks)), st, r->stats, r->n_passed, r->n_expected)) return -1;
+    } else if (integrate_impl<double>(ctx, &in, tracks_of<double>(&r->tracks), st, r->stats, r->n_passed, r->n_expected)) return -1;
     // (the stats of tcr_stats_dev are accumulated by the batch's last kernel, k_flags)
     STAGE(TCR_STAGE_STATS);
     if (r->acc_idx) {
@@ -1771,7 +1814,7 @@ int tcr_round_dev(tcr_ctx *ctx, const tcr_round *r, uint64_t seed, int32_t year,
     {   // the one run of padding bytes in the descriptor (behind tcr_tracks.tc_rows_only) must not take part in the comparison
         constexpr size_t pad0 = offsetof(tcr_round, tracks) + offsetof(tcr_tracks, tc_rows_only) + sizeof(int32_t);
         constexpr size_t pad1 = offsetof(tcr_round, tracks) + sizeof(tcr_tracks);
-        static_assert(pad1 >= pad0 && sizeof(tcr_seeds) == 80 && sizeof(tcr_round) == 376, "tcr_round layout changed: revisit the key");
+        static_assert(pad1 >= pad0 && sizeof(tcr_seeds) == 80 && sizeof(tcr_round) == 384, "tcr_round layout changed: revisit the key");
         memset(key.data() + pad0, 0, pad1 - pad0);
     }
     memcpy(key.data() + sizeof(tcr_round), &ctx->epoch, sizeof(uint64_t));

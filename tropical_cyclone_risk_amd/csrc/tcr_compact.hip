@@ -15,6 +15,46 @@ constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;                       // items per thread
 constexpr int kScanTile = kScanThreads * kScanItems;
 
+// ---------------------------------------------------------------------------------------------------------------
+// Locality order of the dense batch (round 3).  The step is bound by L2 misses on the 142 MB field set (DESIGN.md §9):
+// storms are drawn at random positions, so the 64 lanes of an integrator wave gather from 64 unrelated places.  Ordering
+// the selected candidates by the 2-degree cell of their genesis point (latitude row major) — a stable counting sort of the
+// index list, before the seeds are gathered, so no storm data moves — puts neighbours into the same wave: the
+// integrator's L2 misses drop by ~20 %, the 100 000-storm step by 5-7 %.  Per-storm results do not depend on the order.
+// key = row * ncol + col; bins <= 65536.
+struct CellOrderArgs {
+    const double *lon0, *lat0;       // candidate arrays (indexed by idx[])
+    int32_t *idx_in;                 // [n] scratch: the selection (ascending candidate indices), copied aside by k_cell_key
+    int32_t *idx_out;
+    const int64_t *count;            // device scalar: how many entries of idx_in are valid (may be NULL: n)
+    int64_t n;
+    double inv_cell;
+    int ncol, nbins;
+    int32_t *key;                    // [n] scratch
+    int32_t *hist;                   // [nbins + 1]: counts -> exclusive offsets (k_cell_scan) -> running cursors (k_cell_scatter)
+    int32_t *start;                  // [nbins + 1]: a copy of the exclusive offsets for k_cell_rank
+    int32_t *tmp, *tmp_key;          // [n] each: the scatter's output (cell-grouped, unordered inside a cell) and its keys
+    int32_t *long_cells;             // [nbins + 1]: [0] how many cells hold more than kCellLong entries, then those cells (k_cell_scan)
+};
+
+// A cell with more entries than this is not ranked entry by entry (one thread scanning the whole segment per entry: quadratic
+// in the cell's population) but sorted as a segment by a workgroup (k_cell_rank's second half).  Typical cells — 2-degree
+// cells, 100 000 storms over a basin — hold 5-30 entries; a small basin with large cells, or NaN genesis points (all in
+// cell 0), put thousands into one.
+constexpr int kCellLong = 96;
+constexpr int kCellSortChunk = 4096;
+
+// the cell of a genesis point (k_cell_key; also inside k_compact when a round asks for the locality order)
+__device__ __forceinline__ int cell_of(const CellOrderArgs &a, double lo, double la)
+{
+    lo = lo - 360.0 * floor(lo / 360.0);
+    int col = (int)(lo * a.inv_cell), row = (int)((la + 90.0) * a.inv_cell);
+    const int nrow = a.nbins / a.ncol;
+    col = col < 0 ? 0 : (col >= a.ncol ? a.ncol - 1 : col);
+    row = row < 0 ? 0 : (row >= nrow ? nrow - 1 : row);
+    return (lo == lo && la == la) ? row * a.ncol + col : 0;          // (a NaN position: cell 0)
+}
+
 // One launch (three until round 4: count, a 1024-thread scan workgroup, write).  A tile's workgroup counts its selected
 // items, publishes the count, adds up the counts of the tiles in front of it — a look-back over their published words, one
 // word per thread, no chain between tiles — and writes its indices at their ranks.  Small workgroups matter as much as the
@@ -34,9 +74,12 @@ __device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long lo
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// KEY: the selection is about to be put into locality order (tcr_round_dev): what k_cell_key would do in a launch of its own
+// — copy the entry aside, compute its cell, count the cell — happens where the entry is written.
+template <bool KEY>
 __global__ __launch_bounds__(kScanThreads) void k_compact(int64_t n, const int32_t *__restrict__ flags, int32_t mask,
                                                           int64_t max_out, int32_t *__restrict__ idx, int64_t *__restrict__ total,
-                                                          unsigned long long *__restrict__ state, int n_tiles)
+                                                          unsigned long long *__restrict__ state, int n_tiles, CellOrderArgs cell)
 {
     __shared__ int s[kScanThreads];
     __shared__ int s_tile;
@@ -90,7 +133,16 @@ __global__ __launch_bounds__(kScanThreads) void k_compact(int64_t n, const int32
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k)
         if (sel[k]) {
-            if (rank < max_out) idx[rank] = (int32_t)(base + k);
+            if (rank < max_out) {
+                const int32_t c = (int32_t)(base + k);
+                idx[rank] = c;
+                if (KEY) {
+                    cell.idx_in[rank] = c;
+                    const int kk = cell_of(cell, cell.lon0[c], cell.lat0[c]);
+                    cell.key[rank] = kk;
+                    atomicAdd(cell.hist + kk, 1);
+                }
+            }
             ++rank;
         }
 }
@@ -144,35 +196,6 @@ __global__ __launch_bounds__(256) void k_gather_seeds(GatherSeedArgs a)
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Locality order of the dense batch (round 3).  The step is bound by L2 misses on the 142 MB field set (DESIGN.md §9):
-// storms are drawn at random positions, so the 64 lanes of an integrator wave gather from 64 unrelated places.  Ordering
-// the selected candidates by the 2-degree cell of their genesis point (latitude row major) — a stable counting sort of the
-// index list, before the seeds are gathered, so no storm data moves — puts neighbours into the same wave: the
-// integrator's L2 misses drop by ~20 %, the 100 000-storm step by 5-7 %.  Per-storm results do not depend on the order.
-// key = row * ncol + col; bins <= 65536.
-struct CellOrderArgs {
-    const double *lon0, *lat0;       // candidate arrays (indexed by idx[])
-    int32_t *idx_in;                 // [n] scratch: the selection (ascending candidate indices), copied aside by k_cell_key
-    int32_t *idx_out;
-    const int64_t *count;            // device scalar: how many entries of idx_in are valid (may be NULL: n)
-    int64_t n;
-    double inv_cell;
-    int ncol, nbins;
-    int32_t *key;                    // [n] scratch
-    int32_t *hist;                   // [nbins + 1]: counts -> exclusive offsets (k_cell_scan) -> running cursors (k_cell_scatter)
-    int32_t *start;                  // [nbins + 1]: a copy of the exclusive offsets for k_cell_rank
-    int32_t *tmp, *tmp_key;          // [n] each: the scatter's output (cell-grouped, unordered inside a cell) and its keys
-    int32_t *long_cells;             // [nbins + 1]: [0] how many cells hold more than kCellLong entries, then those cells (k_cell_scan)
-};
-
-// A cell with more entries than this is not ranked entry by entry (one thread scanning the whole segment per entry: quadratic
-// in the cell's population) but sorted as a segment by a workgroup (k_cell_rank's second half).  Typical cells — 2-degree
-// cells, 100 000 storms over a basin — hold 5-30 entries; a small basin with large cells, or NaN genesis points (all in
-// cell 0), put thousands into one.
-constexpr int kCellLong = 96;
-constexpr int kCellSortChunk = 4096;
-
 __device__ __forceinline__ int64_t cell_n(const CellOrderArgs &a) { return (a.count && *a.count < a.n) ? *a.count : a.n; }
 
 // With few cells (large cells / a small basin) thousands of entries hit the same counter: the workgroup counts in LDS first
@@ -191,13 +214,7 @@ __global__ __launch_bounds__(256) void k_cell_key(CellOrderArgs a)
     if (i < cell_n(a)) {
         const int32_t c = a.idx_out[i];                   // the selection as tcr_compact_dev left it (in place: idx_out == the list)
         a.idx_in[i] = c;                                  // ... copied aside: the ranked result overwrites the list
-        double lo = a.lon0[c], la = a.lat0[c];
-        lo = lo - 360.0 * floor(lo / 360.0);
-        int col = (int)(lo * a.inv_cell), row = (int)((la + 90.0) * a.inv_cell);
-        const int nrow = a.nbins / a.ncol;
-        col = col < 0 ? 0 : (col >= a.ncol ? a.ncol - 1 : col);
-        row = row < 0 ? 0 : (row >= nrow ? nrow - 1 : row);
-        const int k = (lo == lo && la == la) ? row * a.ncol + col : 0;          // (a NaN position: cell 0)
+        const int k = cell_of(a, a.lon0[c], a.lat0[c]);
         a.key[i] = k;
         if (local) atomicAdd(&h[k], 1); else atomicAdd(a.hist + k, 1);
     }

@@ -260,12 +260,14 @@ struct BatchReset {
     unsigned long long *und_count;
     int32_t *flags;
     int64_t n_flags;
+    unsigned long long *tc_count;       // TC-rows-only: the length of the list k_screen appends to
 };
 __device__ __forceinline__ void batch_reset(const BatchReset &z, int64_t i, int64_t stride)
 {
     if (!z.queue) return;
     for (int64_t k = i; k < z.queue_words; k += stride) z.queue[k] = 0ull;
     if (i == 0 && z.und_count) *z.und_count = 0ull;
+    if (i == 0 && z.tc_count) *z.tc_count = 0ull;
     for (int64_t k = i; k < z.n_flags; k += stride) z.flags[k] = 0;
 }
 __global__ __launch_bounds__(256) void k_batch_reset(BatchReset z)
@@ -984,6 +986,8 @@ struct EArgsT {
     const uint8_t *screen_skip;  // k_screen: storms the integrator already found to fail the 2-day test (KArgsT::screen_skip; NULL: none)
     const int32_t *und_list;     // k_screen: if set, only these storms are looked at (KArgsT::und_list); flags[] was zeroed beforehand
     const unsigned long long *und_count;
+    int32_t *tc_list;            // k_screen (TC rows only): appends the storms that pass accept test 1 ...
+    unsigned long long *tc_count;    // ... counted here (zeroed by the batch reset)
     EvalKT<R> K;                 // built on the host; k_emit's small workgroups copy it to LDS
 };
 using EArgs = EArgsT<double>;
@@ -1369,7 +1373,13 @@ __global__ __launch_bounds__(kScreenThreads, TCR_SHADOW_WPS) void k_screen(EArgs
     int hit = any15 ? 1 : 0;
     for (int off = kScreenGroup / 2; off > 0; off >>= 1) hit |= __shfl_xor(hit, off);       // every lane takes part
     any15 = hit != 0;
-    if (on && l == 0) a.flags[sid] = (any15 && pass2d) ? TCR_FLAG_IS_TC : 0;
+    if (on && l == 0) {
+        const bool tc = any15 && pass2d;
+        a.flags[sid] = tc ? TCR_FLAG_IS_TC : 0;
+        // the list k_dense / k_emit walk is appended to here (a compaction launch of its own until round 4; the list's order does
+        // not matter: every consumer works storm by storm)
+        if (tc && a.tc_list) a.tc_list[atomicAdd(a.tc_count, 1ull)] = (int32_t)sid;
+    }
 }
 
 // One thread per storm of the batch.  TC-rows-only mode (tc_list): the storms k_screen passed (exactly the

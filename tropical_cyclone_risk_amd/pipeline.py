@@ -147,7 +147,7 @@ class DevicePipeline:
                                               C.byref(so), counters.data_ptr(), _lib.N_STATS, C.c_void_p(self._stream())))
 
     def round(self, year, cand0, n_cand=None, n_take=None, experiment_seed=None, exact_count=True, stats=None,
-              accepted=False, packed=None, pack_cap=0, seed_hist=None, graph=False):
+              accepted=False, packed=None, pack_cap=0, seed_hist=None, graph=False, n_expected=0):
         """One round of the accept loop in ONE library call (tcr_round_dev): seed_round → select_passed → integrate
         (→ add_stats → select_accepted → pack with the meta columns → n_seeds histogram), nothing returning to Python in
         between; the same kernels in the same order as the separate methods, so the results are theirs.
@@ -155,13 +155,14 @@ class DevicePipeline:
         exact_count: integrate min(n_take, n_passed) storms (n_dev); False: the round is sized so that n_take seeds pass.
         stats: int64 tensor [_lib.N_STATS] added to.  accepted: also select the accepted tracks (acc_idx / n_accepted);
         packed [cap, >= 9*ns + 3]: their survivor records + (candidate index, month, basin index).  seed_hist: int64 tensor
-        [7*12] set to the round's n_seeds contribution.  graph: replay the round from a captured hipGraph (one launch)."""
+        [7*12] set to the round's n_seeds contribution.  graph: replay the round from a captured hipGraph (one launch).
+        n_expected: how many seeds are expected to pass (shapes the integrator's launch; 0 = n_take)."""
         n_cand = self.C if n_cand is None else int(n_cand)
         n_take = self.B if n_take is None else int(n_take)
         assert n_cand <= self.C and n_take <= self.B
         cfg = (n_cand, n_take, bool(exact_count), stats.data_ptr() if stats is not None else 0, bool(accepted),
                packed.data_ptr() if packed is not None else 0, int(pack_cap), int(packed.stride(0)) if packed is not None else 0,
-               seed_hist.data_ptr() if seed_hist is not None else 0)
+               seed_hist.data_ptr() if seed_hist is not None else 0, int(n_expected))
         r = self._rounds.get(cfg)
         if r is None:
             if stats is not None:
@@ -181,6 +182,7 @@ class DevicePipeline:
             if packed is not None:
                 r.packed, r.pack_cap, r.pack_stride = packed.data_ptr(), int(pack_cap), int(packed.stride(0))
             r.seed_hist = seed_hist.data_ptr() if seed_hist is not None else None
+            r.n_expected = int(n_expected)
             self._rounds[cfg] = r
         seed = int(self.eng.nl.gpu_experiment_seed if experiment_seed is None else experiment_seed)
         self.eng._ck(self.eng.L.tcr_round_dev(self.eng.h, C.byref(r), C.c_uint64(seed), int(year), int(cand0),
