@@ -133,7 +133,10 @@ def main():
         C_ens = -(-int(round(args.storms / max(p_pass, 1e-3))) // 8) * 8        # the same block at 1, 2, 4 and 8 ranks
         C = -(-C_ens // world)                                                  # candidates per rank and ensemble
         C_ens = C * world
-        B = int(args.storms / world * 1.25) + 2048                             # capacity: 25 % + 2048 over the expected count
+        # capacity: the number of passing seeds of a sub-block is binomial (sigma = sqrt(C p (1 - p)) < sqrt(expected)): the expected
+        # count + 8 sigma + 256; a sub-block that still has more drops seeds, which the run checks on the device (acc[9])
+        exp_rank = args.storms / world
+        B = int(exp_rank + 8.0 * exp_rank ** 0.5) + 256
     else:
         C = int(B / max(p_pass, 1e-3) * 1.15) + 4096
     pipes = [DevicePipeline(e, C, B, sort_storms=(float(os.environ.get('TCR_CELL_DEG', '2')) if args.order == 'cells' else False), tc_rows_only=(args.rows == 'tc'), dtype=args.dtype) for e in engs]
@@ -145,7 +148,7 @@ def main():
     # storm-steps, nfev, samples, accepted, is_tc, is_tc samples, rounds with < B passing seeds, storms, step-record overflows,
     # passing seeds a batch had no room for (tcr_stats_dev)
     acc = torch.zeros(10, dtype=torch.int64, device=dev)
-    n_exp = int(args.storms / world) if strong else 0      # strong: a rank's batch has 25 % + 2048 rows to spare
+    n_exp = int(args.storms / world) if strong else 0      # strong: a rank's batch has 8 sigma + 256 rows to spare
     use_graph = (args.graph == 'on' or (args.graph == 'auto' and B < 50_000)) and not args.stage_trace
     row = 9 * ns
     # N > 1: all-gather of every batch's final (accepted) tracks through distributed.DeferredRowGather:
