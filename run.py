@@ -12,6 +12,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# run_downscaling keeps several years in flight, each on its own stream: a hardware queue for each (ROCm multiplexes a process's
+# streams onto 4 by default); must be set before the HIP runtime starts
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 
 def main():
