@@ -114,3 +114,37 @@ def test_entry_scripts_compile():
     for f in os.listdir(os.path.join(ROOT, 'tools')):
         if f.endswith('.py'):
             py_compile.compile(os.path.join(ROOT, 'tools', f), doraise=True)
+
+
+def test_kernel_register_budgets():
+    """The resident-next-to-the-integrator contract of round 4: an integrator wave leaves 88 registers on its
+    SIMD, so every kernel of a batch other than the integrator and the forcing-table GEMM must need at most that many
+    (VGPRs + AGPRs, in the allocation granule of 8), and the fp64 integrator must not spill.  Read from the compiler's own
+    resource report (hipcc -Rpass-analysis=kernel-resource-usage: no GPU needed), so that a compiler upgrade that changes
+    the trade shows up here and not as a slower bench."""
+    import subprocess
+    from tropical_cyclone_risk_amd import build as B
+    cmd = [B.hipcc()] + B.FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-o', os.devnull, os.path.join(B.CSRC, 'tcr_abi.hip')]
+    out = subprocess.run(cmd, cwd=B.CSRC, capture_output=True, text=True).stderr
+    rows, cur = {}, None
+    for line in out.splitlines():
+        m = re.search(r'remark: \S+ +(Function Name|Name): (\S+)', line)
+        if m:
+            cur = rows.setdefault(m.group(2), {})
+            continue
+        m = re.search(r'(VGPRs|AGPRs|ScratchSize \[bytes/lane\]): (\d+)', line)
+        if m and cur is not None:
+            cur[m.group(1).split()[0]] = int(m.group(2))
+    assert len(rows) > 40, 'no resource report from hipcc'
+    small = ('k_seed', 'k_compact', 'k_gather_seeds', 'k_cell_key', 'k_cell_scan', 'k_cell_scatter', 'k_cell_rank', 'k_phase_factors_frag',
+             'k_batch_reset', 'k_screenId', 'k_denseId', 'k_emitId', 'k_flagsId', 'k_pack_tracksId', 'k_seed_hist', 'k_stats')
+    seen = set()
+    for name, r in rows.items():
+        if 'k_integrateIdLb' in name:
+            assert r.get('ScratchSize', 0) == 0, (name, r)            # the fp64 integrator owns its SIMD's registers without spilling
+        for s in small:
+            if ('3tcr' + str(len(s.replace('Id', ''))) + s.replace('Id', '') in name) and (not s.endswith('Id') or 'Id' in name.split(s.replace('Id', ''))[1][:3]):
+                regs = r.get('VGPRs', 0) + r.get('AGPRs', 0)
+                assert -(-regs // 8) * 8 <= 88, (name, r)
+                seen.add(s)
+    assert seen >= set(small) - {'k_batch_reset'}, sorted(set(small) - seen)
