@@ -285,8 +285,9 @@ int tcr_seed_hist_dev(tcr_ctx *ctx, const tcr_seeds *cand_dev, int64_t cand0, co
  *     tcr_integrate[_f32]_dev -> tcr_stats_dev -> tcr_compact_dev (accepted tracks) -> tcr_pack_tracks_meta_dev ->
  *     tcr_seed_hist_dev
  * on `stream`, with nothing returning to the host in between; every stage is optional through a NULL buffer.  The results
- * are exactly those of the separate calls (the same kernels in the same order).  All pointers are device memory and the
- * caller owns them; they must stay valid until the stream has run the round. */
+ * are exactly those of the separate calls, bit for bit (the same arithmetic; the round fuses a few of the small launches:
+ * the locality order's cell keys come out of the compaction, the statistics out of the last post-processing kernel).  All
+ * pointers are device memory and the caller owns them; they must stay valid until the stream has run the round. */
 typedef struct {
     int64_t n_cand;             /* candidates of the round: [cand0, cand0 + n_cand) */
     int64_t n_storms;           /* capacity of the dense batch: the first n_storms passing seeds are integrated */
@@ -310,7 +311,8 @@ typedef struct {
                                    shaped for that many storms instead of the batch's capacity; never changes a result */
 } tcr_round;
 /* use_graph != 0: the round is captured into a hipGraph the first time a (ctx, descriptor) pair is seen and replayed from
- * then on — one graph launch instead of ~30 kernel launches, which is what bounds small rounds.  The graph
+ * then on — one graph launch instead of ~20 kernel launches: half the host time of a round (it is not what bounds small
+ * rounds: DESIGN.md section 9, round 4).  The graph
  * is keyed by the descriptor's bytes; it is dropped whenever the context allocates or its parameters change.  seed / year /
  * cand0 reach the replayed kernels through a device-side key that a one-thread launch refreshes in front of the graph.
  * The TCR_* scheduling knobs are read when the graph is captured.  Timing events (tcr_timing_enable) are not recorded by
