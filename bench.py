@@ -78,6 +78,14 @@ def main():
                     help='HBM bytes per integrate launch from a separate rocprofv3 --pmc pass (see profiles/)')
     ap.add_argument('--dtype', choices=('f64', 'f32'), default='f64',
                     help='f32: the fp32 variant of the path (BASELINE config 5): fp32 fields / state / RHS / rows, fp64 time and controller')
+    ap.add_argument('--static-res', type=float, default=0.25, choices=(0.25, 0.125),
+                    help='grid of the synthetic land / bathymetry planes: 0.25 (SURVEY.md section 8d) or 0.125 = the grid and '
+                         "type of the reference's own intensity/data/land.nc (int8, 1440 x 2880)")
+    ap.add_argument('--bathy-kind', choices=('i16', 'f32', 'f64'), default=None,
+                    help='what the synthetic bathymetry holds (default: f64 at 0.25 degrees, whole metres at 0.125)')
+    ap.add_argument('--static-store', choices=('auto', 'f64'), default='auto',
+                    help='auto: exact narrow storage of land / bathymetry where the values allow it (tcr_static_upload); '
+                         'f64: the fp64 planes of rounds 1-4')
     ap.add_argument('--rows', choices=('tc', 'all'), default='tc',
                     help="tc: env winds / vmax / rows only for storms that pass accept test 1, as the reference does "
                          "(compute.py:190-204); all: rows for every integrated storm (round 1's workload)")
@@ -110,7 +118,9 @@ def main():
     dev = torch.device('cuda', local)
     year = 2000
 
-    env = synthetic.make_env('era5')
+    env = synthetic.make_env('era5', static_res=args.static_res, bathy_kind=args.bathy_kind)
+    from tropical_cyclone_risk_amd import namelist as _nl
+    _nl.gpu_static_store = args.static_store
     n_str = max(1, args.streams)
     # many batches in flight: batches that do not fill the chip run with lanes that take ~3 storms in turn (tcr_schedule_set)
     engs = [TCEngine(args.basin, device=local).stage_env(env).schedule(args.storms_per_lane) for _ in range(n_str)]
@@ -365,13 +375,14 @@ def main():
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'gpu_active_s': gpu_active_s,
             'config': {'workload': '%s basin, %s, synthetic ERA5-shaped monthly fields '
-                                   '(1 deg thermo/wind, 0.25 deg land/bathymetry), 15-day tracks, hourly output, '
+                                   '(1 deg thermo/wind, %s deg land/bathymetry), 15-day tracks, hourly output, '
                                    'device-side seeding, %s; %s' % (args.basin, (
                                        'one ensemble of %d candidates (%.0f storms pass on average) per step, sharded over %d GPU(s), '
                                        'accepted tracks all-gathered once per ensemble' % (C_ens, storms_total / args.steps, world)) if strong
-                                       else '%d storms per GPU per step' % B, 'fp64' if args.dtype == 'f64' else 'fp32 fields/state/RHS/rows with fp64 time and step controller', (
+                                       else '%d storms per GPU per step' % B, '%g' % args.static_res, 'fp64' if args.dtype == 'f64' else 'fp32 fields/state/RHS/rows with fp64 time and step controller', (
                                        'env winds, vmax and rows only for storms that pass accept test 1, as the reference '
                                        'does (compute.py:190-204)' if args.rows == 'tc' else 'rows for every integrated storm')),
+                       'static_fields': dict(zip(('storage', 'bytes'), eng.static_info()), resolution_deg=args.static_res),
                        'rows': args.rows, 'batch_order': args.order, 'is_tc_fraction': tc_total / storms_total,
                        'storms_per_step': storms_total / args.steps, 'storm_steps_total': int(steps_total),
                        'emitted_samples_per_step': emitted_total / (args.steps * world),
@@ -452,7 +463,8 @@ def cpu_baseline(pipe, args, B):
         try:
             env1 = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
             r = subprocess.run([sys.executable, '-m', 'oracle.cpu_baseline', '--inputs', fn, '--basin', args.basin,
-                                '--budget', str(args.cpu_budget)], cwd=ROOT, capture_output=True, text=True,
+                                '--budget', str(args.cpu_budget), '--static-res', str(args.static_res)] +
+                               (['--bathy-kind', args.bathy_kind] if args.bathy_kind else []), cwd=ROOT, capture_output=True, text=True,
                                timeout=600, env=env1)
             res = json.loads(r.stdout.strip().splitlines()[-1])
         except Exception as e:                                        # report, never hide

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TCR_ABI_VERSION 5
+#define TCR_ABI_VERSION 6
 #define TCR_NW 4            /* ua250, va250, ua850, va850  (track/env_wind.py:22-26) */
 #define TCR_NCOV 10         /* packed lower triangle (0,0),(1,0),(1,1),(2,0)..(3,3) (env_wind.py:31-42) */
 #define TCR_MAX_SERIES 32
@@ -153,6 +153,15 @@ int tcr_static_upload(tcr_ctx *ctx, const tcr_grid *hg, const double *land, cons
  * f_land / f_bath of the reference allow (intensity/geo.py:9-34); equal grids take the one-grid path */
 int tcr_static_upload2(tcr_ctx *ctx, const tcr_grid *land_grid, const double *land,
                        const tcr_grid *bathy_grid, const double *bathy);
+/* How the two planes are kept in HBM.  The reference hands float64 arrays to RectBivariateSpline whatever the files hold
+ * (intensity/geo.py:15-19, 29-33) — its own land.nc is int8 0 / 1 on a 0.125-degree grid (1440 x 2880).  With pref 0 (auto,
+ * the default) an upload inspects the VALUES and stores them narrow when that is exact: land 0 / 1 and whole-metre
+ * bathymetry in [-16384, 16383] on one grid -> one uint16 per grid point (mode 2); land in 0 .. 255 and a bathymetry that
+ * round-trips through float32 -> a uint8 and a float plane (mode 3); anything else the fp64 planes of pref 1 (mode 0, or 1
+ * on two grids).  The kernels widen to the same doubles before any arithmetic, so results do not depend on the mode.
+ * Call before tcr_static_upload*.  tcr_static_info reports the mode in use and the bytes the planes occupy. */
+int tcr_static_store(tcr_ctx *ctx, int32_t pref);
+int tcr_static_info(tcr_ctx *ctx, int32_t *mode, int64_t *bytes);
 /* replaces: BetaAdvectionTrack._load_wnd_stat (bam_track.py:76-91) +
  *           Coupled_FAST.init_fields (coupled_fast.py:217-225) for one month slot.
  */

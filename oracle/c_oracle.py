@@ -85,6 +85,9 @@ def c_params(prm=None):
     return p
 
 
+_STATIC_CROPS = {}
+
+
 class CMonthEnv:
     """Cropped [lat][lon] planes of one (basin, month) + the C struct pointing at them."""
 
@@ -107,11 +110,21 @@ class CMonthEnv:
         tl, ta, _ = crop(env.lon, env.lat, env.vpot[month0])
         for name in ('vpot', 'chi', 'mld', 'strat'):
             setattr(e, name, _dp(crop(env.lon, env.lat, getattr(env, name)[month0])[2]))
-        hl, ha, _ = crop(env.hlon, env.hlat, env.land)
-        e.land = _dp(crop(env.hlon, env.hlat, env.land)[2])
-        # the bathymetry is its own interpolator on its own grid (geo.py:9-20); env.blon / blat when it differs
-        blon, blat = getattr(env, 'blon', None), getattr(env, 'blat', None)
-        bl, ba, bb = crop(env.hlon if blon is None else blon, env.hlat if blat is None else blat, env.bathy)
+        # the static planes are the same for the twelve months of an (environment, basin): cropped once, shared (the
+        # reference's 0.125-degree land.nc is 33 MB per float64 copy)
+        key = (id(env.land), id(env.bathy), tuple(b))
+        st = _STATIC_CROPS.get(key)
+        if st is None or st[0] is not env.land or st[1] is not env.bathy:
+            hl, ha, lb_ = crop(env.hlon, env.hlat, env.land)
+            # the bathymetry is its own interpolator on its own grid (geo.py:9-20); env.blon / blat when it differs
+            blon, blat = getattr(env, 'blon', None), getattr(env, 'blat', None)
+            bl, ba, bb = crop(env.hlon if blon is None else blon, env.hlat if blat is None else blat, env.bathy)
+            if len(_STATIC_CROPS) >= 4:
+                _STATIC_CROPS.clear()
+            st = _STATIC_CROPS[key] = (env.land, env.bathy, hl, ha, lb_, bl, ba, bb)
+        _, _, hl, ha, lb_, bl, ba, bb = st
+        keep += [lb_, bb]
+        e.land = _dp(lb_)
         e.bathy = _dp(bb)
         for g, (lo, la) in zip((e.wg, e.tg, e.hg, e.bg), ((wl, wa), (tl, ta), (hl, ha), (bl, ba))):
             g.nlon, g.nlat, g.lon, g.lat = lo.size, la.size, _dp(lo), _dp(la)

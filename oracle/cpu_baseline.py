@@ -106,10 +106,12 @@ def main():
     ap.add_argument('--env-seed', type=int, default=20250614)
     ap.add_argument('--procs', type=int, default=0)
     ap.add_argument('--budget', type=float, default=12.0, help='target seconds per leg')
+    ap.add_argument('--static-res', type=float, default=0.25)
+    ap.add_argument('--bathy-kind', default=None)
     a = ap.parse_args()
     global _ENV, _BASIN, _STORMS
     from tropical_cyclone_risk_amd import synthetic
-    _ENV = synthetic.make_env(a.shape, seed=a.env_seed)
+    _ENV = synthetic.make_env(a.shape, seed=a.env_seed, static_res=a.static_res, bathy_kind=a.bathy_kind)
     _BASIN = a.basin
     z = np.load(a.inputs)
     _STORMS = {k: z[k] for k in z.files}

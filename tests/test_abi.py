@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     for name in _declared():
         assert hasattr(L, name), name
     from tropical_cyclone_risk_amd import _lib
-    assert L.tcr_abi_version() == _lib.TCR_ABI_VERSION == 5
+    assert L.tcr_abi_version() == _lib.TCR_ABI_VERSION == 6
 
 
 def test_struct_layout_matches_header(built_lib):

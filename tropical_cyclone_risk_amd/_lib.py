@@ -10,11 +10,12 @@ import os
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, 'libtcrisk_hip.so')
 
-TCR_ABI_VERSION = 5
+TCR_ABI_VERSION = 6
 TCR_NW, TCR_NCOV, TCR_MAX_SERIES, TCR_N_BASINS = 4, 10, 32, 7
 STATUS_GATED, STATUS_FINISHED, STATUS_EVENT, STATUS_STEP_FAIL, STATUS_STEP_OVERFLOW = -1, 0, 1, -2, -3
 FLAG_IS_TC, FLAG_ACCEPTED = 1, 2
 STAGES = ('start', 'seed', 'select', 'order', 'gather', 'fourier', 'integrate', 'screen', 'select_tc', 'dense', 'emit', 'flags', 'stats', 'pack')
+STATIC_MODES = ('f64', 'f64_split', 'pack16', 'u8_f32')     # StaticMode (tcr_static_info)
 N_STATS = 10        # TCR_N_STATS: words of a tcr_stats_dev / tcr_round.stats counter block
 
 DP = C.POINTER(C.c_double)
@@ -31,7 +32,8 @@ EXPORTS = ('tcr_abi_version', 'tcr_ctx_create', 'tcr_ctx_destroy', 'tcr_last_err
            'tcr_potential_intensity_host', 'tcr_potential_intensity_dev', 'tcr_chi_rh_host',
            'tcr_integrate_probe_host', 'tcr_integrate_f32_dev', 'tcr_integrate_f32_host', 'tcr_pack_tracks_f32_dev',
            'tcr_wind_stats_f32_dev', 'tcr_wind_stats_f32_host', 'tcr_static_upload2', 'tcr_init_m_dev', 'tcr_init_m_host', 'tcr_cell_order_dev',
-           'tcr_round_dev', 'tcr_round_graph_stats', 'tcr_schedule_set', 'tcr_stage_trace_enable', 'tcr_stage_trace_sum', 'tcr_seed_hist_dev', 'tcr_pack_tracks_meta_dev')
+           'tcr_round_dev', 'tcr_round_graph_stats', 'tcr_schedule_set', 'tcr_stage_trace_enable', 'tcr_stage_trace_sum', 'tcr_seed_hist_dev', 'tcr_pack_tracks_meta_dev',
+           'tcr_static_store', 'tcr_static_info')
 
 
 class Grid(C.Structure):
@@ -141,6 +143,8 @@ def lib():
     L.tcr_params_set.argtypes = [C.c_void_p, C.POINTER(Params)]
     L.tcr_static_upload.argtypes = [C.c_void_p, C.POINTER(Grid), DP, DP]
     L.tcr_static_upload2.argtypes = [C.c_void_p, C.POINTER(Grid), DP, C.POINTER(Grid), DP]
+    L.tcr_static_store.argtypes = [C.c_void_p, C.c_int32]
+    L.tcr_static_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     L.tcr_init_m_dev.argtypes = [C.c_void_p, C.POINTER(Storms), C.c_double, C.c_void_p, C.c_void_p]
     L.tcr_init_m_host.argtypes = [C.c_void_p, C.POINTER(Storms), C.c_double, DP]
     L.tcr_cell_order_dev.argtypes = [C.c_void_p, C.POINTER(Seeds), C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p]

@@ -76,7 +76,14 @@ struct tcr_ctx {
     double *d_stat = nullptr;                   // [lat][lon][2] land, bathymetry interleaved (one shared grid)
     double *d_land = nullptr, *d_bathy = nullptr;   // separate planes when the two grids differ (split_static)
     float *d_land32 = nullptr, *d_bathy32 = nullptr;
-    bool split_static = false;
+    bool split_static = false;                  // land and bathymetry on two grids (hg, bg)
+    // exact narrow storage of the two (tcr_device.h, StaticMode): kStatPack16 -> d_nstat = uint16 [lat][lon];
+    // kStatU8F32 -> d_nstat = the uint8 land plane, d_nbathy = the float bathymetry plane
+    int static_mode = kStatF64;
+    int static_pref = 0;                        // tcr_static_store: 0 auto, 1 fp64 planes
+    void *d_nstat = nullptr;
+    float *d_nbathy = nullptr;
+    size_t static_bytes = 0;                    // footprint of the staged land + bathymetry
     uint8_t *d_mask_bits = nullptr;             // the eight mask planes as the bits of one byte per grid point
     // workspaces
     double *d_fs = nullptr, *d_srec = nullptr;    // forcing tables, accepted-step records
@@ -413,23 +420,49 @@ int timing_events(tcr_ctx *ctx, hipEvent_t **quad)
 }
 
 
-// k_integrate<R, AFFINE, PROBE, SPLIT>: pick the instantiation
+// k_integrate<R, AFFINE, PROBE, SM>: pick the instantiation.  The narrow static modes exist for affine grids only (a context
+// whose grids are not all affine has had its static planes widened to fp64 by settle_static).
 template <typename R, bool PROBE>
-void launch_integrate_rp(const KArgsT<R> &a, bool affine, bool split, unsigned waves, hipStream_t st)
+void launch_integrate_rp(const KArgsT<R> &a, bool affine, int sm, unsigned waves, hipStream_t st)
 {
-    if (affine && !split) hipLaunchKernelGGL((k_integrate<R, true, PROBE, false>), dim3(waves), dim3(kWave), 0, st, a);
-    else if (!affine && !split) hipLaunchKernelGGL((k_integrate<R, false, PROBE, false>), dim3(waves), dim3(kWave), 0, st, a);
-    else if (affine) hipLaunchKernelGGL((k_integrate<R, true, PROBE, true>), dim3(waves), dim3(kWave), 0, st, a);
-    else hipLaunchKernelGGL((k_integrate<R, false, PROBE, true>), dim3(waves), dim3(kWave), 0, st, a);
+#define TCR_LI(A, S) hipLaunchKernelGGL((k_integrate<R, A, PROBE, S>), dim3(waves), dim3(kWave), 0, st, a)
+    if (affine) {
+        switch (sm) {
+        case kStatF64Split: TCR_LI(true, kStatF64Split); break;
+        case kStatPack16: TCR_LI(true, kStatPack16); break;
+        case kStatU8F32: TCR_LI(true, kStatU8F32); break;
+        default: TCR_LI(true, kStatF64); break;
+        }
+    } else if (sm == kStatF64Split) TCR_LI(false, kStatF64Split);
+    else TCR_LI(false, kStatF64);
+#undef TCR_LI
 }
-void launch_integrate(const KArgsT<double> &a, bool affine, bool probe, bool split, unsigned waves, hipStream_t st)
+void launch_integrate(const KArgsT<double> &a, bool affine, bool probe, int sm, unsigned waves, hipStream_t st)
 {
-    if (probe) launch_integrate_rp<double, true>(a, affine, split, waves, st);
-    else launch_integrate_rp<double, false>(a, affine, split, waves, st);
+    if (probe) launch_integrate_rp<double, true>(a, affine, sm, waves, st);
+    else launch_integrate_rp<double, false>(a, affine, sm, waves, st);
 }
-void launch_integrate(const KArgsT<float> &a, bool affine, bool, bool split, unsigned waves, hipStream_t st)
+void launch_integrate(const KArgsT<float> &a, bool affine, bool, int sm, unsigned waves, hipStream_t st)
 {
-    launch_integrate_rp<float, false>(a, affine, split, waves, st);      // the decision probe is an fp64 instrument
+    launch_integrate_rp<float, false>(a, affine, sm, waves, st);      // the decision probe is an fp64 instrument
+}
+
+// kStatPack16 / kStatU8F32 -> the fp64 planes the general (non-affine) kernels read: the same values, widened
+__global__ __launch_bounds__(256) void k_static_widen(int mode, const void *__restrict__ nstat, const float *__restrict__ nbathy,
+                                                      size_t n_land, size_t n_bathy, double *__restrict__ stat,
+                                                      double *__restrict__ land, double *__restrict__ bathy)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode == kStatPack16) {
+        if (i >= n_land) return;
+        const unsigned v = reinterpret_cast<const uint16_t *>(nstat)[i];
+        stat[2 * i] = (double)(int)(v & 1u);
+        stat[2 * i + 1] = (double)((int)(v >> 1) - kPack16Bias);
+    } else {
+        // (stat != NULL: one shared grid, interleaved; else two planes)
+        if (i < n_land) { const double v = (double)reinterpret_cast<const uint8_t *>(nstat)[i]; if (stat) stat[2 * i] = v; else land[i] = v; }
+        if (i < n_bathy) { const double v = (double)nbathy[i]; if (stat) stat[2 * i + 1] = v; else bathy[i] = v; }
+    }
 }
 
 // ---- fp32 staging: float knots (+ reciprocal widths and the affine test in float arithmetic) and float
@@ -481,7 +514,7 @@ int ensure_f32(tcr_ctx *ctx, hipStream_t st)
         s.f32_stale = false;
         ctx->slots_dirty = true;
     }
-    if (ctx->stat32_stale) {
+    if (ctx->stat32_stale && ctx->static_mode != kStatPack16 && ctx->static_mode != kStatU8F32) {
         if (ctx->split_static) {
             if (conv(ctx->d_land, &ctx->d_land32, nh / kStaticStride)) return -1;
             if (conv(ctx->d_bathy, &ctx->d_bathy32, ctx->bg.lon.size() * ctx->bg.lat.size())) return -1;
@@ -519,20 +552,61 @@ void host_eval_k(const tcr_ctx *ctx, EvalKT<R> &K, bool *all_affine)
     K.tx = axis_of<R>(ctx->tg, true); K.ty = axis_of<R>(ctx->tg, false);
     K.hx = axis_of<R>(ctx->hg, true); K.hy = axis_of<R>(ctx->hg, false);
     const bool f64 = std::is_same<R, double>::value;
-    if (ctx->split_static) {
-        K.bx = axis_of<R>(ctx->bg, true); K.by = axis_of<R>(ctx->bg, false);
-        K.stat = f64 ? reinterpret_cast<const R *>(ctx->d_land) : reinterpret_cast<const R *>(ctx->d_land32);
-        K.bathy = f64 ? reinterpret_cast<const R *>(ctx->d_bathy) : reinterpret_cast<const R *>(ctx->d_bathy32);
-    } else {
-        K.bx = K.hx; K.by = K.hy;
-        K.stat = f64 ? reinterpret_cast<const R *>(ctx->d_stat) : reinterpret_cast<const R *>(ctx->d_stat32);
+    if (ctx->split_static) { K.bx = axis_of<R>(ctx->bg, true); K.by = axis_of<R>(ctx->bg, false); }
+    else { K.bx = K.hx; K.by = K.hy; }
+    switch (ctx->static_mode) {
+    case kStatF64Split:
+        K.stat = f64 ? static_cast<const void *>(ctx->d_land) : static_cast<const void *>(ctx->d_land32);
+        K.bathy = f64 ? static_cast<const void *>(ctx->d_bathy) : static_cast<const void *>(ctx->d_bathy32);
+        break;
+    case kStatPack16: K.stat = ctx->d_nstat; K.bathy = nullptr; break;
+    case kStatU8F32: K.stat = ctx->d_nstat; K.bathy = ctx->d_nbathy; break;
+    default:
+        K.stat = f64 ? static_cast<const void *>(ctx->d_stat) : static_cast<const void *>(ctx->d_stat32);
         K.bathy = nullptr;
+        break;
     }
     eval_k_scalars<R>(ctx->prm, K);
     K.tw_same = (ctx->wg.lon == ctx->tg.lon && ctx->wg.lat == ctx->tg.lat) ? 1 : 0;       // same knots: the same cells and weights
     K.pad_ = 0;
     *all_affine = K.wx.affine && K.wy.affine && K.tx.affine && K.ty.affine && K.hx.affine && K.hy.affine &&
                   K.bx.affine && K.by.affine;
+}
+
+// The narrow static modes are instantiated for affine grids only.  A context whose grids are not all affine in the precision
+// of the call (a Gaussian latitude axis, say) gets its land / bathymetry widened to the fp64 planes once — the same values —
+// and keeps them.
+int widen_static(tcr_ctx *ctx, hipStream_t st)
+{
+    const int mode = ctx->static_mode;
+    if (mode != kStatPack16 && mode != kStatU8F32) return 0;
+    const size_t np = ctx->hg.lon.size() * ctx->hg.lat.size();
+    const size_t nb = ctx->split_static ? ctx->bg.lon.size() * ctx->bg.lat.size() : np;
+    if (ctx->split_static) { if (dev_alloc(ctx, &ctx->d_land, np) || dev_alloc(ctx, &ctx->d_bathy, nb)) return -1; }
+    else if (dev_alloc(ctx, &ctx->d_stat, np * kStaticStride)) return -1;
+    hipLaunchKernelGGL(k_static_widen, dim3((unsigned)((std::max(np, nb) + 255) / 256)), dim3(256), 0, st, mode, ctx->d_nstat, ctx->d_nbathy,
+                       np, nb, ctx->d_stat, ctx->d_land, ctx->d_bathy);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, hipFree(ctx->d_nstat)); ctx->d_nstat = nullptr;
+    if (ctx->d_nbathy) { HIPCHK(ctx, hipFree(ctx->d_nbathy)); ctx->d_nbathy = nullptr; }
+    ctx->static_mode = ctx->split_static ? kStatF64Split : kStatF64;
+    ctx->static_bytes = sizeof(double) * (np + nb);
+    ctx->stat32_stale = true;
+    ++ctx->epoch;
+    return 0;
+}
+
+template <typename R>
+int eval_k_ready(tcr_ctx *ctx, EvalKT<R> &K, bool *affine, hipStream_t st)
+{
+    host_eval_k<R>(ctx, K, affine);
+    if (!*affine && (ctx->static_mode == kStatPack16 || ctx->static_mode == kStatU8F32)) {
+        if (widen_static(ctx, st)) return -1;
+        if (!std::is_same<R, double>::value && ensure_f32(ctx, st)) return -1;
+        host_eval_k<R>(ctx, K, affine);
+    }
+    return 0;
 }
 
 // Outputs of one precision: tcr_tracks (double planes) or tcr_tracks_f32 (float planes), same layout
@@ -649,7 +723,7 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
     R *fs = reinterpret_cast<R *>(ctx->d_fs);
     EvalKT<R> EK{};
     bool affine = false;
-    host_eval_k<R>(ctx, EK, &affine);
+    if (eval_k_ready<R>(ctx, EK, &affine, st)) return -1;
 
     hipEvent_t *ev = nullptr;
     if (ctx->timing && !ctx->capturing && timing_events(ctx, &ev)) return -1;
@@ -726,7 +800,7 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
             a.park_out = ctx->d_park[pass & 1];
             // the stage times of an attempt lie in [t, t_new] and the table lookup at t reads samples up to ceil(t / dt) + 1
             a.t_limit = (segmented && pass == 0) ? ts_host(P, kFsSegSamples - 2) : 1e300;
-            launch_integrate(a, affine, probe, ctx->split_static, waves, st);
+            launch_integrate(a, affine, probe, ctx->static_mode, waves, st);
             if (last) break;
             if (segmented && pass == 0) {
                 // the rest of the table, for the storms that are still alive (park list of pass 0, count on the device);
@@ -855,7 +929,7 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     }
     for (auto &s : ctx->slots) { (void)hipFree(s.wind); (void)hipFree(s.thermo); (void)hipFree(s.rh); (void)hipFree(s.wind32); (void)hipFree(s.thermo32); }
     (void)hipFree(ctx->d_stat32); (void)hipFree(ctx->d_land); (void)hipFree(ctx->d_bathy); (void)hipFree(ctx->d_land32); (void)hipFree(ctx->d_bathy32);
-    (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_mask_bits);
+    (void)hipFree(ctx->d_slots); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_mask_bits); (void)hipFree(ctx->d_nstat); (void)hipFree(ctx->d_nbathy);
     (void)hipFree(ctx->d_fs); (void)hipFree(ctx->d_srec); (void)hipFree(ctx->d_vrec);
     for (auto &ev : ctx->ev_pool) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : ctx->st_pool) if (ev) (void)hipEventDestroy(ev);
@@ -901,6 +975,23 @@ int tcr_params_set(tcr_ctx *ctx, const tcr_params *p)
     return 0;
 }
 
+int tcr_static_store(tcr_ctx *ctx, int32_t pref)
+{
+    if (!ctx) return -1;
+    if (pref != 0 && pref != 1) return fail(ctx, "tcr_static_store: 0 (auto) or 1 (fp64 planes)");
+    ctx->static_pref = pref;
+    return 0;
+}
+
+int tcr_static_info(tcr_ctx *ctx, int32_t *mode, int64_t *bytes)
+{
+    if (!ctx) return -1;
+    if (!ctx->hg.set) return fail(ctx, "static fields not staged (tcr_static_upload)");
+    if (mode) *mode = ctx->static_mode;
+    if (bytes) *bytes = (int64_t)ctx->static_bytes;
+    return 0;
+}
+
 int tcr_static_upload2(tcr_ctx *ctx, const tcr_grid *lg, const double *land, const tcr_grid *bg, const double *bathy)
 {
     if (!ctx) return -1;
@@ -912,21 +1003,66 @@ int tcr_static_upload2(tcr_ctx *ctx, const tcr_grid *lg, const double *land, con
     if (ctx->hg.set && shared == ctx->split_static)
         return fail(ctx, "static fields were staged %s before; a context keeps one arrangement", ctx->split_static ? "on two grids" : "on one grid");
     if (stage_grid(ctx, ctx->hg, lg, shared ? "static" : "land")) return -1;
-    const size_t np = (size_t)lg->nlon * lg->nlat;
-    if (shared) {
+    if (!shared && stage_grid(ctx, ctx->bg, bg, "bathymetry")) return -1;
+    const size_t np = (size_t)lg->nlon * lg->nlat, nb = (size_t)bg->nlon * bg->nlat;
+    // Exact narrow storage where the VALUES allow it (the reference's land.nc is int8 0 / 1 on a 0.125-degree grid,
+    // intensity/geo.py:23-34; bathymetry products are whole metres or float32): the kernels widen to the same doubles, so
+    // nothing downstream — the `land == 1` decision included — can tell the difference.
+    bool land01 = true, land_u8 = true, bathy_i15 = true, bathy_f32 = true;
+    for (size_t i = 0; i < np && land_u8; ++i) {
+        const double v = land[i];
+        if (!(v >= 0.0 && v <= 255.0 && v == (double)(int)v)) land_u8 = false;
+        if (v != 0.0 && v != 1.0) land01 = false;
+    }
+    for (size_t i = 0; i < nb && bathy_f32; ++i) {
+        const double v = bathy[i];
+        if (!((double)(float)v == v)) bathy_f32 = false;                  // (a NaN keeps the fp64 planes)
+        if (!(v >= -(double)kPack16Bias && v < (double)kPack16Bias && v == (double)(int)v)) bathy_i15 = false;
+    }
+    int mode = shared ? kStatF64 : kStatF64Split;
+    if (ctx->static_pref == 0) {
+        if (shared && land_u8 && land01 && bathy_f32 && bathy_i15) mode = kStatPack16;
+        else if (land_u8 && bathy_f32) mode = kStatU8F32;
+    }
+    // a context may be re-staged with other planes (another mode, even): start from nothing
+    for (void **q : {reinterpret_cast<void **>(&ctx->d_stat), reinterpret_cast<void **>(&ctx->d_land), reinterpret_cast<void **>(&ctx->d_bathy),
+                     reinterpret_cast<void **>(&ctx->d_stat32), reinterpret_cast<void **>(&ctx->d_land32), reinterpret_cast<void **>(&ctx->d_bathy32),
+                     &ctx->d_nstat, reinterpret_cast<void **>(&ctx->d_nbathy)}) {
+        if (*q) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(*q)); *q = nullptr; ++ctx->epoch; }
+    }
+    if (mode == kStatPack16) {
+        std::vector<uint16_t> h(np + 8, 0);
+        for (size_t i = 0; i < np; ++i) h[i] = (uint16_t)((((int)bathy[i] + kPack16Bias) << 1) | (int)land[i]);
+        uint16_t *d = nullptr;
+        if (dev_alloc(ctx, &d, h.size())) return -1;
+        ctx->d_nstat = d;
+        HIPCHK(ctx, copy_sync(ctx->stream, d, h.data(), sizeof(uint16_t) * h.size(), hipMemcpyHostToDevice));
+        ctx->static_bytes = sizeof(uint16_t) * np;
+    } else if (mode == kStatU8F32) {
+        std::vector<uint8_t> hl(np + 8, 0);
+        std::vector<float> hb(nb + 4, 0.f);
+        for (size_t i = 0; i < np; ++i) hl[i] = (uint8_t)(int)land[i];
+        for (size_t i = 0; i < nb; ++i) hb[i] = (float)bathy[i];
+        uint8_t *d = nullptr;
+        if (dev_alloc(ctx, &d, hl.size()) || dev_alloc(ctx, &ctx->d_nbathy, hb.size())) return -1;
+        ctx->d_nstat = d;
+        HIPCHK(ctx, copy_sync(ctx->stream, d, hl.data(), hl.size(), hipMemcpyHostToDevice));
+        HIPCHK(ctx, copy_sync(ctx->stream, ctx->d_nbathy, hb.data(), sizeof(float) * hb.size(), hipMemcpyHostToDevice));
+        ctx->static_bytes = np + sizeof(float) * nb;
+    } else if (shared) {
         std::vector<double> h(np * kStaticStride);
         for (size_t i = 0; i < np; ++i) { h[i * 2] = land[i]; h[i * 2 + 1] = bathy[i]; }
-        if (!ctx->d_stat && dev_alloc(ctx, &ctx->d_stat, h.size())) return -1;
+        if (dev_alloc(ctx, &ctx->d_stat, h.size())) return -1;
         HIPCHK(ctx, copy_sync(ctx->stream, ctx->d_stat, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+        ctx->static_bytes = sizeof(double) * h.size();
     } else {
-        if (stage_grid(ctx, ctx->bg, bg, "bathymetry")) return -1;
-        const size_t nb = (size_t)bg->nlon * bg->nlat;
-        if (!ctx->d_land && dev_alloc(ctx, &ctx->d_land, np)) return -1;
-        if (!ctx->d_bathy && dev_alloc(ctx, &ctx->d_bathy, nb)) return -1;
+        if (dev_alloc(ctx, &ctx->d_land, np) || dev_alloc(ctx, &ctx->d_bathy, nb)) return -1;
         HIPCHK(ctx, copy_sync(ctx->stream, ctx->d_land, land, sizeof(double) * np, hipMemcpyHostToDevice));
         HIPCHK(ctx, copy_sync(ctx->stream, ctx->d_bathy, bathy, sizeof(double) * nb, hipMemcpyHostToDevice));
-        ctx->split_static = true;
+        ctx->static_bytes = sizeof(double) * (np + nb);
     }
+    ctx->split_static = !shared;
+    ctx->static_mode = mode;
     ctx->stat32_stale = true;
     return 0;
 }
@@ -1376,14 +1512,17 @@ int tcr_probe_rhs_host(tcr_ctx *ctx, int slot, double h_bl, const double *Fs, in
     const DevFields DF = dev_fields(ctx);
     EvalK EK{};
     bool affine = false;
-    host_eval_k<double>(ctx, EK, &affine);
+    if (eval_k_ready<double>(ctx, EK, &affine, ctx->stream)) return -1;
     const dim3 grid((unsigned)((n + 63) / 64)), block(64);
 #define PROBE_RHS(A, S) hipLaunchKernelGGL((k_probe_rhs<A, S>), grid, block, 0, ctx->stream, ctx->prm, DF, EK, slot, h_bl, \
                                            d_fs, n, d_t, d_lon, d_lat, d_v, d_m, d_dy, d_w, d_al)
-    if (affine && !ctx->split_static) PROBE_RHS(true, false);
-    else if (!affine && !ctx->split_static) PROBE_RHS(false, false);
-    else if (affine) PROBE_RHS(true, true);
-    else PROBE_RHS(false, true);
+    const int sm = ctx->static_mode;
+    if (affine && sm == kStatPack16) PROBE_RHS(true, kStatPack16);
+    else if (affine && sm == kStatU8F32) PROBE_RHS(true, kStatU8F32);
+    else if (affine && sm == kStatF64) PROBE_RHS(true, kStatF64);
+    else if (affine) PROBE_RHS(true, kStatF64Split);
+    else if (sm == kStatF64) PROBE_RHS(false, kStatF64);
+    else PROBE_RHS(false, kStatF64Split);
 #undef PROBE_RHS
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1400,14 +1539,17 @@ int init_m_launch(tcr_ctx *ctx, const tcr_storms *in, double dvdt, double *m_out
     const DevFields DF = dev_fields(ctx);
     EvalK EK{};
     bool affine = false;
-    host_eval_k<double>(ctx, EK, &affine);
+    if (eval_k_ready<double>(ctx, EK, &affine, st)) return -1;
     const dim3 grid((unsigned)((in->n + 63) / 64)), block(64);
 #define INIT_M(A, S) hipLaunchKernelGGL((k_init_m<A, S>), grid, block, 0, st, ctx->prm, DF, EK, in->n, in->n_dev, in->lon0, in->lat0, \
                                         in->v0, in->m0, in->h_bl, in->slot, in->phases, dvdt, m_out)
-    if (affine && !ctx->split_static) INIT_M(true, false);
-    else if (!affine && !ctx->split_static) INIT_M(false, false);
-    else if (affine) INIT_M(true, true);
-    else INIT_M(false, true);
+    const int sm = ctx->static_mode;
+    if (affine && sm == kStatPack16) INIT_M(true, kStatPack16);
+    else if (affine && sm == kStatU8F32) INIT_M(true, kStatU8F32);
+    else if (affine && sm == kStatF64) INIT_M(true, kStatF64);
+    else if (affine) INIT_M(true, kStatF64Split);
+    else if (sm == kStatF64) INIT_M(false, kStatF64);
+    else INIT_M(false, kStatF64Split);
 #undef INIT_M
     HIPCHK(ctx, hipGetLastError());
     return 0;

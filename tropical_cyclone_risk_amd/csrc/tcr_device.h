@@ -39,6 +39,8 @@ constexpr double kPi = 3.141592653589793;
 constexpr int kWindStride = 16;     // 14 fields + 2 pad  -> one 128-B (fp64) / 64-B (fp32) line per grid point
 constexpr int kThermoStride = 4;    // vpot, chi, mld, strat
 constexpr int kStaticStride = 2;    // land, bathy
+enum StaticMode { kStatF64 = 0, kStatF64Split = 1, kStatPack16 = 2, kStatU8F32 = 3 };
+constexpr int kPack16Bias = 16384;  // kStatPack16: stored = (bathymetry + bias) * 2 + land
 constexpr int kStepHdr = 4;         // accepted-step record: doubles t_old, h, t_new, - ; then R y_old[4], K[7][4]
 constexpr int kStepBody = 32;
 
@@ -92,12 +94,20 @@ struct DevFields {
 template <typename R>
 struct EvalKT {
     AxisT<R> wx, wy, tx, ty, hx, hy;
-    // land and bathymetry are two independent interpolators in the reference (intensity/geo.py:9-34).  On one grid
-    // (what the reference ships: both 0.25 degree) they are staged interleaved, `stat` = [lat][lon][2], one gather;
-    // on different grids (SPLIT instantiations) `stat` is the land plane on (hx, hy) and `bathy` its own plane on (bx, by)
+    // land and bathymetry are two independent interpolators in the reference (intensity/geo.py:9-34).  How they are stored
+    // is the kernels' static mode SM (StaticLookup below):
+    //   kStatF64      one grid, `stat` = [lat][lon][2] R (land, bathymetry interleaved), one 16-byte gather per corner;
+    //   kStatF64Split `stat` = the land plane (R) on (hx, hy), `bathy` its own plane (R) on (bx, by);
+    //   kStatPack16   one grid, `stat` = [lat][lon] uint16 = ((int)bathymetry + 16384) * 2 + land: exact when land is 0 / 1 and
+    //                 the bathymetry is whole metres in [-16384, 16383] (ETOPO / GEBCO); the two lon-adjacent corners of a
+    //                 row are ONE 4-byte gather;
+    //   kStatU8F32    `stat` = the land plane as uint8 (values 0 .. 255, the reference's int8 land.nc) on (hx, hy), `bathy` a
+    //                 float plane on (bx, by) (exact when every value round-trips through float32); a row's two corners are
+    //                 one 2-byte and one 8-byte gather.
+    // The narrow forms hold exactly the values the fp64 planes would: the kernels widen them to R before FITPACK's arithmetic.
     AxisT<R> bx, by;
-    const R *stat;
-    const R *bathy;
+    const void *stat;
+    const void *bathy;
     R earth_R, Ck, epsilon, kappa, u_beta, v_beta;
     R y_alpha[2], m_alpha[2], alpha_max[2], alpha_min[2], steering_coefs[2];
     double total_time, tstep, inv_tstep;        // time stays fp64 in both instantiations
@@ -461,30 +471,85 @@ __device__ __forceinline__ void rhs_tail(const EvalKT<R> &K, R h_bl, R lat, R v,
     rhs_intensity<R>(K, h_bl, lat, v, m, th, lb, mid, r);
 }
 
-// land and bathymetry at (lon, lat): one interleaved gather, or (SPLIT) two planes on their own grids
-template <typename R, bool AFFINE, bool SPLIT>
+// loads of 2 / 4 / 8 bytes at the natural alignment of the *element* (1 / 2 / 4 bytes), i.e. possibly straddling the
+// load's own size: gfx950 under HSA runs with unaligned global access enabled, and the compiler (unaligned-access-mode)
+// emits one global_load_ushort / _dword / _dwordx2 for them
+__device__ __forceinline__ uint32_t ldg_u16x1_pair_u8(const uint8_t *p)
+{
+    typedef uint16_t u16_a1 __attribute__((aligned(1)));
+    return *(const __attribute__((address_space(1))) u16_a1 *)(p);
+}
+__device__ __forceinline__ uint32_t ldg_u32_pair_u16(const uint16_t *p)
+{
+    typedef uint32_t u32_a2 __attribute__((aligned(2)));
+    return *(const __attribute__((address_space(1))) u32_a2 *)(p);
+}
+__device__ __forceinline__ float2 ldg_pair_f32(const float *p)
+{
+    typedef float f2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+    const f2_a4 v = *(const __attribute__((address_space(1))) f2_a4 *)(p);
+    return make_float2(v[0], v[1]);
+}
+
+// bilinear sum of four corner values in fpbisp.f's order (the body of blend for one field)
+template <typename R>
+__device__ __forceinline__ R blend4(R a, R b, R c, R d, const CellT<R> &cx, const CellT<R> &cy)
+{
+    R sp = R(0.0);
+    sp = sp + a * cx.w0 * cy.w0;
+    sp = sp + b * cx.w0 * cy.w1;
+    sp = sp + c * cx.w1 * cy.w0;
+    sp = sp + d * cx.w1 * cy.w1;
+    return sp;
+}
+
+// land and bathymetry at (lon, lat) in the storage of static mode SM (EvalKT): the gathers are issued by issue(), the values
+// — widened to R, then blended in FITPACK's order — come out of finish()
+template <typename R, bool AFFINE, int SM>
 struct StaticLookup {
     CellT<R> hx, hy, bx, by;
-    CornersT<R, 2, Widths<R>::H> CH;        // !SPLIT: (land, bathy) pairs
-    CornersT<R, 1, 1> CL, CB;               // SPLIT
+    CornersT<R, 2, Widths<R>::H> CH;        // kStatF64: (land, bathy) pairs
+    CornersT<R, 1, 1> CL, CB;               // kStatF64Split
+    uint32_t p0, p1;                        // kStatPack16: rows y0 / y1, elements (x0, x1); kStatU8F32: the land bytes likewise
+    float2 b0, b1;                          // kStatU8F32: bathymetry rows y0 / y1
     __device__ __forceinline__ void issue(const EvalKT<R> &K, R lon, R lat)
     {
         hx = locate_t<R, AFFINE>(K.hx, lon); hy = locate_t<R, AFFINE>(K.hy, lat);
-        if (SPLIT) {
+        if (SM == kStatF64Split) {
             bx = locate_t<R, AFFINE>(K.bx, lon); by = locate_t<R, AFFINE>(K.by, lat);
-            gather<R, 1, 1, 1>(RD(K.stat), RD(K.hx.n), hx, hy, CL);
-            gather<R, 1, 1, 1>(RD(K.bathy), RD(K.bx.n), bx, by, CB);
+            gather<R, 1, 1, 1>(reinterpret_cast<const R *>(RD(K.stat)), RD(K.hx.n), hx, hy, CL);
+            gather<R, 1, 1, 1>(reinterpret_cast<const R *>(RD(K.bathy)), RD(K.bx.n), bx, by, CB);
+        } else if (SM == kStatPack16) {
+            const int nl = RD(K.hx.n);
+            const uint16_t *q = reinterpret_cast<const uint16_t *>(RD(K.stat)) + ((size_t)hy.i * nl + hx.i);
+            p0 = ldg_u32_pair_u16(q); p1 = ldg_u32_pair_u16(q + nl);
+        } else if (SM == kStatU8F32) {
+            bx = locate_t<R, AFFINE>(K.bx, lon); by = locate_t<R, AFFINE>(K.by, lat);
+            const int nl = RD(K.hx.n), nb = RD(K.bx.n);
+            const uint8_t *q = reinterpret_cast<const uint8_t *>(RD(K.stat)) + ((size_t)hy.i * nl + hx.i);
+            const float *f = reinterpret_cast<const float *>(RD(K.bathy)) + ((size_t)by.i * nb + bx.i);
+            p0 = ldg_u16x1_pair_u8(q); p1 = ldg_u16x1_pair_u8(q + nl);
+            b0 = ldg_pair_f32(f); b1 = ldg_pair_f32(f + nb);
         } else {
-            gather<R, 2, kStaticStride, Widths<R>::H>(RD(K.stat), RD(K.hx.n), hx, hy, CH);
+            gather<R, 2, kStaticStride, Widths<R>::H>(reinterpret_cast<const R *>(RD(K.stat)), RD(K.hx.n), hx, hy, CH);
         }
     }
     __device__ __forceinline__ void finish(R (&lb)[2]) const
     {
-        if (SPLIT) {
+        if (SM == kStatF64Split) {
             R a[1], b[1];
             blend<R, 1, 1>(CL, hx, hy, a);
             blend<R, 1, 1>(CB, bx, by, b);
             lb[0] = a[0]; lb[1] = b[0];
+        } else if (SM == kStatPack16) {
+            // corners (x0,y0) = low half of row y0, (x1,y0) = its high half; land = bit 0, bathymetry = the rest minus the bias
+            const uint32_t c00 = p0 & 0xffffu, c10 = p0 >> 16, c01 = p1 & 0xffffu, c11 = p1 >> 16;
+            lb[0] = blend4<R>((R)(int)(c00 & 1u), (R)(int)(c01 & 1u), (R)(int)(c10 & 1u), (R)(int)(c11 & 1u), hx, hy);
+            lb[1] = blend4<R>((R)((int)(c00 >> 1) - kPack16Bias), (R)((int)(c01 >> 1) - kPack16Bias),
+                              (R)((int)(c10 >> 1) - kPack16Bias), (R)((int)(c11 >> 1) - kPack16Bias), hx, hy);
+        } else if (SM == kStatU8F32) {
+            lb[0] = blend4<R>((R)(int)(p0 & 0xffu), (R)(int)(p1 & 0xffu), (R)(int)((p0 >> 8) & 0xffu), (R)(int)((p1 >> 8) & 0xffu), hx, hy);
+            lb[1] = blend4<R>((R)b0.x, (R)b1.x, (R)b0.y, (R)b1.y, bx, by);
         } else {
             blend<R, 2, Widths<R>::H>(CH, hx, hy, lb);
         }
@@ -494,7 +559,7 @@ struct StaticLookup {
 // fun(t, y) = Coupled_FAST.dydt (coupled_fast.py:196-207): _calc_steering_coefs (:183-192),
 // _step_bam_track (bam_track.py:131-144) on _env_winds (:116-128), _dvdt (:141-150) with
 // _get_current_vpot (:54-58), _calc_alpha/_calc_z (:65-94), _dmdt (:175-180).
-template <typename R, bool AFFINE, bool SPLIT>
+template <typename R, bool AFFINE, int SM>
 __device__ __forceinline__ RhsT<R> rhs_eval(const EvalKT<R> &K, const R *__restrict__ wind, const R *__restrict__ thermo,
                                             const R *__restrict__ fs, R h_bl, double t, R lon, R lat, R v, R m)
 {
@@ -507,7 +572,7 @@ __device__ __forceinline__ RhsT<R> rhs_eval(const EvalKT<R> &K, const R *__restr
     // ---- one round of independent gathers
     CornersT<R, 14, Wd::W> CW;
     CornersT<R, 4, Wd::T> CT;
-    StaticLookup<R, AFFINE, SPLIT> SL;
+    StaticLookup<R, AFFINE, SM> SL;
     FsPairT<R> fp;
     gather<R, 14, kWindStride, Wd::W>(wind, RD(K.wx.n), wx, wy, CW);
     fs_gather<R>(fs, fb, fp);
@@ -546,14 +611,14 @@ template <typename R> __device__ __forceinline__ void cache_reset(CornerCacheT<R
 //              static corners to their bilinear values, so the load registers are free for the next issue;
 //   intensity  dv/dt, dm/dt — runs in the shadow of the next point's gathers.
 // The operations and their order per value are those of rhs_eval; only independent work is reordered.
-template <typename R, bool AFFINE, bool SPLIT>
+template <typename R, bool AFFINE, int SM>
 struct RhsPipeT {
     typedef Widths<R> Wd;
     CellT<R> wx, wy, tx, ty;
     FsBracket fb;
     FsPairT<R> fp;
     CornersT<R, 4, Wd::T> CT;
-    StaticLookup<R, AFFINE, SPLIT> SL;
+    StaticLookup<R, AFFINE, SM> SL;
 
     __device__ __forceinline__ void issue(CornerCacheT<R> &C, const EvalKT<R> &K, const R *__restrict__ wind,
                                           const R *__restrict__ thermo, const R *__restrict__ fs, double t, R lon, R lat)

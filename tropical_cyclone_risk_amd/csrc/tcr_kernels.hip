@@ -547,7 +547,7 @@ template <typename R> constexpr int int_wps() { return sizeof(R) == 8 ? TCR_INT_
 // *time* (t, h, t_new, the stage times, the output grid) and the step-size controller: the error norm
 // is accumulated in fp64 from the fp32 stage derivatives, and err < 1, the factor 0.9 err^-0.2 and the
 // min-step test are the fp64 expressions of the fp64 build (every (double) cast below is the identity there).
-template <typename R, bool AFFINE, bool PROBE, bool SPLIT>
+template <typename R, bool AFFINE, bool PROBE, int SM>
 __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate(KArgsT<R> a)
 {
     // Kl[(stage*4 + component)*64 + lane]
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
     R g = R(0.0);
     CornerCacheT<R> CC;
     cache_reset(CC);
-    RhsPipeT<R, AFFINE, SPLIT> PIPE;
+    RhsPipeT<R, AFFINE, SM> PIPE;
     bool pre = false;                       // the gathers of the point (e, et) are already in flight
     double etn = 0;
 
@@ -1458,7 +1458,7 @@ __global__ __launch_bounds__(256) void k_flags(tcr_params P, int64_t n_storms, c
 // Coupled_FAST._init_m(y, dvdt) (intensity/coupled_fast.py:153-173): the inner-core moisture gen_track(m=None) starts
 // from (:258-261, dvdt = 0) — the m that makes dv/dt equal `dvdt` at t = 0, with PI taken as the maximum over the
 // point and the four points 0.25 degrees diagonally off it.  One thread per storm; storms whose m0 is a number keep it.
-template <bool AFFINE, bool SPLIT>
+template <bool AFFINE, int SM>
 __global__ __launch_bounds__(64) void k_init_m(tcr_params P, DevFields D, EvalK K_host, int64_t n, const int64_t *__restrict__ n_dev,
                                                const double *__restrict__ lon0, const double *__restrict__ lat0,
                                                const double *__restrict__ v0, const double *__restrict__ m0,
@@ -1503,7 +1503,7 @@ __global__ __launch_bounds__(64) void k_init_m(tcr_params P, DevFields D, EvalK 
     }
     // _get_current_vpot at a point (coupled_fast.py:35-58)
     auto vpot_at = [&](double x, double y) {
-        StaticLookup<double, AFFINE, SPLIT> SL;
+        StaticLookup<double, AFFINE, SM> SL;
         SL.issue(K, x, y);
         const Cell tx = locate_t<double, AFFINE>(K.tx, x), ty = locate_t<double, AFFINE>(K.ty, y);
         CornersT<double, 4, 2> CT;
@@ -1523,7 +1523,7 @@ __global__ __launch_bounds__(64) void k_init_m(tcr_params P, DevFields D, EvalK 
     // alpha = _calc_alpha(lon, lat, v_bam, v) (coupled_fast.py:65-94): the intensity half of the RHS has it
     double th[4], lb[2];
     {
-        StaticLookup<double, AFFINE, SPLIT> SL;
+        StaticLookup<double, AFFINE, SM> SL;
         SL.issue(K, lon, lat);
         const Cell tx = locate_t<double, AFFINE>(K.tx, lon), ty = locate_t<double, AFFINE>(K.ty, lat);
         CornersT<double, 4, 2> CT;
@@ -1541,7 +1541,7 @@ __global__ __launch_bounds__(64) void k_init_m(tcr_params P, DevFields D, EvalK 
     m_out[i] = np_max(np_min(c, 1.0), 0.0);
 }
 
-template <bool AFFINE, bool SPLIT>
+template <bool AFFINE, int SM>
 __global__ __launch_bounds__(64) void k_probe_rhs(tcr_params P, DevFields D, EvalK K_host, int slot, double h_bl, const double *fs,
                             int64_t n, const double *t, const double *lon, const double *lat,
                             const double *v, const double *m, double *dydt, double *envw, double *alpha)
@@ -1552,7 +1552,7 @@ __global__ __launch_bounds__(64) void k_probe_rhs(tcr_params P, DevFields D, Eva
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const DevSlot S = D.slots[slot];
-    const RhsT<double> r = rhs_eval<double, AFFINE, SPLIT>(K, S.wind, S.thermo, fs, h_bl, t[i], lon[i], lat[i], v[i], m[i]);
+    const RhsT<double> r = rhs_eval<double, AFFINE, SM>(K, S.wind, S.thermo, fs, h_bl, t[i], lon[i], lat[i], v[i], m[i]);
     for (int k = 0; k < 4; ++k) dydt[i * 4 + k] = r.d[k];
     alpha[i] = r.alpha;
     double w[4];

@@ -97,10 +97,10 @@ class TCEngine:
         if rc != 0:
             raise _lib.TcrError(self.L.tcr_last_error(self.h).decode())
 
-    def grow_step_record(self, limit=1024):
+    def grow_step_record(self, limit=4096):
         """Double tcr_params.max_rk_steps (accepted RK45 steps recorded per storm; the workspaces — n x max_rk_steps x
-        ~400 B — follow at the next integrate).  Returns False when `limit` is reached (the ABI takes up to 4096; no storm of
-        the 40-year config 3 needs more than 128).  The value persists for the engine's later rounds and years."""
+        ~400 B — follow at the next integrate).  Returns False when `limit` (the ABI's 4096; the reference's solve_ivp is unbounded;
+        no storm of the 40-year config 3 needs more than 128; `compute.GpuRound.grow` stops earlier when HBM would not hold it) is reached.  The value persists for the engine's later rounds and years."""
         cur = int(self.params.max_rk_steps) or 64
         if cur >= limit:
             return False
@@ -132,8 +132,18 @@ class TCEngine:
         lo, la, land_b = self.basin.transform_global_field(hlon, hlat, land)
         blo, bla, bathy_b = self.basin.transform_global_field(hlon if blon is None else blon, hlat if blat is None else blat, bathy)
         g, gb = self._grid(lo, la), self._grid(blo, bla)
+        # (the reference passes whatever dtype the files hold — its land.nc is int8 — to RectBivariateSpline, which computes
+        # in float64; the library decides from the values whether a narrow storage is exact: tcr_static_store)
         land_b, bathy_b = _f64(land_b), _f64(bathy_b)
+        self._ck(self.L.tcr_static_store(self.h, 1 if str(getattr(self.nl, 'gpu_static_store', 'auto')) == 'f64' else 0))
         self._ck(self.L.tcr_static_upload2(self.h, C.byref(g), _dp(land_b), C.byref(gb), _dp(bathy_b)))
+        self._staged_static = None          # (stage_env's identity shortcut: whatever it remembered is no longer what is staged)
+
+    def static_info(self):
+        """(storage mode, bytes) of the staged land / bathymetry planes: 'f64' | 'f64_split' | 'pack16' | 'u8_f32'."""
+        m, b = C.c_int32(0), C.c_int64(0)
+        self._ck(self.L.tcr_static_info(self.h, C.byref(m), C.byref(b)))
+        return _lib.STATIC_MODES[m.value], int(b.value)
 
     def stage_month(self, slot, wlon, wlat, wnd_mean, wnd_cov, lon, lat, vpot, chi, mld, strat, rh_mid=None):
         """One month's field set: `_load_wnd_stat` (bam_track.py:76-91) + `init_fields`
@@ -165,6 +175,7 @@ class TCEngine:
         g = self._grid(mlon, mlat)
         arr = (_lib.U8P * 7)(*[m.ctypes.data_as(_lib.U8P) for m in ms])
         self._ck(self.L.tcr_masks_upload(self.h, C.byref(g), run.ctypes.data_as(_lib.U8P), arr))
+        self._staged_masks = None
 
     def stage_env(self, env, months=range(12)):
         """Stage a ``synthetic.SyntheticEnv``-shaped object (12 monthly field sets).  The static planes (land, bathymetry,
@@ -179,7 +190,8 @@ class TCEngine:
             self.stage_month(mo, env.wlon, env.wlat, env.wnd_mean[mo], env.wnd_cov[mo], env.lon, env.lat,
                              env.vpot[mo], env.chi[mo], env.mld[mo], env.strat[mo], env.rh_mid[mo])
         if getattr(env, 'basin_masks', None):
-            masks = (getattr(env, 'mlon', env.hlon), getattr(env, 'mlat', env.hlat), env.basin_masks[self.basin.basin_id], env.basin_masks)
+            mlon, mlat = getattr(env, 'mlon', None), getattr(env, 'mlat', None)
+            masks = (env.hlon if mlon is None else mlon, env.hlat if mlat is None else mlat, env.basin_masks[self.basin.basin_id], env.basin_masks)
             staged = getattr(self, '_staged_masks', None)
             if not (self._same(staged and staged[:3], masks[:3]) and all(masks[3][b] is staged[3][b] for b in BASIN_IDS)):
                 self.stage_masks(*masks)

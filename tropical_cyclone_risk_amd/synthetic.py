@@ -78,13 +78,16 @@ class SyntheticEnv:
     rh_mid: np.ndarray
     hlon: np.ndarray
     hlat: np.ndarray
-    land: np.ndarray          # [721, 1440] 0/1 float64
-    bathy: np.ndarray         # [721, 1440] metres, >0 over land
-    basin_masks: dict = field(default_factory=dict)   # id -> [721,1440] float64 0/1
+    land: np.ndarray          # [721, 1440] 0/1 float64 (static_res 0.125: [1440, 2880] int8, the reference's land.nc)
+    bathy: np.ndarray         # same grid, metres, >0 over land
+    basin_masks: dict = field(default_factory=dict)   # id -> [721,1440] float64 0/1 (always the 0.25 degree mask grid)
     seed: int = 0
     shape: str = 'era5'
     blon: np.ndarray = None   # the bathymetry's own grid when it differs from the land mask's (intensity/geo.py:9-34)
     blat: np.ndarray = None
+    mlon: np.ndarray = None   # the basin masks' grid (scripts/generate_land_masks.py:24-25: always 0.25 degree) when it
+    mlat: np.ndarray = None   # differs from the land mask's
+    static_res: float = 0.25
 
     def cov_matrix(self, month):
         """Dense symmetric [4,4,nlat,nlon] view of one month's covariances."""
@@ -125,8 +128,15 @@ def make_basin_masks(hlon, hlat, land):
     return {k: v.astype(np.float64) for k, v in m.items()}
 
 
-def make_env(shape='era5', seed=20250614, wind_scale=0.7, zero_cov_patch=False):
+def make_env(shape='era5', seed=20250614, wind_scale=0.7, zero_cov_patch=False, static_res=0.25, bathy_kind=None):
     """Build the 12-month synthetic environment.
+
+    static_res: 0.25 (land / bathymetry on the 721 x 1440 grid of the basin masks, float64 — what every
+           golden fixture was generated on) or 0.125: the grid and type of the file the reference actually ships,
+           `intensity/data/land.nc` — int8 land on lon 0 .. 359.875 (2880), lat -89.875 .. 90 (1440) (intensity/geo.py:23-34).
+           The basin masks stay on their own 0.25 degree grid (scripts/generate_land_masks.py:24-25) as `mlon` / `mlat`.
+    bathy_kind: what the (absent) `bathymetry.nc` is taken to hold — 'i16' whole metres (ETOPO / GEBCO style; default at
+           0.125), 'f32' float32 values, 'f64' the continuous analytic depth (default at 0.25).
 
     shape: 'era5' (wind grid == thermo grid 181x360) or 'gfdl' (wind 90x144 on
            2°x2.5°, thermo 180x288 on 1°x1.25°).
@@ -149,8 +159,16 @@ def make_env(shape='era5', seed=20250614, wind_scale=0.7, zero_cov_patch=False):
             wlat = wlat + 0.35 * np.sin(np.deg2rad(wlat) * 3.0)
     else:
         raise ValueError('unknown synthetic shape %r' % (shape,))
-    hlat = np.linspace(-90.0, 90.0, 721)
-    hlon = np.linspace(0.0, 360.0, 1441)[:-1]
+    mlat = np.linspace(-90.0, 90.0, 721)
+    mlon = np.linspace(0.0, 360.0, 1441)[:-1]
+    if static_res == 0.25:
+        hlat, hlon = mlat, mlon
+    elif static_res == 0.125:
+        hlat = -89.875 + 0.125 * np.arange(1440)          # land.nc: float32 axes, exact multiples of 1/8
+        hlon = 0.125 * np.arange(2880)
+    else:
+        raise ValueError('static_res must be 0.25 or 0.125')
+    bathy_kind = bathy_kind or ('f64' if static_res == 0.25 else 'i16')
 
     # a handful of random phases/amplitudes make each seed a different climate
     ph = rng.uniform(0, 2 * np.pi, size=32)
@@ -158,10 +176,16 @@ def make_env(shape='era5', seed=20250614, wind_scale=0.7, zero_cov_patch=False):
 
     # ---- high-resolution land / bathymetry ---------------------------------
     g = _continent_index(hlon, hlat)
-    land = (g > 0).astype(np.float64)
+    land = (g > 0).astype(np.float64 if static_res == 0.25 else np.int8)
     depth = 4000.0 * np.clip(-g / 0.30, 0.0, 1.0) ** 1.5
     bathy = np.where(g > 0, 300.0 * g + 1.0, -depth)
-    basin_masks = make_basin_masks(hlon, hlat, land)
+    if bathy_kind == 'i16':
+        bathy = np.round(bathy).astype(np.int16)
+    elif bathy_kind == 'f32':
+        bathy = bathy.astype(np.float32)
+    elif bathy_kind != 'f64':
+        raise ValueError('bathy_kind must be i16, f32 or f64')
+    basin_masks = make_basin_masks(mlon, mlat, land if static_res == 0.25 else (_continent_index(mlon, mlat) > 0).astype(np.float64))
 
     # ---- thermo grid -------------------------------------------------------
     gt = _continent_index(lon, lat)
@@ -220,7 +244,8 @@ def make_env(shape='era5', seed=20250614, wind_scale=0.7, zero_cov_patch=False):
                         wnd_mean=wnd_mean, wnd_cov=wnd_cov, vpot=vpot, chi=chi,
                         mld=mld, strat=strat, rh_mid=rh, hlon=hlon, hlat=hlat,
                         land=land, bathy=bathy, basin_masks=basin_masks,
-                        seed=seed, shape=shape)
+                        seed=seed, shape=shape, static_res=static_res,
+                        mlon=None if static_res == 0.25 else mlon, mlat=None if static_res == 0.25 else mlat)
 
 
 def draw_storm_inputs(n, basin, seed, env=None):
