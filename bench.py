@@ -90,6 +90,14 @@ def main():
                     help="tc: env winds / vmax / rows only for storms that pass accept test 1, as the reference does "
                          "(compute.py:190-204); all: rows for every integrated storm (round 1's workload)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit('bench.py: --gpus must be >= 1')
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
+    if env_world is not None and int(env_world) != args.gpus:
+        # never report a rank count other than the one asked for (`--gpus 8` without a launcher printed n_gpus 1)
+        sys.exit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks' % (args.gpus, env_world))
     # A batch is latency-bound by its longest storm (~300 sequential evaluations, ~2 ms), so throughput comes from batches
     # in flight.  ROCm multiplexes a process's streams onto GPU_MAX_HW_QUEUES = 4 hardware queues by default; the small
     # per-rank batches of a sharded ensemble need more of them in flight than that (measured on one MI355X, 12 500 storms
@@ -111,8 +119,7 @@ def main():
     from tropical_cyclone_risk_amd.pipeline import DevicePipeline
 
     rank, world, local = D.init_from_env()
-    if world != args.gpus and rank == 0:
-        print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world), file=sys.stderr)
+    assert world == args.gpus
     local = D.local_device(local)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -165,7 +172,7 @@ def main():
     # nothing in a step waits on the host — batch k's count is read back only when batch k + n_str is
     # issued, and only then is its row all-gather launched on RCCL's stream, n_str batches behind compute.
     cap = max(1024, int(0.2 * B))               # accepted fraction is ~6 %
-    gather = D.DeferredRowGather(cap, row, dev, lag=n_str) if world > 1 else None
+    gather = D.DeferredRowGather(cap, row, dev, lag=n_str) if D.collective() else None
 
     def step(k):
         with torch.cuda.stream(streams[k % n_str]):
@@ -222,6 +229,7 @@ def main():
     torch.cuda.synchronize(); D.barrier()
     dt = time.perf_counter() - t0
     dt = D.max_over_ranks(dt, dev)
+    rows_gathered, rows_clipped = (gather.rows_gathered, gather.rows_clipped) if gather is not None else (None, None)
 
     def sum_timings():
         tot = dict(fourier_ms=0.0, integrate_ms=0.0, post_ms=0.0, calls=0)
@@ -260,12 +268,13 @@ def main():
             with torch.cuda.stream(streams[0]):
                 _step(k, pipes[0], graph=False)          # direct enqueue: the library's timing events are recorded
             torch.cuda.synchronize()
+        drain()                                          # (nothing of the isolated batches stays in flight in the collective backend)
+        torch.cuda.synchronize()
         iso = sum_timings()
         iso_counts = (acc - acc_keep).tolist()
         acc.copy_(acc_keep)
         iso_passes = engs[0].pass_stats()
-    if world > 1:
-        D.allreduce_sum_(acc)
+    D.allreduce_sum_(acc)
     (steps_total, nfev_total, samples_total, accepted_total, tc_total, tc_samples_total, n_short, storms_total, n_overflow,
      n_dropped) = (float(x) for x in acc.tolist())
     emitted_total = tc_samples_total if args.rows == 'tc' else samples_total     # samples k_emit actually produced
@@ -365,10 +374,16 @@ def main():
             lane_utilisation=sum(p['lane_cycles'] for ps in pipe_passes for p in ps) / max(1, 64 * sum(p['wave_cycles'] for ps in pipe_passes for p in ps)),
             note='wave residency of the k_integrate passes of the last timed batch of every stream / SIMDs')
     out = None
+    backend = D.backend_name()
+    # (the sample of the CPU baseline: the first storms of rank 0's last batch)
+    sample = cpu_sample(pipe, B) if (rank == 0 and not args.no_cpu_baseline) else None
+    if D.collective():
+        D.barrier()
+        torch.distributed.destroy_process_group()
     if rank == 0:
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(pipe, args, B)
+        # rank 0 times the CPU path at every N — after the timed region and after the process group is gone, so that no other
+        # rank waits in a collective meanwhile — and the line is complete in one run
+        cpu = cpu_baseline(sample, args) if sample is not None else None
         out = {
             'metric': 'storm-steps/sec (100k-storm ensemble)', 'value': value, 'unit': 'storm-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -394,21 +409,36 @@ def main():
                        'stage_ms_under_load': stage_ms,
                        'allgather': ('accepted tracks of every %s all-gathered once (26 kB records, backend %s, one collective per step, '
                                      '%d steps behind compute)' % ('ensemble' if strong else 'step',
-                                                                   {'nccl': 'nccl = RCCL'}.get(torch.distributed.get_backend(), torch.distributed.get_backend()),
-                                                                   n_str)) if world > 1 else 'none (one GPU)',
+                                                                   backend, n_str)) if gather is not None else 'none (one GPU)',
+                       'collectives': ('forced through a one-rank process group (TCR_FORCE_COLLECTIVES=1), backend %s' % backend) if (world == 1 and gather is not None)
+                                      else (backend if world > 1 else 'none'),
                        'warmup_effective': w_eff, 'host_issue_ms_per_step': t_issue / args.steps * 1e3,
                        'storm_steps_per_storm': steps_total / storms_total,
                        'rhs_per_storm_step': nfev_total / max(steps_total, 1),
                        'accepted_fraction': accepted_total / storms_total, 'accepted_total': int(accepted_total),
-                       'allgather_rows': gather.rows_gathered if gather is not None else None,
-                       'allgather_rows_clipped': gather.rows_clipped if gather is not None else None},
+                       'allgather_rows': rows_gathered, 'allgather_rows_clipped': rows_clipped},
             'roofline': roof,
             'cpu_baseline': cpu,
         }
         print(json.dumps(out))
-    if world > 1:
-        D.barrier()
-        torch.distributed.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this very command under torch.distributed.run (one per
+    GPU, RCCL) and return its exit code.  Fewer than N GPUs is an error, never a smaller run."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get('TCR_DIST_BACKEND') != 'gloo':      # (gloo: ranks may share a GPU, functional tests)
+        print('bench.py: --gpus %d needs %d GPUs on this node, %d visible; not running a smaller job under that name'
+              % (n, n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def scattered_line_fill_ceiling():
@@ -448,15 +478,20 @@ def measured_traffic(kernel, storms, rows, dtype='f64', order='cells'):
     return None, None
 
 
-def cpu_baseline(pipe, args, B):
-    """Time oracle/scipy_port.py on a bounded sample of the last batch's storms (rank 0, N=1)."""
+def cpu_sample(pipe, B):
+    """The storms the CPU baseline is timed on: the first (at most 16 384) of this rank's last GPU batch, as host arrays."""
     import numpy as np
     n = min(B, 16384)
     s = pipe.storms
-    host = dict(lon=s['lon0'][:n].cpu().numpy(), lat=s['lat0'][:n].cpu().numpy(), v0=s['v0'][:n].cpu().numpy(),
+    return dict(lon=s['lon0'][:n].cpu().numpy(), lat=s['lat0'][:n].cpu().numpy(), v0=s['v0'][:n].cpu().numpy(),
                 m0=s['m0'][:n].cpu().numpy(), h_bl=s['h_bl'][:n].cpu().numpy(),
                 month=(s['slot'][:n].cpu().numpy() + 1).astype(np.int32),
                 phases=s['phases'][:n].cpu().numpy().reshape(n, 4, -1))
+
+
+def cpu_baseline(host, args):
+    """Time oracle/scipy_port.py on a bounded sample of the last batch's storms (rank 0, at every N)."""
+    import numpy as np
     with tempfile.TemporaryDirectory() as d:
         fn = os.path.join(d, 'storms.npz')
         np.savez(fn, **host)

@@ -242,28 +242,30 @@ def replayer(env, basin, storms, prm=None, bounds=None, ensemble=None):
     """Callback for parity.check_tracks: `replay(idx, dec_force)` re-runs storms `idx` with the other
     implementation's decision sequence forced at the rounding-sensitive evaluations.
 
-    `replay.twin_max()` is the yardstick for the far tail of a comparison (parity.check_tracks' bound on EVERY sample):
-    the oracle's own response to one input changed by one ulp (v0 -> nextafter(v0)) on the same storms — per output, the
-    maximum over the storms whose decision sequence and counters stay the same.  Computed on first use, two oracle runs."""
+    `replay.twin_storms(idx)` is the yardstick for the far tail of a comparison (parity.check_tracks' bound on EVERY sample):
+    the oracle's own response ON THOSE STORMS to one input changed by one ulp — three twins (v0 up, v0 down, lon up); per
+    output and storm the maximum over the twins whose decision sequence and counters stay the same (NaN if none does)."""
     ens = ensemble or Ensemble(env, basin, prm, bounds)
 
     def replay(idx, dec_force):
         sub = {k: np.asarray(v)[idx] for k, v in storms.items()}
         return ens.run(sub, post=True, probe=True, force=dec_force)
-    cache = {}
 
-    def twin_max():
-        if not cache:
-            from . import parity as P
-            base = ens.run(storms, post=True, probe=True)
-            pert = dict(storms)
-            pert['v0'] = np.nextafter(np.asarray(storms['v0'], dtype=np.float64), np.inf)
+    def twin_storms(idx):
+        from . import parity as P
+        idx = np.atleast_1d(np.asarray(idx, dtype=np.int64))
+        sub = {k: np.asarray(v)[idx] for k, v in storms.items()}
+        base = ens.run(sub, post=True, probe=True)
+        out = {name: np.full(len(idx), np.nan) for name in ('traj', 'envw', 'vmax')}
+        for key, sgn in (('v0', 1.0), ('v0', -1.0), ('lon', 1.0)):
+            pert = dict(sub)
+            pert[key] = np.nextafter(np.asarray(sub[key], dtype=np.float64), sgn * np.inf)
             twin = ens.run(pert, post=True, probe=True)
             same = (P.first_divergence(twin['dec'], base['dec']) < 0) & (twin['nfev'] == base['nfev']) & (twin['n_valid'] == base['n_valid'])
-            for name in ('traj', 'envw', 'vmax'):
-                a, b = np.asarray(base[name])[same], np.asarray(twin[name])[same]
-                d = np.abs(np.nan_to_num(a) - np.nan_to_num(b))
-                cache[name] = float(d.max()) if d.size else 0.0
-        return dict(cache)
-    replay.twin_max = twin_max
+            for name in out:
+                a, b = np.asarray(base[name]), np.asarray(twin[name])
+                d = np.abs(np.nan_to_num(a) - np.nan_to_num(b)).reshape(len(idx), -1).max(axis=1)
+                out[name] = np.fmax(out[name], np.where(same, d, np.nan))
+        return out
+    replay.twin_storms = twin_storms
     return replay

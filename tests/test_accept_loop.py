@@ -177,6 +177,57 @@ def test_step_record_overflow_grows_on_every_rank():
         assert grown == 2 and calls == rounds + 2, (rank, grown, calls, rounds)       # both ranks grew, both re-ran the first round twice
 
 
+def _refuse_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from tropical_cyclone_risk_amd import compute, distributed as D
+    D.init_from_env(backend='gloo')
+
+    class Round:
+        """Rank 0's storms overflow; rank 0 could grow its record, rank 1 has no memory for it (GpuRound.can_grow is a
+        local fact: free HBM)."""
+        grown = 0
+
+        def __call__(self, cand0, count):
+            out = fake_round(cand0, count)
+            out['bad'] = 2 if rank == 0 else 0
+            return out
+
+        def can_grow(self):
+            return rank == 0
+
+        def grow(self):
+            self.grown += 1
+            return True
+    rf = Round()
+    try:
+        compute.accept_loop(rf, 25, 64, NS)
+        q.put((rank, 'no error', rf.grown))
+    except RuntimeError as e:
+        q.put((rank, str(e), rf.grown))
+    D.barrier()                                    # both ranks get here: nobody is left waiting in a collective
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_grow_refused_by_one_rank_raises_on_every_rank():
+    """whether the step record can grow depends on a rank's free memory.  If ONE rank cannot, NO rank grows and
+    every rank raises — a rank that grew and re-ran the round would wait for ever in its all-gather."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_refuse_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, msg, grown in got:
+        assert 'gpu_max_rk_steps' in msg and grown == 0, (rank, msg, grown)
+
+
 def test_allgather_rows_ragged_gloo():
     """Ragged all-gather incl. an empty contribution and the rank-order guarantee."""
     ctx = mp.get_context('spawn')
@@ -301,10 +352,17 @@ def _years_worker(rank, world, port, n_years, q):
     years = list(range(2000, 2000 + n_years))
     mine = list(range(rank, n_years, world))
     out = [None] * n_years
+    from tropical_cyclone_risk_amd.basins import BASIN_IDS
     for i in mine:
-        out[i] = _year_tuple(i, T, ns)
-    res = compute._allgather_years(out, mine, years, nl, torch.device('cpu'))
+        # a year as the accept loop leaves it on the device: records + (candidate index, month, basin index), n_seeds
+        t9 = _year_tuple(i, T, ns)
+        rows = np.concatenate([t9[0], t9[1], t9[2], t9[3], t9[4], t9[5].reshape(T, ns * 4), np.arange(T, dtype=np.float64)[:, None],
+                               t9[6][:, None], np.array([BASIN_IDS.index(x) for x in t9[7]], dtype=np.float64)[:, None]], axis=1)
+        out[i] = dict(rows_dev=torch.from_numpy(rows), n_seeds_dev=torch.from_numpy(t9[8].reshape(-1)))
+    # (rank 0 is the one that writes the file; here every rank rebuilds the tuples so that each can check them)
+    res = compute._allgather_years(out, mine, years, nl, torch.device('cpu'), to_host=True)
     ok = all(all(np.array_equal(a, b, equal_nan=(a.dtype.kind == 'f')) for a, b in zip(res[i], _year_tuple(i, T, ns))) for i in range(n_years))
+    ok = ok and compute._allgather_years(out, mine, years, nl, torch.device('cpu'), to_host=False) is None
     # the single-rank form of the accept loop (distributed.Local) runs without touching the process group
     loc = compute.accept_loop(fake_round, 12, 64, NS, ops=D.Local)
     q.put((rank, ok, loc['cand']))

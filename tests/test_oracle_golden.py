@@ -240,3 +240,31 @@ def test_checker_is_not_vacuous(golden_env):
     worse['nfev'][i] += 6
     with pytest.raises(AssertionError, match='after forced replay'):
         check(worse, got_dec)
+    # (d) the bound on every sample is PER STORM: one storm off by 5e-7 fails unless the oracle itself amplifies
+    #     THAT storm (its own one-ulp twins, TWIN_FACTOR x), whatever the other storms' twins are; nothing passes above the cap
+    i = int(np.nonzero(ref['n_valid'] > 100)[0][0])
+    one = {kk: (vv.copy() if hasattr(vv, 'copy') else vv) for kk, vv in ref.items()}
+    one['traj'][i, 0, 50] += 5e-7
+    tw = replay.twin_storms([i])
+    assert tw['traj'][0] < 5e-9                                  # an ordinary storm: the oracle moves by ~1e-13 on it
+    with pytest.raises(AssertionError, match='storm %d' % i):
+        check(one)
+    under = {kk: (vv.copy() if hasattr(vv, 'copy') else vv) for kk, vv in ref.items()}
+    under['traj'][i, 0, 50] += 5e-8                              # under the floor, one storm: passes (and is inside the tiers' slack)
+    assert check(under)['amplified'] == []
+    real = replay.twin_storms
+    try:
+        replay.twin_storms = lambda idx: {k: np.where(np.asarray(idx) == i, 1e-8, v) for k, v in real(idx).items()}
+        s = check(one)                                           # the same storm, were it one the oracle amplifies to 1e-8
+        assert [a[0] for a in s['amplified']] == [i]
+        two = {kk: (vv.copy() if hasattr(vv, 'copy') else vv) for kk, vv in ref.items()}
+        two['traj'][i, 0, 50] += 2e-6                            # 200 x its twin
+        with pytest.raises(AssertionError, match='storm %d' % i):
+            check(two)
+        replay.twin_storms = lambda idx: {k: np.full(len(idx), 1.0) for k in ('traj', 'envw', 'vmax')}
+        far = {kk: (vv.copy() if hasattr(vv, 'copy') else vv) for kk, vv in ref.items()}
+        far['traj'][i, 0, 50] += 2e-4                            # above the cap, whatever the twin says
+        with pytest.raises(AssertionError, match='storm %d' % i):
+            check(far)
+    finally:
+        replay.twin_storms = real

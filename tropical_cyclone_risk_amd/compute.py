@@ -58,7 +58,7 @@ def _legacy_round(out, cand0, n_steps, torch):
                 bad=torch.tensor([int(out.get('bad', 0))], dtype=torch.int64, device=dev), hist=hist)
 
 
-def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000, ops=None):
+def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000, ops=None, device_result=False):
     """Order-preserving accept loop over rounds of candidates (backend-agnostic: RCCL on the GPUs, gloo in the
     CPU tests).
 
@@ -74,7 +74,9 @@ def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000, ops=Non
     overflow) pairs that size the all-gather — and the result is copied to the host once, at the end.
     Returns dict(rows [n_tracks, 9*n_steps], month, basin_idx, cand, n_seeds [7, 12], rounds); every rank
     returns the same result.  ops: the collectives (default: the process group's, `distributed`; `distributed.Local` when
-    this rank works the whole year on its own).
+    this rank works the whole year on its own).  device_result: nothing is copied to the host — the return value is
+    dict(rows_dev [n_tracks, 9*n_steps + 3] (records + candidate index, month, basin index), n_seeds_dev [7*12], rounds), both on
+    the round function's device (year-sharded runs keep a year's tracks in HBM until the all-gather of final tracks).
     """
     import torch
     D = ops or globals()['D']          # ops = distributed.Local: this rank works the year on its own (years sharded over the ranks)
@@ -107,7 +109,12 @@ def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000, ops=Non
             # A storm needed more accepted RK steps than its step record holds (the reference's solve_ivp is unbounded):
             # the round function doubles the record and the round is integrated again, or, if it cannot grow, every rank
             # raises.
-            if not (hasattr(round_fn, 'grow') and round_fn.grow()):
+            # Whether the record CAN grow depends on a rank's free HBM (GpuRound.can_grow), so that is decided collectively
+            # as well: every rank grows, or every rank raises — none is left waiting in the next round's all-gather.
+            can = hasattr(round_fn, 'grow') and (not hasattr(round_fn, 'can_grow') or bool(round_fn.can_grow()))
+            if hasattr(round_fn, 'can_grow'):
+                can = all(f[0] for f in D.allgather_ints(torch.tensor([1 if can else 0], dtype=torch.int64, device=bad.device)))
+            if not (can and round_fn.grow()):
                 raise RuntimeError('%d storms needed more accepted RK steps than the step record holds; raise '
                                    'namelist.gpu_max_rk_steps (tcr_params.max_rk_steps)' % sum(bads))
         if counts[rk] > out['rows'].shape[0]:
@@ -139,6 +146,9 @@ def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000, ops=Non
     h = last['hist'](cutoff)
     t_seeds = h if hist_full is None else hist_full + h
     D.allreduce_sum_(t_seeds)
+    if device_result:
+        assert rows.shape[0] < 2 or bool((rows[1:, width] > rows[:-1, width]).all())
+        return dict(rows_dev=rows, n_seeds_dev=t_seeds.double(), rounds=r + 1)
     host = rows.cpu().numpy()                    # the result leaves the device here, once
     cand = host[:, width].astype(np.int64)
     assert (np.diff(cand) > 0).all() if len(cand) > 1 else True
@@ -208,14 +218,16 @@ class GpuRound:
         self._build()
         return True
 
-    def grow(self):
-        """Double the per-storm step record (tcr_params.max_rk_steps).  False once it is at its limit, or when the records
-        of a round (per_rank x max_rk_steps x ~400 B) would take more than half of the free HBM — the caller then raises
-        the explicit 'raise gpu_max_rk_steps' error instead of running into an allocation failure."""
+    def can_grow(self):
+        """This rank's HBM holds a doubled step record (per_rank x max_rk_steps x ~400 B in at most half of what is free).
+        A local fact: accept_loop combines it over the ranks before anyone grows."""
         cur = int(self.eng.params.max_rk_steps) or 64
         free = self.torch.cuda.mem_get_info(self.pipe.dev)[0] if self.pipe.dev.type == 'cuda' else 1 << 62
-        if self.B * 2 * cur * 400 > free // 2:
-            return False
+        return self.B * 2 * cur * 400 <= free // 2
+
+    def grow(self):
+        """Double the per-storm step record (tcr_params.max_rk_steps).  False once it is at the ABI's limit (the same on every
+        rank); whether the memory is there is `can_grow`, which the caller has already agreed on with the other ranks."""
         return self.eng.grow_step_record()
 
     def repack(self, need):
@@ -268,7 +280,7 @@ def default_per_rank(nl, n_tracks):
     return int(max(4096, min(nl.gpu_candidate_round, 64 * n_tracks)))
 
 
-def run_tracks(year, n_tracks, b, engine=None, env=None, nl=None, per_rank=None, info=None, round_fn=None, ops=None):
+def run_tracks(year, n_tracks, b, engine=None, env=None, nl=None, per_rank=None, info=None, round_fn=None, ops=None, device_result=False):
     """Generate n_tracks TC tracks in basin b for one year (reference: compute.py:64-210).
 
     Returns (tc_lon, tc_lat, tc_v, tc_m, tc_vmax, tc_env_wnds, tc_month, tc_basin, n_seeds).
@@ -277,6 +289,7 @@ def run_tracks(year, n_tracks, b, engine=None, env=None, nl=None, per_rank=None,
     reference's loop keeps implicit: ``cand`` (global candidate index of every returned track) and ``rounds``.
     ``round_fn``: a GpuRound of the same engine to reuse (its buffers and its captured round) for this year.
     ``ops``: `distributed.Local` to work the year on this rank alone (see `accept_loop`).
+    ``device_result``: return accept_loop's device-resident result instead of the 9-tuple (`_allgather_years` consumes it).
     """
     nl = nl or default_namelist
     basin_id = b.basin_id if isinstance(b, TC_Basin) else b
@@ -290,7 +303,11 @@ def run_tracks(year, n_tracks, b, engine=None, env=None, nl=None, per_rank=None,
     else:
         per_rank = int(per_rank or default_per_rank(nl, n_tracks))
         rf = GpuRound(engine, year, per_rank)
-    res = accept_loop(rf, n_tracks, per_rank, engine.n_steps, ops=ops)
+    res = accept_loop(rf, n_tracks, per_rank, engine.n_steps, ops=ops, device_result=device_result)
+    if device_result:
+        if own:
+            engine.close()
+        return res
     if info is not None:
         info.update(cand=res['cand'], rounds=res['rounds'], per_rank=per_rank)
     if own:
@@ -330,12 +347,12 @@ def run_downscaling(basin_id, env=None, nl=None, out_dir=None):
     # Several ranks: with at least as many years as ranks the YEARS are sharded (rank r works years r, r + W, ... on its own —
     # what the reference's one-process-per-year fan-out is — and the final tracks are all-gathered once); with fewer years
     # a year's candidate blocks are sharded and the years run one after another.
-    shard_years = W > 1 and len(years) >= W and bool(getattr(nl, 'gpu_shard_years', True))
+    shard_years = D.collective() and len(years) >= W and bool(getattr(nl, 'gpu_shard_years', True))
     mine = list(range(rk, len(years), W)) if shard_years else list(range(len(years)))
     ops = D.Local if shard_years else None
-    n_workers = max(1, min(int(getattr(nl, 'gpu_years_in_flight', 3)), len(mine))) if (W == 1 or shard_years) else 1
+    n_workers = max(1, min(int(getattr(nl, 'gpu_years_in_flight', 3)), len(mine))) if (not D.collective() or shard_years) else 1
     out = [None] * len(years)
-    writer = tio.TrackFileWriter(years, b, nl, out_dir) if (rk == 0 and W == 1) else None
+    writer = tio.TrackFileWriter(years, b, nl, out_dir) if (rk == 0 and not D.collective()) else None
     errors = []
 
     def work(w):
@@ -359,9 +376,11 @@ def run_downscaling(basin_id, env=None, nl=None, out_dir=None):
                         rf = GpuRound(eng, yr, default_per_rank(nl, nl.tracks_per_year))
                         if n_workers > 1:
                             rf.graph = False         # stream capture does not tolerate the other workers' field uploads (tcrisk_hip.h)
-                    out[i] = run_tracks(yr, nl.tracks_per_year, b, engine=eng, nl=nl, round_fn=rf, ops=ops)
+                    # (year-sharded: the year's tracks stay in HBM until the all-gather of final tracks)
+                    out[i] = run_tracks(yr, nl.tracks_per_year, b, engine=eng, nl=nl, round_fn=rf, ops=ops, device_result=shard_years)
                     if writer is not None:
                         writer.put(i, out[i])
+                stream.synchronize()
             if rf is not None:
                 rf.release()
             eng.close()
@@ -383,7 +402,7 @@ def run_downscaling(basin_id, env=None, nl=None, out_dir=None):
             raise errors[0]
         if failed:
             raise RuntimeError('run_downscaling: %d rank(s) failed' % int(failed))
-        out = _allgather_years(out, mine, years, nl, torch.device('cuda', device))
+        out = _allgather_years(out, mine, years, nl, torch.device('cuda', device), to_host=(rk == 0))
     elif errors:
         if writer is not None:
             writer.abort()
@@ -397,33 +416,38 @@ def run_downscaling(basin_id, env=None, nl=None, out_dir=None):
     return fn
 
 
-def _allgather_years(out, mine, years, nl, dev):
+def _allgather_years(out, mine, years, nl, dev, to_host=True):
     """The all-gather of final tracks for year-sharded runs (`north_star`: "storms shard trivially across the GPUs with an
-    RCCL all-gather of final tracks"): every rank packs its years' 9-tuples into one device block — per year the rows
-    [tracks, 9 x n_steps], month and basin index per track, n_seeds [7 x 12] — one collective moves everything, and the
-    per-year tuples are rebuilt in year order on every rank."""
+    RCCL all-gather of final tracks"; the reference collects its dask workers' 9-tuples, util/compute.py:233-242).
+
+    out[i], i in mine: accept_loop's device result for year i — rows_dev [tracks, 9 x n_steps + 3] (survivor records +
+    candidate index, month, basin index) and n_seeds_dev [7 x 12], both in HBM.  Every rank copies its years into one device
+    block, ONE collective moves everything device to device, and only a rank that asks for it (`to_host`: rank 0, which
+    writes the file) brings the result to the host and rebuilds the per-year 9-tuples in year order; the others drop it.
+    Returns the list of 9-tuples, or None."""
     import torch
     W = D.world()
     T = int(nl.tracks_per_year)
     k_max = -(-len(years) // W)
-    ns = out[mine[0]][0].shape[1] if mine else int(nl.total_track_time_days * 24 * 3600 / nl.output_interval_s) + 1
-    width = ROW_VARS * ns + 2
+    ns = int(nl.total_track_time_days * 24 * 3600 / nl.output_interval_s) + 1
+    width = ROW_VARS * ns + N_META
     n_b = len(BASIN_IDS) * 12
-    block = torch.zeros(k_max, T * width + n_b, dtype=torch.float64)
+    block = torch.zeros(k_max, T * width + n_b, dtype=torch.float64, device=dev)
     for j, i in enumerate(mine):
-        t9 = out[i]
-        rows = np.concatenate([t9[0], t9[1], t9[2], t9[3], t9[4], t9[5].reshape(T, ns * 4), t9[6][:, None],
-                               np.array([BASIN_IDS.index(x) for x in t9[7]], dtype=np.float64)[:, None]], axis=1)
-        block[j, :T * width] = torch.from_numpy(np.ascontiguousarray(rows)).reshape(-1)
-        block[j, T * width:] = torch.from_numpy(np.asarray(t9[8], dtype=np.float64).reshape(-1))
-    got, counts = D.allgather_year_blocks(block.to(dev), len(mine), dev)
+        rows = out[i]['rows_dev']
+        assert tuple(rows.shape) == (T, width), (tuple(rows.shape), (T, width))
+        block[j, :T * width] = rows.reshape(-1)
+        block[j, T * width:] = out[i]['n_seeds_dev'].reshape(-1)
+    got, counts = D.allgather_year_blocks(block, len(mine), dev)
+    if not to_host:
+        return None
     got = got.cpu().numpy()
     res = [None] * len(years)
     for r in range(W):
         for j in range(counts[r]):
             i = r + j * W
             rows = got[r, j, :T * width].reshape(T, width)
-            tc = [rows[:, k * ns:(k + 1) * ns].copy() for k in range(5)]
-            res[i] = (tc[0], tc[1], tc[2], tc[3], tc[4], rows[:, 5 * ns:9 * ns].reshape(T, ns, 4).copy(), rows[:, 9 * ns].copy(),
-                      np.array([BASIN_IDS[int(x)] for x in rows[:, 9 * ns + 1]], dtype='U2'), got[r, j, T * width:].reshape(len(BASIN_IDS), 12).copy())
+            res[i] = rows_to_tuple(dict(rows=rows[:, :ROW_VARS * ns], month=rows[:, ROW_VARS * ns + 1].astype(np.int64),
+                                        basin_idx=rows[:, ROW_VARS * ns + 2].astype(np.int64),
+                                        n_seeds=got[r, j, T * width:].reshape(len(BASIN_IDS), 12).copy()), ns)
     return res

@@ -23,22 +23,54 @@ import torch
 import torch.distributed as dist
 
 
+def forced():
+    """TCR_FORCE_COLLECTIVES=1: a one-rank run takes the world > 1 branches — a one-rank process group is created and every
+    collective below goes through the backend (RCCL on a GPU box) instead of short-circuiting.  This is how the code RCCL
+    and its stream ordering run on an eight-GPU node is executed on the one GPU a test box has."""
+    return os.environ.get('TCR_FORCE_COLLECTIVES', '0') == '1'
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
 def init_from_env(backend=None):
-    """Initialise the default process group from torchrun's environment (no-op when
-    WORLD_SIZE is 1 or unset).  Returns (rank, world, local_rank)."""
+    """Initialise the default process group from torchrun's environment (no-op when WORLD_SIZE is 1 or unset, unless
+    TCR_FORCE_COLLECTIVES=1).  Returns (rank, world, local_rank).  Fails loudly when the backend is RCCL and the node has
+    fewer GPUs than local ranks (RCCL cannot put two ranks on one device; TCR_DIST_BACKEND=gloo can, for functional tests)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world == 1:
+            os.environ.setdefault('MASTER_PORT', str(_free_port()))
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
             # TCR_DIST_BACKEND=gloo lets several ranks share one GPU for functional tests
             backend = os.environ.get('TCR_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
+            n_local = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
+            if torch.cuda.device_count() < n_local:
+                raise RuntimeError('%d local ranks but %d GPU(s) visible: RCCL needs one device per rank '
+                                   '(TCR_DIST_BACKEND=gloo lets ranks share a GPU for functional tests)'
+                                   % (n_local, torch.cuda.device_count()))
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def collective():
+    """True when collectives go through the process group (several ranks, or TCR_FORCE_COLLECTIVES=1 with one)."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or forced())
+
+
+def backend_name():
+    b = dist.get_backend() if dist.is_initialized() else 'none'
+    return {'nccl': 'nccl = RCCL'}.get(b, b)
 
 
 def local_device(local):
@@ -65,7 +97,7 @@ def round_block(round_idx, per_rank, rank_=None, world_=None):
 
 def allgather_counts(count):
     """count: int64 tensor [1] on the compute device -> list of python ints per rank."""
-    if world() == 1:
+    if not collective():
         return [int(count.item())]
     buf = torch.empty(world(), dtype=count.dtype, device=count.device)
     dist.all_gather_into_tensor(buf, count.reshape(1))
@@ -75,7 +107,7 @@ def allgather_counts(count):
 def allgather_ints(vec):
     """vec: int64 tensor [k] on the compute device -> list (per rank) of lists of k python ints.  This is the
     accept loop's one host synchronisation per round."""
-    if world() == 1:
+    if not collective():
         return [[int(x) for x in vec.tolist()]]
     buf = torch.empty(world() * vec.numel(), dtype=vec.dtype, device=vec.device)
     dist.all_gather_into_tensor(buf, vec.contiguous())
@@ -96,7 +128,7 @@ def allgather_rows(rows, count, counts=None, async_op=False, concat=True):
     """
     counts = allgather_counts(count) if counts is None else counts
     w = world()
-    if w == 1:
+    if not collective():
         out = rows[:counts[0]] if concat else [rows[:counts[0]]]
         return ((None, lambda: (out, counts)) if async_op else (out, counts))
     m = max(counts)
@@ -152,7 +184,7 @@ class DeferredRowGather:
     def submit(self, count):
         """The buffer returned by the last buffer() call holds `count` (device int64 [1]) valid rows."""
         slot = self.k % self.depth
-        if self.w > 1:
+        if collective():
             wc = dist.all_gather_into_tensor(self.cnt[slot], count.reshape(1), async_op=True)
         else:
             self.cnt[slot].copy_(count.reshape(1))
@@ -236,7 +268,7 @@ def allgather_year_blocks(block, n_mine, device):
     w = world()
     cnt = torch.tensor([int(n_mine)], dtype=torch.int64, device=device)
     counts = allgather_counts(cnt)
-    if w == 1:
+    if not collective():
         return block.unsqueeze(0), counts
     recv = torch.empty((w,) + tuple(block.shape), dtype=block.dtype, device=block.device)
     dist.all_gather_into_tensor(recv.view(w * block.shape[0], -1), block.contiguous().view(block.shape[0], -1))
@@ -252,25 +284,25 @@ class _null:
 
 
 def allreduce_sum_(t):
-    if world() > 1:
+    if collective():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 
 def barrier():
-    if world() > 1:
+    if collective():
         dist.barrier()
 
 
 def max_over_ranks(x, device):
     t = torch.tensor([float(x)], dtype=torch.float64, device=device)
-    if world() > 1:
+    if collective():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def sum_over_ranks(x, device):
     t = torch.tensor([float(x)], dtype=torch.float64, device=device)
-    if world() > 1:
+    if collective():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())

@@ -100,6 +100,7 @@ gpu_dtype = 'f64'                 # 'f32': the fp32 variant of the path (fields 
                                  # tolerance study in profiles/r02_fp32_study.json); the reference itself is fp64
 gpu_locality_order = True        # integrate a round's storms ordered by the 2-degree cell of their genesis point (results are per storm: unchanged)
 gpu_years_in_flight = 3          # run_downscaling on one GPU: years whose rounds are in flight at a time (own context, month slots and stream each)
+gpu_shard_years = True           # several ranks and at least as many years: rank r works years r, r + W, ... on its own and the final tracks are all-gathered once (False: every year's candidate blocks are sharded, collectives per round)
 gpu_round_graph = False          # replay a round (one tcr_round_dev call) from a captured hipGraph after its first use: saves ~40 us of host time per round, no GPU time; never used while run_downscaling has several years in flight (HIP stream capture does not tolerate legacy-stream copies on other threads)
 gpu_static_store = 'auto'         # land / bathymetry in HBM: 'auto' = exact narrow storage where the values allow it (the reference's int8 land.nc + whole-metre or float32 bathymetry: 2-5 bytes per grid point), 'f64' = the fp64 planes (16 bytes); results do not depend on it (tcr_static_store)
 gpu_max_rk_steps = 64            # accepted RK45 steps recorded per storm (max observed 24); if a storm needs more, the record is doubled and the round integrated again (compute.accept_loop)
