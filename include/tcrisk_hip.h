@@ -173,6 +173,14 @@ int tcr_fields_upload(tcr_ctx *ctx, int slot,
  * RH of one month slot on the *uncropped* thermo grid, as the reference builds it; only the
  * device-side seeding reads it (initial m, compute.py:173-174). */
 int tcr_rh_upload(tcr_ctx *ctx, int slot, const tcr_grid *rg, const double *rh_mid);
+/* tcr_fields_upload + tcr_rh_upload of one month slot in ONE transfer (rg / rh_mid may both be NULL).  All three calls copy
+ * the planes into pinned memory (tcr_tune.copy_threads host threads), enqueue one asynchronous transfer and the device kernel
+ * that interleaves the planes into the slot's layouts, and return: the caller's arrays are free again, and the library waits
+ * for the staged fields when they are first used.  Do not stage a slot while launches that read it are still in flight. */
+int tcr_slot_upload(tcr_ctx *ctx, int slot,
+                    const tcr_grid *wg, const double *const mean[TCR_NW], const double *const cov[TCR_NCOV],
+                    const tcr_grid *tg, const double *vpot, const double *chi, const double *mld, const double *strat,
+                    const tcr_grid *rg, const double *rh_mid);
 /* replaces: the land/<B>.nc interpolators f_b and f_basins (compute.py:87-97).
  * masks are uint8 0/1 planes on one global grid; run_mask is the run basin's. */
 int tcr_masks_upload(tcr_ctx *ctx, const tcr_grid *mg, const uint8_t *run_mask,
@@ -183,12 +191,8 @@ int tcr_masks_upload(tcr_ctx *ctx, const tcr_grid *mg, const uint8_t *run_mask,
  * accept test 1 (:185-189), env-wind recompute (:201-202), axi_to_max_wind
  * (:203-204), accept test 2 (:205) — for a whole batch.  Host buffers. */
 int tcr_integrate_host(tcr_ctx *ctx, const tcr_storms *in, const tcr_tracks *out);
-/* same with device buffers, asynchronous on `stream`.
- * Results do not depend on how the library schedules a batch; the schedule can be steered through the environment for
- * experiments and tests (read at every call): TCR_WAVES (persistent integrator waves), TCR_PARK (tail-compaction
- * threshold, 0 = one launch), TCR_PARK_FINAL, TCR_TABLE_SEGMENTS=0 (forcing table in one piece instead of a second
- * segment written only for the storms the first integration pass parks), TCR_PRUNE=0 (tc_rows_only: no in-flight
- * 2-day test), TCR_EMIT_GRID_CAP (workgroup rows walking the list of storms that pass accept test 1). */
+/* same with device buffers, asynchronous on `stream`.  Results do not depend on how the library schedules a batch
+ * (tcr_tune below; tests/test_gpu_parity.py::test_full_size_ensemble_properties). */
 int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in_dev, const tcr_tracks *out_dev, void *stream);
 
 /* Launch shape of batches that do not fill the chip (fewer than 64 storms per SIMD).  The reference has no counterpart: it
@@ -198,6 +202,25 @@ int tcr_integrate_dev(tcr_ctx *ctx, const tcr_storms *in_dev, const tcr_tracks *
  * chain, which is what a caller with many batches in flight on other streams / contexts wants (bench.py, pipelined years).
  * Results do not depend on it. */
 int tcr_schedule_set(tcr_ctx *ctx, int32_t storms_per_lane);
+
+/* Launch-shape knobs of a context (the reference has no counterpart).  Results never depend on them.  A context starts from
+ * the environment — TCR_WAVES, TCR_PARK, TCR_PARK_FINAL, TCR_TABLE_SEGMENTS, TCR_PRUNE, TCR_EMIT_GRID_CAP, TCR_COPY_THREADS,
+ * read ONCE, in tcr_ctx_create; no entry point reads the environment afterwards — and tcr_tune_set replaces all of them.
+ * A negative field = the library's own choice. */
+typedef struct {
+    int32_t waves;            /* persistent integrator waves per launch (default: from the batch size and tcr_schedule_set) */
+    int32_t park;             /* tail-compaction threshold of k_integrate's chain of passes; 0 = one launch (default: 12 when a
+                                 launch fills the chip, else 0) */
+    int32_t park_final;       /* a pass of at most this many waves runs to the end (default 8) */
+    int32_t table_segments;   /* 0: the forcing table in one piece instead of a second segment written only for the storms the
+                                 first integration pass parks (default 1) */
+    int32_t prune;            /* 0: tc_rows_only without the in-flight 2-day test (default 1) */
+    int32_t emit_grid_cap;    /* workgroup rows walking the list of storms that pass accept test 1 (default 8192) */
+    int32_t copy_threads;     /* host threads that copy a month slot's planes into the pinned staging buffer (default 4) */
+    int32_t reserved;
+} tcr_tune;
+int tcr_tune_set(tcr_ctx *ctx, const tcr_tune *t);
+int tcr_tune_get(tcr_ctx *ctx, tcr_tune *t);
 
 /* The fp32 variant of the same path (BASELINE config 5; the reference itself is fp64 throughout, so this is a
  * documented departure with a stated tolerance, see DESIGN.md and profiles/r02_fp32_study.json): fields are

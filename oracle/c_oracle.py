@@ -243,25 +243,31 @@ def replayer(env, basin, storms, prm=None, bounds=None, ensemble=None):
     implementation's decision sequence forced at the rounding-sensitive evaluations.
 
     `replay.twin_storms(idx)` is the yardstick for the far tail of a comparison (parity.check_tracks' bound on EVERY sample):
-    the oracle's own response ON THOSE STORMS to one input changed by one ulp — three twins (v0 up, v0 down, lon up); per
-    output and storm the maximum over the twins whose decision sequence and counters stay the same (NaN if none does)."""
+    the oracle's own response ON THOSE STORMS to one input changed by one ulp — three twins (v0 up, v0 down, lon up), each
+    walking the base run's decision sequence (forced like the replay); per output and storm the maximum over the twins whose
+    decisions and counters stay the same (NaN if none does)."""
     ens = ensemble or Ensemble(env, basin, prm, bounds)
 
     def replay(idx, dec_force):
         sub = {k: np.asarray(v)[idx] for k, v in storms.items()}
         return ens.run(sub, post=True, probe=True, force=dec_force)
 
-    def twin_storms(idx):
+    def twin_storms(idx, dec=None):
+        """dec [len(idx), cap] (optional): the decision sequences the compared runs walked on those storms; base and twins
+        are then run with them forced at their rounding-sensitive evaluations, like the replay itself — a flicker-exposed
+        storm would otherwise flip a `land == 1` decision under the one-ulp change and show the jump between two branches
+        (degrees) instead of its sensitivity along one."""
         from . import parity as P
         idx = np.atleast_1d(np.asarray(idx, dtype=np.int64))
         sub = {k: np.asarray(v)[idx] for k, v in storms.items()}
-        base = ens.run(sub, post=True, probe=True)
+        base = ens.run(sub, post=True, probe=True, force=dec)
         out = {name: np.full(len(idx), np.nan) for name in ('traj', 'envw', 'vmax')}
         for key, sgn in (('v0', 1.0), ('v0', -1.0), ('lon', 1.0)):
             pert = dict(sub)
             pert[key] = np.nextafter(np.asarray(sub[key], dtype=np.float64), sgn * np.inf)
-            twin = ens.run(pert, post=True, probe=True)
-            same = (P.first_divergence(twin['dec'], base['dec']) < 0) & (twin['nfev'] == base['nfev']) & (twin['n_valid'] == base['n_valid'])
+            twin = ens.run(pert, post=True, probe=True, force=base['dec'])
+            same = ((P.first_divergence(twin['dec'], base['dec']) < 0) & (twin['nfev'] == base['nfev']) &
+                    (twin['n_valid'] == base['n_valid']) & (np.asarray(twin['hard_mismatch']) == 0))
             for name in out:
                 a, b = np.asarray(base[name]), np.asarray(twin[name])
                 d = np.abs(np.nan_to_num(a) - np.nan_to_num(b)).reshape(len(idx), -1).max(axis=1)

@@ -118,7 +118,9 @@ def check_tracks(tag, got, want, dec_got, dec_want, t0_want, t_s, counters=('sta
             return d <= sc * TOL_ALL
         storm = int(storm)
         if storm not in twin_cache:
-            twin_cache[storm] = {k: float(v[0]) for k, v in replay.twin_storms([storm]).items()}
+            # (the twins walk the decision sequence both compared runs walked on this storm)
+            walked = np.ascontiguousarray((np.asarray(dec_got) if replay_as == 'want' else np.asarray(dec_want))[[storm]])
+            twin_cache[storm] = {k: float(v[0]) for k, v in replay.twin_storms([storm], walked).items()}
         tw = twin_cache[storm].get(name, float('nan'))
         ok = bool(d <= TWIN_FACTOR * tw) and d <= sc * TOL_TAIL_CAP          # (a NaN twin — every twin changed a decision — fails)
         amplified.append((storm, name, float(d), tw))

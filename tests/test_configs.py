@@ -244,7 +244,7 @@ def test_survivor_buffer_grows_when_a_round_accepts_more(golden_env, built_lib):
 
 
 def test_forced_chain_on_a_small_batch(golden_env, built_lib):
-    """with TCR_PARK forced on a batch of <= 8 waves the first pass was also the last one, yet it ran against a
+    """with the park threshold (tcr_tune.park, TCR_PARK) forced on a batch of <= 8 waves the first pass was also the last one, yet it ran against a
     forcing table cut at sample 191 and parked — i.e. dropped — every storm that lives beyond it.  The segmented table now
     requires a second pass; forcing the chain (and the segmented table) on small batches must give the default results."""
     from tropical_cyclone_risk_amd import synthetic
@@ -253,13 +253,12 @@ def test_forced_chain_on_a_small_batch(golden_env, built_lib):
     eng = TCEngine('NA', device=0).stage_env(golden_env)
     base = eng.integrate(storms)
     assert (base['n_valid'] > 200).sum() > 50            # storms that live beyond the first table segment
-    for env_over in (dict(TCR_PARK='12'), dict(TCR_PARK='12', TCR_PARK_FINAL='1'), dict(TCR_PARK='40', TCR_PARK_FINAL='2')):
-        os.environ.update(env_over)
+    for env_over in (dict(park=12), dict(park=12, park_final=1), dict(park=40, park_final=2)):
+        eng.tune(**env_over)
         try:
             got = eng.integrate(storms)
         finally:
-            for k in env_over:
-                del os.environ[k]
+            eng.tune(park=-1, park_final=-1)
         for k in ('lon', 'lat', 'v', 'm', 'vmax', 'envw'):
             assert np.array_equal(base[k], got[k], equal_nan=True), (env_over, k)
         for k in ('status', 'n_valid', 'nfev', 'flags', 'n_accept', 'n_reject'):

@@ -273,24 +273,24 @@ def test_full_size_ensemble_properties(golden_env, built_lib):
     assert int(pipe.n_passed.item()) >= B
     pipe.integrate(B)
     a = pipe.host_tracks()
-    os.environ['TCR_WAVES'] = '700'
+    eng.tune(waves=700)
     try:
         pipe.integrate(B)
         b = pipe.host_tracks()
     finally:
-        del os.environ['TCR_WAVES']
+        eng.tune(waves=-1)
     for k in ('lon', 'lat', 'v', 'm', 'vmax', 'envw'):
         assert np.array_equal(a[k], b[k], equal_nan=True), k
     for k in ('n_valid', 'status', 'flags', 'nfev', 'n_accept', 'n_reject'):
         assert np.array_equal(a[k], b[k]), k
     # the forcing table in one piece (every storm, before the chain) instead of two segments (the second only for the
     # storms the first pass parks): same chain of passes otherwise, bitwise the same result
-    os.environ['TCR_TABLE_SEGMENTS'] = '0'
+    eng.tune(table_segments=0)
     try:
         pipe.integrate(B)
         c = pipe.host_tracks()
     finally:
-        del os.environ['TCR_TABLE_SEGMENTS']
+        eng.tune(table_segments=-1)
     for k in ('lon', 'lat', 'v', 'm', 'vmax', 'envw'):
         assert np.array_equal(a[k], c[k], equal_nan=True), k
     for k in ('n_valid', 'status', 'flags', 'nfev', 'n_accept', 'n_reject'):
@@ -392,13 +392,13 @@ def test_tc_rows_only_matches_all_rows(golden_env, built_lib):
         del full
     # the bounded grids of k_dense / k_emit over the TC list: with 64 workgroup rows every workgroup takes ~30 list
     # entries in turn; rows and flags must not depend on the grid
-    os.environ['TCR_EMIT_GRID_CAP'] = '64'
+    eng.tune(emit_grid_cap=64)
     try:
         tc2 = DevicePipeline(eng, 200_000, B, tc_rows_only=True)
         tc2.seed_round(2002, 0); tc2.select_passed(B); tc2.integrate(B)
         c = tc2.host_tracks()
     finally:
-        del os.environ['TCR_EMIT_GRID_CAP']
+        eng.tune(emit_grid_cap=-1)
     assert np.array_equal(c['flags'], b['flags']) and c['is_tc'].sum() > 64 * 3
     for k in keys:
         assert np.array_equal(c[k][is_tc], b[k][is_tc], equal_nan=True), k

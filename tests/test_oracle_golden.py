@@ -254,14 +254,14 @@ def test_checker_is_not_vacuous(golden_env):
     assert check(under)['amplified'] == []
     real = replay.twin_storms
     try:
-        replay.twin_storms = lambda idx: {k: np.where(np.asarray(idx) == i, 1e-8, v) for k, v in real(idx).items()}
+        replay.twin_storms = lambda idx, dec=None: {k: np.where(np.asarray(idx) == i, 1e-8, v) for k, v in real(idx, dec).items()}
         s = check(one)                                           # the same storm, were it one the oracle amplifies to 1e-8
         assert [a[0] for a in s['amplified']] == [i]
         two = {kk: (vv.copy() if hasattr(vv, 'copy') else vv) for kk, vv in ref.items()}
         two['traj'][i, 0, 50] += 2e-6                            # 200 x its twin
         with pytest.raises(AssertionError, match='storm %d' % i):
             check(two)
-        replay.twin_storms = lambda idx: {k: np.full(len(idx), 1.0) for k in ('traj', 'envw', 'vmax')}
+        replay.twin_storms = lambda idx, dec=None: {k: np.full(len(idx), 1.0) for k in ('traj', 'envw', 'vmax')}
         far = {kk: (vv.copy() if hasattr(vv, 'copy') else vv) for kk, vv in ref.items()}
         far['traj'][i, 0, 50] += 2e-4                            # above the cap, whatever the twin says
         with pytest.raises(AssertionError, match='storm %d' % i):

@@ -33,7 +33,7 @@ EXPORTS = ('tcr_abi_version', 'tcr_ctx_create', 'tcr_ctx_destroy', 'tcr_last_err
            'tcr_integrate_probe_host', 'tcr_integrate_f32_dev', 'tcr_integrate_f32_host', 'tcr_pack_tracks_f32_dev',
            'tcr_wind_stats_f32_dev', 'tcr_wind_stats_f32_host', 'tcr_static_upload2', 'tcr_init_m_dev', 'tcr_init_m_host', 'tcr_cell_order_dev',
            'tcr_round_dev', 'tcr_round_graph_stats', 'tcr_schedule_set', 'tcr_stage_trace_enable', 'tcr_stage_trace_sum', 'tcr_seed_hist_dev', 'tcr_pack_tracks_meta_dev',
-           'tcr_static_store', 'tcr_static_info')
+           'tcr_static_store', 'tcr_static_info', 'tcr_tune_set', 'tcr_tune_get', 'tcr_slot_upload')
 
 
 class Grid(C.Structure):
@@ -90,6 +90,11 @@ class Round(C.Structure):
                 ('n_expected', C.c_int64)]
 
 
+class Tune(C.Structure):
+    """tcr_tune: launch-shape knobs (negative = the library's choice)."""
+    _fields_ = [(k, C.c_int32) for k in ('waves', 'park', 'park_final', 'table_segments', 'prune', 'emit_grid_cap', 'copy_threads', 'reserved')]
+
+
 class TcrError(RuntimeError):
     pass
 
@@ -143,6 +148,8 @@ def lib():
     L.tcr_params_set.argtypes = [C.c_void_p, C.POINTER(Params)]
     L.tcr_static_upload.argtypes = [C.c_void_p, C.POINTER(Grid), DP, DP]
     L.tcr_static_upload2.argtypes = [C.c_void_p, C.POINTER(Grid), DP, C.POINTER(Grid), DP]
+    L.tcr_tune_set.argtypes = [C.c_void_p, C.POINTER(Tune)]
+    L.tcr_tune_get.argtypes = [C.c_void_p, C.POINTER(Tune)]
     L.tcr_static_store.argtypes = [C.c_void_p, C.c_int32]
     L.tcr_static_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     L.tcr_init_m_dev.argtypes = [C.c_void_p, C.POINTER(Storms), C.c_double, C.c_void_p, C.c_void_p]
@@ -151,6 +158,7 @@ def lib():
     L.tcr_fields_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Grid), C.POINTER(DP), C.POINTER(DP),
                                     C.POINTER(Grid), DP, DP, DP, DP]
     L.tcr_rh_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Grid), DP]
+    L.tcr_slot_upload.argtypes = L.tcr_fields_upload.argtypes + [C.POINTER(Grid), DP]
     L.tcr_masks_upload.argtypes = [C.c_void_p, C.POINTER(Grid), U8P, C.POINTER(U8P)]
     L.tcr_integrate_host.argtypes = [C.c_void_p, C.POINTER(Storms), C.POINTER(Tracks)]
     L.tcr_integrate_probe_host.argtypes = [C.c_void_p, C.POINTER(Storms), C.POINTER(Tracks), C.c_void_p, C.c_int32]

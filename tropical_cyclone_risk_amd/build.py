@@ -14,7 +14,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 OUT = os.path.join(PKG, 'libtcrisk_hip.so')
-SOURCES = ['tcr_abi.hip', 'tcr_kernels.hip', 'tcr_seed.hip', 'tcr_compact.hip', 'tcr_prep.hip', 'tcr_thermo.hip', 'tcr_device.h',
+SOURCES = ['tcr_abi.hip', 'tcr_kernels.hip', 'tcr_seed.hip', 'tcr_compact.hip', 'tcr_prep.hip', 'tcr_thermo.hip', 'tcr_device.h', 'tcr_experiments.h',
            os.path.join('..', '..', 'include', 'tcrisk_hip.h')]
 # -disable-machine-licm: the kernels here are register-bound loops around libm-heavy bodies; hoisting the bodies' constant
 # materialisations out of the loops costs k_emit 40 VGPRs + spills (0.36 instead of 0.15 ms) and k_integrate 70 AGPRs.

@@ -4,7 +4,12 @@
 // workspaces (forcing tables, track records), and kernel launches.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,6 +21,9 @@
 #include "tcr_compact.hip"
 #include "tcr_prep.hip"
 #include "tcr_thermo.hip"
+#ifdef TCR_EXPERIMENTS
+#include "tcr_experiments.h"       // scheduling probes and per-call environment knobs: tools/build_variant.py NAME -DTCR_EXPERIMENTS
+#endif
 
 using namespace tcr;
 
@@ -58,6 +66,64 @@ struct SlotStore {
     double *wind = nullptr, *thermo = nullptr, *rh = nullptr;
     float *wind32 = nullptr, *thermo32 = nullptr;       // fp32 copies (tcr_integrate_f32_*), converted on the device
     bool f32_stale = true;
+};
+
+// Host threads that copy a month slot's planes from the caller's (pageable) arrays into the pinned staging buffer: one
+// thread moves ~10 GB/s, a slot of the global basin is 9.9 MB and crosses PCIe in 0.2 ms — the copy into pinned memory, not
+// the link, is what a year's staging waits for.  Fork / join per call; the caller takes part.
+struct CopyPool {
+    struct Seg { char *dst; const char *src; size_t bytes; };
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    const Seg *segs = nullptr;
+    size_t n_segs = 0;
+    std::atomic<size_t> next{0};
+    int active = 0;
+    uint64_t gen = 0;
+    bool stop = false;
+
+    explicit CopyPool(int helpers)
+    {
+        for (int i = 0; i < helpers; ++i) th.emplace_back([this] { loop(); });
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_go.notify_all();
+        for (auto &t : th) t.join();
+    }
+    void work()
+    {
+        for (size_t i; (i = next.fetch_add(1)) < n_segs;) memcpy(segs[i].dst, segs[i].src, segs[i].bytes);
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+            }
+            work();
+            std::lock_guard<std::mutex> lk(mu);
+            if (--active == 0) cv_done.notify_one();
+        }
+    }
+    void run(const std::vector<Seg> &v)
+    {
+        if (v.empty()) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            segs = v.data(); n_segs = v.size(); next = 0; active = (int)th.size(); ++gen;
+        }
+        cv_go.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return active == 0; });
+    }
 };
 
 }  // namespace
@@ -117,14 +183,26 @@ struct tcr_ctx {
     size_t tc_idx_cap = 0;
     int64_t *d_tc_count = nullptr;
     double *d_cell = nullptr; size_t cell_cap = 0; int cell_bins = 0;     // scratch of tcr_cell_order_dev
+    bool cell_counts_open = false;              // a compaction that counts cells has been enqueued, the rank kernel that zeroes them again not yet
+    unsigned int *d_hist_partial = nullptr;     // k_seed_hist: per-workgroup counts + ticket (zero between launches)
     uint8_t *d_probe = nullptr;                 // decision probe of the next tcr_integrate_dev (tcr_integrate_probe_host)
     int probe_cap = 0;
     // rounds replayed from captured graphs (tcr_round_dev): the device copy of the round key the replayed kernels read, the
     // graphs keyed by the bytes of their descriptor, and an epoch that every allocation / parameter change bumps (a graph
     // holds the workspaces' addresses and the parameters by value)
     int storms_per_lane = 1;                    // tcr_schedule_set
-    double *h_stage = nullptr;                  // pinned staging buffer of the field uploads (two halves)
-    size_t h_stage_cap = 0;
+    tcr_tune tune;                              // launch-shape knobs: the environment at tcr_ctx_create, then tcr_tune_set
+    // field staging: two pinned halves (the host fills one while the other crosses the link), one device landing buffer for the
+    // planes as they are, and the kernel that interleaves them into the slot layouts; nothing waits on the host until the
+    // fields are used (fields_pending)
+    double *h_stage[2] = {nullptr, nullptr};
+    size_t h_stage_cap = 0;                     // doubles per half
+    hipEvent_t h_stage_ev[2] = {nullptr, nullptr};
+    int h_stage_next = 0;
+    double *d_stage = nullptr;
+    size_t d_stage_cap = 0;
+    bool fields_pending = false;
+    std::unique_ptr<CopyPool> pool;
     RoundKey *d_round_key = nullptr;
     uint64_t epoch = 0;
     bool capturing = false;
@@ -276,6 +354,12 @@ int ready(tcr_ctx *ctx, bool need_masks)
     if (!ctx->wg.set || !ctx->tg.set || ctx->slots.empty()) return fail(ctx, "no field slot staged (tcr_fields_upload)");
     if (!ctx->hg.set) return fail(ctx, "static fields not staged (tcr_static_upload)");
     if (need_masks && !ctx->mg.set) return fail(ctx, "basin masks not staged (tcr_masks_upload)");
+    if (ctx->fields_pending) {
+        // the slots staged since the last use: their copies and interleave kernels run on the context's stream, the caller's
+        // launches may be on any stream
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->fields_pending = false;
+    }
     return sync_slots(ctx);
 }
 
@@ -304,10 +388,7 @@ unsigned integrate_waves(const tcr_ctx *ctx, int64_t n, int wps)
     (void)wps;
     const int64_t simds = (int64_t)ctx->cu_count * 4;
     int64_t waves = (n + kWave - 1) / kWave;
-    if (const char *e = getenv("TCR_WAVES")) {
-        const long v = atol(e);
-        if (v > 0) return (unsigned)(v < waves ? v : waves);
-    }
+    if (ctx->tune.waves > 0) return (unsigned)(ctx->tune.waves < waves ? ctx->tune.waves : waves);
     if (waves > simds) waves = (n >= simds * kWave * 4) ? 2 * simds : simds;
     else if (ctx->storms_per_lane > 1) {
         // a batch that does not fill the chip, on a context set up for throughput (tcr_schedule_set): fewer waves whose lanes
@@ -322,13 +403,10 @@ unsigned integrate_waves(const tcr_ctx *ctx, int64_t n, int wps)
 // Tail compaction of k_integrate: a wave parks its storms once fewer than this many lanes are
 // live and the queue is empty.  Only worth it when the launch fills the chip (one wave per SIMD):
 // it trades latency of the chain (pass barriers) for SIMD time, and SIMD time is only scarce then.
-// TCR_PARK=0 disables the chain (one launch runs every storm to its end), TCR_PARK=k forces k.
+// tcr_tune.park = 0 disables the chain (one launch runs every storm to its end), k > 0 forces k.
 int park_threshold(const tcr_ctx *ctx, unsigned waves, int wps)
 {
-    if (const char *e = getenv("TCR_PARK")) {
-        const long v = atol(e);
-        return v <= 0 ? 0 : (v > 63 ? 63 : (int)v);
-    }
+    if (ctx->tune.park >= 0) return ctx->tune.park > 63 ? 63 : ctx->tune.park;
     (void)wps;
     // 12: measured on 100 000-storm steps (4 streams, segmented forcing table) — threshold 8 / 12 / 16 / 24 give 1.41 / 1.39 / 1.39 /
     // 1.38 ms per step and chains of 2.20 / 2.14-2.20 / 2.20-2.24 / 2.31-2.34 ms (5 / 5 / 6 / 7 passes): a higher threshold buys lane
@@ -336,23 +414,15 @@ int park_threshold(const tcr_ctx *ctx, unsigned waves, int wps)
     return waves >= (unsigned)ctx->cu_count * 4u ? 12 : 0;
 }
 
-// TCR_PASS_FILL=p: passes after the first launch only p % as many lanes as they have parked storms (k_integrate, fill_pct)
+// TCR_PASS_FILL=p (experiment builds): passes after the first launch only p % as many lanes as they have parked storms
+// (k_integrate, fill_pct)
 int pass_fill_pct()
 {
-    if (const char *e = getenv("TCR_PASS_FILL")) { const long v = atol(e); if (v > 0 && v <= 100) return (int)v; }
+#ifdef TCR_EXPERIMENTS
+    return tcr_exp::pass_fill_pct();
+#else
     return 100;
-}
-// TCR_PRUNE=0: no in-flight 2-day test (every storm writes all its step records, k_screen looks at every storm)
-bool prune_enabled()
-{
-    if (const char *e = getenv("TCR_PRUNE")) return atol(e) != 0;
-    return true;
-}
-// TCR_TABLE_SEGMENTS=0: the whole forcing table for every storm before the chain
-bool table_segments_enabled()
-{
-    if (const char *e = getenv("TCR_TABLE_SEGMENTS")) return atol(e) != 0;
-    return true;
+#endif
 }
 // np.linspace(0, total_time, n_steps)[i] as the kernels form it (ts_at)
 double ts_host(const tcr_params &P, int i)
@@ -361,10 +431,29 @@ double ts_host(const tcr_params &P, int i)
 }
 
 constexpr size_t kQueueWords = 6 * kMaxPasses;     // heads, parked counts, 4 occupancy counters per pass
-unsigned park_final_waves()               // a pass this small runs to the end
+unsigned park_final_waves(const tcr_ctx *ctx)               // a pass this small runs to the end
 {
-    if (const char *e = getenv("TCR_PARK_FINAL")) { const long v = atol(e); if (v > 0) return (unsigned)v; }
-    return 8;
+    return ctx->tune.park_final > 0 ? (unsigned)ctx->tune.park_final : 8u;
+}
+
+// The launch-shape knobs a context starts from: the environment, read ONCE (tcr_ctx_create); tcr_tune_set replaces them.
+long env_long(const char *name, long dflt)
+{
+    const char *e = getenv(name);
+    return e ? atol(e) : dflt;
+}
+tcr_tune tune_from_env()
+{
+    tcr_tune t;
+    t.waves = (int32_t)env_long("TCR_WAVES", -1);
+    t.park = (int32_t)env_long("TCR_PARK", -1);
+    t.park_final = (int32_t)env_long("TCR_PARK_FINAL", -1);
+    t.table_segments = (int32_t)env_long("TCR_TABLE_SEGMENTS", -1);
+    t.prune = (int32_t)env_long("TCR_PRUNE", -1);
+    t.emit_grid_cap = (int32_t)env_long("TCR_EMIT_GRID_CAP", -1);
+    t.copy_threads = (int32_t)env_long("TCR_COPY_THREADS", -1);
+    t.reserved = 0;
+    return t;
 }
 
 struct DevBuf {
@@ -463,6 +552,35 @@ __global__ __launch_bounds__(256) void k_static_widen(int mode, const void *__re
         if (i < n_land) { const double v = (double)reinterpret_cast<const uint8_t *>(nstat)[i]; if (stat) stat[2 * i] = v; else land[i] = v; }
         if (i < n_bathy) { const double v = (double)nbathy[i]; if (stat) stat[2 * i + 1] = v; else bathy[i] = v; }
     }
+}
+
+// The planes of one month slot as they came over the link — src = 14 wind planes [nw], 4 thermo planes [nt], rh [nr] —
+// into the slot layouts of tcr_device.h: wind [point][16] (NaN -> 0: _interp_basin_field, bam_track.py:72-74; two pads),
+// thermo [point][4], rh as it is.  One thread per grid point.
+struct StageSlotArgs {
+    const double *src;
+    size_t nw, nt, nr;
+    double *wind, *thermo, *rh;
+};
+__global__ __launch_bounds__(256) void k_stage_slot(StageSlotArgs a)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.nw) {
+        double v[16];
+#pragma unroll
+        for (int f = 0; f < 14; ++f) { const double x = a.src[(size_t)f * a.nw + i]; v[f] = (x != x) ? 0.0 : x; }
+        v[14] = 0.0; v[15] = 0.0;
+        double2 *o = reinterpret_cast<double2 *>(a.wind + i * kWindStride);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = make_double2(v[2 * k], v[2 * k + 1]);
+    }
+    if (i < a.nt) {
+        const double *t = a.src + 14 * a.nw;
+        double2 *o = reinterpret_cast<double2 *>(a.thermo + i * kThermoStride);
+        o[0] = make_double2(t[i], t[a.nt + i]);
+        o[1] = make_double2(t[2 * a.nt + i], t[3 * a.nt + i]);
+    }
+    if (i < a.nr) a.rh[i] = a.src[14 * a.nw + 4 * a.nt + i];
 }
 
 // ---- fp32 staging: float knots (+ reciprocal widths and the affine test in float arithmetic) and float
@@ -675,7 +793,9 @@ int launch_fourier(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const double *
             // workgroups per launch: TCR_FS_WGS=<total> overrides (scheduling experiment: a workgroup's two 191-register waves
             // keep integrator waves of other batches off their SIMDs)
             int64_t want = (int64_t)ctx->cu_count * kFsMfmaWgsPerCu * (4 / kFsMfmaWaves) / groups;
-            if (const char *e = getenv("TCR_FS_WGS")) { const long v = atol(e); if (v > 0) want = std::max<long>(1, v / groups); }
+#ifdef TCR_EXPERIMENTS
+            want = tcr_exp::fs_workgroups(want, groups);
+#endif
             const unsigned wgs = (unsigned)std::min<int64_t>(tiles, std::max<int64_t>(1, want));
             if (part == kFsRest)
                 hipLaunchKernelGGL((k_fourier_mfma<R, true>), dim3(wgs, groups), dim3(64 * kFsMfmaWaves), 0, st, P, n, n_dev, ctx->fs_period,
@@ -739,12 +859,12 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
     // its next attempt could read beyond the first segment.  58 % of the storms never get there.
     // (only when the first pass is not also the last one: a last pass never parks, so a table cut at sample 191 would strand
     // every storm that lives beyond it — ADVICE r2: TCR_PARK forced on a batch of <= 8 waves)
-    const unsigned final_waves = park_final_waves();
+    const unsigned final_waves = park_final_waves(ctx);
     const bool segmented = kFsMfmaColGroups == 2 && thr > 0 && waves > final_waves && kMaxPasses > 1 && fourier_on_matrix_cores(ctx) &&
-                           (int)P.n_steps > kFsSegSamples + 16 && table_segments_enabled();
+                           (int)P.n_steps > kFsSegSamples + 16 && ctx->tune.table_segments != 0;
     // TC rows only: the 2-day half of accept test 1 is decided in flight when 2 d is an output sample (KArgsT::prune_sample)
     int prune_sample = -1;
-    if (out.tc_rows_only && prune_enabled()) {
+    if (out.tc_rows_only && ctx->tune.prune != 0) {
         const double t2d = 2 * 86400.0, step_out = P.total_time / (double)(P.n_steps - 1);
         const int j = (int)floor(t2d / step_out);
         if (j >= 1 && j < P.n_steps - 1 && ts_host(P, j) == t2d) {
@@ -845,7 +965,7 @@ int integrate_impl(tcr_ctx *ctx, const tcr_storms *in, const TracksT<R> out, voi
         }
         // k_dense, TC rows only: a bounded grid of waves walks the device-side list (one wave per storm otherwise)
         int64_t cap = kEmitGridCap;
-        if (const char *e = getenv("TCR_EMIT_GRID_CAP")) { const long v = atol(e); if (v > 0) cap = v; }     // tests: force several list entries per workgroup
+        if (ctx->tune.emit_grid_cap > 0) cap = ctx->tune.emit_grid_cap;     // tests: force several list entries per workgroup
         // (a batch of at most two grid caps gets a row of workgroups per storm: no overflow launch — a dispatch costs a small
         // batch more than 12 000 workgroups that find nothing to do)
         const unsigned gx = (out.tc_rows_only && n > 2 * cap) ? (unsigned)cap : (unsigned)n;
@@ -900,13 +1020,20 @@ int tcr_ctx_create(int device, tcr_ctx **out)
     if (device < 0 || device >= count) return fail(nullptr, "tcr_ctx_create: device index out of range");
     tcr_ctx *ctx = new tcr_ctx();
     ctx->device = device;
+    ctx->tune = tune_from_env();
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
         delete ctx;
         return fail(nullptr, "tcr_ctx_create: hipSetDevice/hipStreamCreate failed");
     }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
         ctx->cu_count = prop.multiProcessorCount;
+        if (prop.sharedMemPerBlock < kCellScanLds) {
+            (void)hipStreamDestroy(ctx->stream);
+            delete ctx;
+            return fail(nullptr, "tcr_ctx_create: this library is built for gfx950 (160 KB of LDS per CU); the device offers less than k_cell_scan's 67 KB per workgroup");
+        }
+    }
     if (hipMalloc(reinterpret_cast<void **>(&ctx->d_queue), kQueueWords * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&ctx->d_tc_count), 64) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&ctx->d_round_key), 64) != hipSuccess) {
@@ -935,8 +1062,9 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     for (auto &ev : ctx->st_pool) if (ev) (void)hipEventDestroy(ev);
     for (auto &g : ctx->graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
     (void)hipFree(ctx->d_round_key);
-    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-    (void)hipFree(ctx->d_cell); (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_seg_sids); (void)hipFree(ctx->d_screen_skip); (void)hipFree(ctx->d_und_list); (void)hipFree(ctx->d_und_count); (void)hipFree(ctx->d_tab);
+    for (int i = 0; i < 2; ++i) { if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]); if (ctx->h_stage_ev[i]) (void)hipEventDestroy(ctx->h_stage_ev[i]); }
+    (void)hipFree(ctx->d_stage);
+    (void)hipFree(ctx->d_hist_partial); (void)hipFree(ctx->d_cell); (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_seg_sids); (void)hipFree(ctx->d_screen_skip); (void)hipFree(ctx->d_und_list); (void)hipFree(ctx->d_und_count); (void)hipFree(ctx->d_tab);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -1072,53 +1200,93 @@ int tcr_static_upload(tcr_ctx *ctx, const tcr_grid *hg, const double *land, cons
     return tcr_static_upload2(ctx, hg, land, hg, bathy);
 }
 
+extern "C++" {
+namespace {
+// One month slot: the planes go to the device as they are — copied by the pool into a pinned half, one asynchronous
+// transfer — and k_stage_slot interleaves them there (wind NaN -> 0 as _interp_basin_field does, bam_track.py:72-74).
+// Nothing here waits for the GPU except for the pinned half it is about to overwrite (two slots back).
+// wind / thermo == false: that part is not given (tcr_rh_upload alone / tcr_fields_upload without rh).
+int slot_stage(tcr_ctx *ctx, int slot, const tcr_grid *wg, const double *const mean[TCR_NW], const double *const cov[TCR_NCOV],
+               const tcr_grid *tg, const double *vpot, const double *chi, const double *mld, const double *strat,
+               const tcr_grid *rg, const double *rh_mid)
+{
+    const bool fields = wg != nullptr, rh = rg != nullptr;
+    if (fields && (stage_grid(ctx, ctx->wg, wg, "wind") || stage_grid(ctx, ctx->tg, tg, "thermo"))) return -1;
+    if (rh && stage_grid(ctx, ctx->rg, rg, "rh")) return -1;
+    if ((size_t)slot >= ctx->slots.size()) ctx->slots.resize(slot + 1);
+    SlotStore &s = ctx->slots[slot];
+    const size_t nw = fields ? (size_t)wg->nlon * wg->nlat : 0, nt = fields ? (size_t)tg->nlon * tg->nlat : 0;
+    const size_t nr = rh ? (size_t)rg->nlon * rg->nlat : 0;
+    const size_t need = nw * 14 + nt * 4 + nr;
+    if (need > ctx->h_stage_cap) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < 2; ++i) {
+            if (ctx->h_stage[i]) HIPCHK(ctx, hipHostFree(ctx->h_stage[i]));
+            ctx->h_stage[i] = nullptr;
+            HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_stage[i]), need * sizeof(double), hipHostMallocDefault));
+            if (!ctx->h_stage_ev[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->h_stage_ev[i], hipEventDisableTiming));
+        }
+        ctx->h_stage_cap = need;
+    }
+    if (need > ctx->d_stage_cap) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (grow(ctx, &ctx->d_stage, &ctx->d_stage_cap, need)) return -1;
+    }
+    if (fields && !s.wind && dev_alloc(ctx, &s.wind, nw * kWindStride)) return -1;
+    if (fields && !s.thermo && dev_alloc(ctx, &s.thermo, nt * kThermoStride)) return -1;
+    if (rh && !s.rh && dev_alloc(ctx, &s.rh, nr)) return -1;
+    if (!ctx->pool) ctx->pool.reset(new CopyPool((ctx->tune.copy_threads > 0 ? std::min(ctx->tune.copy_threads, 16) : 4) - 1));
+    const int half = ctx->h_stage_next;
+    ctx->h_stage_next ^= 1;
+    HIPCHK(ctx, hipEventSynchronize(ctx->h_stage_ev[half]));           // the transfer that last read this half (long done)
+    double *h = ctx->h_stage[half];
+    std::vector<CopyPool::Seg> segs;
+    auto add = [&](double *dst, const double *src, size_t n) {
+        const size_t chunk = 16384;                                    // 128 KB pieces: a slot is ~75 of them
+        for (size_t o = 0; o < n; o += chunk)
+            segs.push_back({reinterpret_cast<char *>(dst + o), reinterpret_cast<const char *>(src + o), sizeof(double) * std::min(chunk, n - o)});
+    };
+    if (fields) {
+        for (int f = 0; f < 14; ++f) add(h + (size_t)f * nw, f < 4 ? mean[f] : cov[f - 4], nw);
+        const double *th[4] = {vpot, chi, mld, strat};
+        for (int k = 0; k < 4; ++k) add(h + 14 * nw + (size_t)k * nt, th[k], nt);
+    }
+    if (rh) add(h + 14 * nw + 4 * nt, rh_mid, nr);
+    ctx->pool->run(segs);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage, h, sizeof(double) * need, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->h_stage_ev[half], ctx->stream));
+    StageSlotArgs a{};
+    a.src = ctx->d_stage; a.nw = nw; a.nt = nt; a.nr = nr; a.wind = s.wind; a.thermo = s.thermo; a.rh = s.rh;
+    const size_t nmax = std::max(nw, std::max(nt, nr));
+    hipLaunchKernelGGL(k_stage_slot, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    HIPCHK(ctx, hipGetLastError());
+    if (fields) s.f32_stale = true;
+    ctx->slots_dirty = true;
+    ctx->fields_pending = true;
+    return 0;
+}
+}  // namespace
+}  // extern "C++"
+
+int tcr_slot_upload(tcr_ctx *ctx, int slot, const tcr_grid *wg, const double *const mean[TCR_NW],
+                    const double *const cov[TCR_NCOV], const tcr_grid *tg, const double *vpot,
+                    const double *chi, const double *mld, const double *strat, const tcr_grid *rg, const double *rh_mid)
+{
+    if (!ctx) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (slot < 0 || slot >= 4096) return fail(ctx, "tcr_slot_upload: slot out of range");
+    if (!wg || !tg || !mean || !cov || !vpot || !chi || !mld || !strat) return fail(ctx, "tcr_slot_upload: NULL plane");
+    for (int f = 0; f < 14; ++f)
+        if (!(f < 4 ? mean[f] : cov[f - 4])) return fail(ctx, "tcr_slot_upload: NULL wind plane");
+    if ((rg == nullptr) != (rh_mid == nullptr)) return fail(ctx, "tcr_slot_upload: rh grid and plane go together");
+    return slot_stage(ctx, slot, wg, mean, cov, tg, vpot, chi, mld, strat, rg, rh_mid);
+}
+
 int tcr_fields_upload(tcr_ctx *ctx, int slot, const tcr_grid *wg, const double *const mean[TCR_NW],
                       const double *const cov[TCR_NCOV], const tcr_grid *tg, const double *vpot,
                       const double *chi, const double *mld, const double *strat)
 {
-    if (!ctx) return -1;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (slot < 0 || slot >= 4096) return fail(ctx, "tcr_fields_upload: slot out of range");
-    if (!mean || !cov || !vpot || !chi || !mld || !strat) return fail(ctx, "tcr_fields_upload: NULL plane");
-    if (stage_grid(ctx, ctx->wg, wg, "wind") || stage_grid(ctx, ctx->tg, tg, "thermo")) return -1;
-    if ((size_t)slot >= ctx->slots.size()) ctx->slots.resize(slot + 1);
-    SlotStore &s = ctx->slots[slot];
-    const size_t nw = (size_t)wg->nlon * wg->nlat, nt = (size_t)tg->nlon * tg->nlat;
-    for (int f = 0; f < 14; ++f)
-        if (!(f < 4 ? mean[f] : cov[f - 4])) return fail(ctx, "tcr_fields_upload: NULL wind plane");
-    // Interleave on the host into a pinned staging buffer (grid point outermost: one contiguous 128-byte record per point,
-    // fourteen streaming reads) and copy asynchronously; the thermo planes are interleaved into the buffer's other half
-    // while the wind copy is in flight.  (Round 3 walked the 8 MB destination fourteen times with a stride of 128 bytes and
-    // copied from pageable memory: 2.7 ms per month slot, the largest item of a 40-year run — profiles/r04_config3.json.)
-    const size_t need = nw * kWindStride + nt * kThermoStride;
-    if (need > ctx->h_stage_cap) {
-        if (ctx->h_stage) HIPCHK(ctx, hipHostFree(ctx->h_stage));
-        ctx->h_stage = nullptr; ctx->h_stage_cap = 0;
-        HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_stage), need * sizeof(double), hipHostMallocDefault));
-        ctx->h_stage_cap = need;
-    }
-    {   // NaN -> 0 as _interp_basin_field does (bam_track.py:72-74)
-        double *h = ctx->h_stage;
-        const double *src[14];
-        for (int f = 0; f < 14; ++f) src[f] = f < 4 ? mean[f] : cov[f - 4];
-        for (size_t i = 0; i < nw; ++i) {
-            double *o = h + i * kWindStride;
-            for (int f = 0; f < 14; ++f) { const double x = src[f][i]; o[f] = (x != x) ? 0.0 : x; }
-            o[14] = 0.0; o[15] = 0.0;
-        }
-        if (!s.wind && dev_alloc(ctx, &s.wind, nw * kWindStride)) return -1;
-        HIPCHK(ctx, hipMemcpyAsync(s.wind, h, sizeof(double) * nw * kWindStride, hipMemcpyHostToDevice, ctx->stream));
-    }
-    {
-        double *h = ctx->h_stage + nw * kWindStride;
-        for (size_t i = 0; i < nt; ++i) { h[i * 4] = vpot[i]; h[i * 4 + 1] = chi[i]; h[i * 4 + 2] = mld[i]; h[i * 4 + 3] = strat[i]; }
-        if (!s.thermo && dev_alloc(ctx, &s.thermo, nt * kThermoStride)) return -1;
-        HIPCHK(ctx, hipMemcpyAsync(s.thermo, h, sizeof(double) * nt * kThermoStride, hipMemcpyHostToDevice, ctx->stream));
-    }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    s.f32_stale = true;
-    ctx->slots_dirty = true;
-    return 0;
+    return tcr_slot_upload(ctx, slot, wg, mean, cov, tg, vpot, chi, mld, strat, nullptr, nullptr);
 }
 
 int tcr_rh_upload(tcr_ctx *ctx, int slot, const tcr_grid *rg, const double *rh_mid)
@@ -1126,15 +1294,8 @@ int tcr_rh_upload(tcr_ctx *ctx, int slot, const tcr_grid *rg, const double *rh_m
     if (!ctx) return -1;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (slot < 0 || slot >= 4096) return fail(ctx, "tcr_rh_upload: slot out of range");
-    if (!rh_mid) return fail(ctx, "tcr_rh_upload: NULL plane");
-    if (stage_grid(ctx, ctx->rg, rg, "rh")) return -1;
-    if ((size_t)slot >= ctx->slots.size()) ctx->slots.resize(slot + 1);
-    SlotStore &s = ctx->slots[slot];
-    const size_t nr = (size_t)rg->nlon * rg->nlat;
-    if (!s.rh && dev_alloc(ctx, &s.rh, nr)) return -1;
-    HIPCHK(ctx, copy_sync(ctx->stream, s.rh, rh_mid, sizeof(double) * nr, hipMemcpyHostToDevice));
-    ctx->slots_dirty = true;
-    return 0;
+    if (!rg || !rh_mid) return fail(ctx, "tcr_rh_upload: NULL plane");
+    return slot_stage(ctx, slot, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rg, rh_mid);
 }
 
 int tcr_masks_upload(tcr_ctx *ctx, const tcr_grid *mg, const uint8_t *run_mask,
@@ -1700,6 +1861,12 @@ int cell_order_args(tcr_ctx *ctx, const tcr_seeds *cand, int32_t *idx, int64_t n
         if (grow(ctx, &ctx->d_cell, &ctx->cell_cap, (words + 1) / 2 + 4096)) return -1;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_cell, 0, sizeof(int32_t) * head, st));
         ctx->cell_bins = a.nbins;
+        ctx->cell_counts_open = false;
+    } else if (ctx->cell_counts_open && !ctx->capturing) {
+        // an earlier ordering was abandoned between the kernel that counts the cells and the one that leaves the counters zero
+        // (an enqueue error in between): the counters are not relied on, they are cleared
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_cell, 0, sizeof(int32_t) * head, st));
+        ctx->cell_counts_open = false;
     }
     int32_t *w = reinterpret_cast<int32_t *>(ctx->d_cell);
     a.hist = w; a.start = w + a.nbins + 1; a.long_cells = w + 2 * (a.nbins + 1);
@@ -1715,11 +1882,13 @@ int cell_order_launch(tcr_ctx *ctx, const CellOrderArgs &a, bool key_done, hipSt
 {
     const int64_t n = a.n;
     const unsigned blocks = (unsigned)((n + 255) / 256);
+    ctx->cell_counts_open = true;
     if (!key_done) hipLaunchKernelGGL(k_cell_key, dim3(blocks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(kCellScanThreads), 0, st, a);
     hipLaunchKernelGGL(k_cell_scatter, dim3(blocks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_cell_rank, dim3((unsigned)((std::max<int64_t>(n, a.nbins + 1) + 255) / 256)), dim3(256), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
+    ctx->cell_counts_open = false;              // k_cell_rank leaves the counters zero
     return 0;
 }
 }  // namespace
@@ -1846,19 +2015,16 @@ int seed_hist_impl(tcr_ctx *ctx, const tcr_seeds *cand, int64_t n, int64_t cand0
     SeedHistArgs a{};
     a.seed_flags = cand->seed_flags; a.basin_idx = cand->basin_idx; a.slot = cand->slot; a.n = n > 0 ? n : 0; a.cand0 = cand0;
     a.key = key; a.cutoff = cutoff; a.out = reinterpret_cast<unsigned long long *>(out);
-    hipLaunchKernelGGL(k_seed_hist, dim3(1), dim3(1024), 0, st, a);
+    if (!ctx->d_hist_partial) {
+        const size_t words = (size_t)kSeedHistBlocks * TCR_N_BASINS * 12 + 16;
+        if (dev_alloc(ctx, &ctx->d_hist_partial, words)) return -1;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_hist_partial, 0, sizeof(unsigned int) * words, st));
+    }
+    a.partial = ctx->d_hist_partial;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(kSeedHistBlocks, (a.n + 1023) / 1024));
+    hipLaunchKernelGGL(k_seed_hist, dim3((unsigned)blocks), dim3(256), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
     return 0;
-}
-
-// scheduling probes (tools / DESIGN.md section 9, round 4): TCR_DUMMY_LAUNCHES=k empty one-wave kernels and TCR_DUMMY_SPIN_US=t, one wave
-// that spins for t microseconds, per round
-__global__ void k_probe_empty() {}
-__global__ void k_probe_store(unsigned long long *p) { if (threadIdx.x == 0) p[blockIdx.x * 16] = clock64(); }
-__global__ void k_probe_spin(long long ticks)
-{
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
 // Everything a round enqueues (see tcr_round_dev in the header).  key != NULL: the replayable form — seed / year / cand0
@@ -1870,22 +2036,15 @@ int enqueue_round(tcr_ctx *ctx, const tcr_round *r, uint64_t seed, int32_t year,
     STAGE(TCR_STAGE_START);
     if (seed_impl(ctx, seed, year, cand0, key, &cand, st)) return -1;
     STAGE(TCR_STAGE_SEED);
-    if (const char *e = getenv("TCR_DUMMY_LAUNCHES")) {
-        const char *m = getenv("TCR_DUMMY_MODE");
-        const int mode = m ? atoi(m) : 0;       // 0: one empty wave; 1: 50 empty workgroups of 256; 2: one wave, one store; 3: 50 x 256, a store each
-        for (long k = atol(e); k > 0; --k) {
-            if (mode == 0) hipLaunchKernelGGL(k_probe_empty, dim3(1), dim3(64), 0, (hipStream_t)st);
-            else if (mode == 1) hipLaunchKernelGGL(k_probe_empty, dim3(50), dim3(256), 0, (hipStream_t)st);
-            else if (mode == 2) hipLaunchKernelGGL(k_probe_store, dim3(1), dim3(64), 0, (hipStream_t)st, reinterpret_cast<unsigned long long *>(ctx->d_cell));
-            else hipLaunchKernelGGL(k_probe_store, dim3(50), dim3(256), 0, (hipStream_t)st, reinterpret_cast<unsigned long long *>(ctx->d_cell) + 4096);
-        }
-    }
-    if (const char *e = getenv("TCR_DUMMY_SPIN_US")) if (atol(e) > 0) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, (hipStream_t)st, 100ll * atol(e));
+#ifdef TCR_EXPERIMENTS
+    tcr_exp::dummy_launches((hipStream_t)st, reinterpret_cast<unsigned long long *>(ctx->d_cell));
+#endif
     if (r->cell_deg > 0) {
         // locality order: with many cells the keys and cell counts are produced by the compaction itself (one launch less)
         CellOrderArgs ca{};
         if (cell_order_args(ctx, &cand, r->cand_idx, r->n_storms, r->n_passed, r->cell_deg, (hipStream_t)st, ca)) return -1;
         const bool fused = ca.nbins > kCellLdsBins;
+        if (fused) ctx->cell_counts_open = true;
         if (compact_impl(ctx, r->n_cand, cand.seed_flags, 2, r->n_storms, r->cand_idx, r->n_passed, st, fused ? &ca : nullptr)) return -1;
         STAGE(TCR_STAGE_SELECT);
         if (cell_order_launch(ctx, ca, fused, (hipStream_t)st)) return -1;
@@ -1999,7 +2158,9 @@ int tcr_round_dev(tcr_ctx *ctx, const tcr_round *r, uint64_t seed, int32_t year,
             g->failed = true;                    // this descriptor keeps the direct form; the round above has run
             return 0;
         }
-        if (const char *dot = getenv("TCR_GRAPH_DOT")) (void)hipGraphDebugDotPrint(graph, dot, 0);      // debugging aid
+#ifdef TCR_EXPERIMENTS
+        tcr_exp::graph_dot(graph);
+#endif
         hipGraphExec_t exec = nullptr;
         if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) {
             (void)hipGraphDestroy(graph); (void)hipGetLastError();
@@ -2024,6 +2185,22 @@ int tcr_schedule_set(tcr_ctx *ctx, int32_t storms_per_lane)
     if (storms_per_lane < 1 || storms_per_lane > 64) return fail(ctx, "tcr_schedule_set: storms_per_lane must be in [1, 64]");
     if (storms_per_lane != ctx->storms_per_lane) ++ctx->epoch;        // captured rounds hold the launch shape
     ctx->storms_per_lane = storms_per_lane;
+    return 0;
+}
+
+int tcr_tune_set(tcr_ctx *ctx, const tcr_tune *t)
+{
+    if (!ctx || !t) return -1;
+    if (t->park > 63) return fail(ctx, "tcr_tune_set: park must be < 64");
+    ctx->tune = *t;
+    ++ctx->epoch;                  // captured rounds hold the launch shape
+    return 0;
+}
+
+int tcr_tune_get(tcr_ctx *ctx, tcr_tune *t)
+{
+    if (!ctx || !t) return -1;
+    *t = ctx->tune;
     return 0;
 }
 

@@ -232,6 +232,10 @@ __global__ __launch_bounds__(256) void k_cell_key(CellOrderArgs a)
 constexpr int kCellScanThreads = 256;
 constexpr int kCellScanRun = 64;
 constexpr int kCellScanWin = kCellScanThreads * kCellScanRun;
+// k_cell_scan's window lives in static LDS (66.6 KB): more than the 64 KB of the CDNA parts before gfx950 (160 KB per CU).
+// This library is built for gfx950 only; tcr_ctx_create refuses a device whose workgroups cannot have that much.
+constexpr size_t kCellScanLds = sizeof(int) * (kCellScanWin + 2 * kCellScanThreads + 1);
+static_assert(kCellScanLds <= 160 * 1024, "k_cell_scan's LDS window exceeds a gfx950 CU's 160 KB");
 __device__ __forceinline__ int cell_lds(int i) { return i + i / kCellScanRun; }
 __global__ __launch_bounds__(kCellScanThreads) void k_cell_scan(CellOrderArgs a)
 {
@@ -482,23 +486,42 @@ struct SeedHistArgs {
     const RoundKey *key;
     const double *cutoff;       // device scalar (a candidate index held as a double, as the survivor records hold it) or NULL
     unsigned long long *out;
+    unsigned int *partial;      // [gridDim.x][7 * 12] per-workgroup counts, then one ticket word (zero between launches)
 };
 
-__global__ __launch_bounds__(1024) void k_seed_hist(SeedHistArgs a)
+// 256-thread workgroups (a 1024-thread one — four waves per SIMD — cannot be resident next to integrator waves, DESIGN.md
+// section 9, round 4): each counts its share in LDS and publishes it; the workgroup that draws the last ticket adds
+// the published counts up and SETS out[] — one launch, nothing to zero beforehand, no atomics on out[].
+constexpr int kSeedHistBlocks = 64;
+__global__ __launch_bounds__(256) void k_seed_hist(SeedHistArgs a)
 {
-    __shared__ unsigned int h[TCR_N_BASINS * 12];
-    for (int i = threadIdx.x; i < TCR_N_BASINS * 12; i += blockDim.x) h[i] = 0;
+    constexpr int NB = TCR_N_BASINS * 12;
+    __shared__ unsigned int h[NB];
+    __shared__ bool last;
+    for (int i = threadIdx.x; i < NB; i += blockDim.x) h[i] = 0;
     __syncthreads();
     const int64_t cand0 = a.key ? a.key->cand0 : a.cand0;
     const double cut = a.cutoff ? *a.cutoff : 0.0;
-    for (int64_t i = threadIdx.x; i < a.n; i += blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
         if (!(a.seed_flags[i] & 1)) continue;
         if (a.cutoff && !((double)(cand0 + i) <= cut)) continue;
         const int b = a.basin_idx[i], m = a.slot[i];
         if (b >= 0 && b < TCR_N_BASINS && m >= 0 && m < 12) atomicAdd(&h[b * 12 + m], 1u);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < TCR_N_BASINS * 12; i += blockDim.x) a.out[i] = h[i];
+    unsigned int *ticket = a.partial + (size_t)gridDim.x * NB;
+    for (int i = threadIdx.x; i < NB; i += blockDim.x)
+        __hip_atomic_store(a.partial + (size_t)blockIdx.x * NB + i, h[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    for (int i = threadIdx.x; i < NB; i += blockDim.x) {
+        unsigned long long sum = 0;
+        for (unsigned b = 0; b < gridDim.x; ++b) sum += __hip_atomic_load(a.partial + (size_t)b * NB + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.out[i] = sum;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace tcr

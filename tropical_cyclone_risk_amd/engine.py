@@ -161,12 +161,12 @@ class TCEngine:
         tlo, tla, vp = tf(lon, lat, vpot)
         th = [_f64(vp)] + [_f64(tf(lon, lat, x)[2]) for x in (chi, mld, strat)]
         wg, tg = self._grid(wlo, wla), self._grid(tlo, tla)
-        self._ck(self.L.tcr_fields_upload(self.h, int(slot), C.byref(wg), mean_p, cov_p, C.byref(tg),
-                                          _dp(th[0]), _dp(th[1]), _dp(th[2]), _dp(th[3])))
-        if rh_mid is not None:
-            # m_init_fx is built on the uncropped grid in the reference (compute.py:111)
-            rh, rg = _f64(rh_mid), self._grid(lon, lat)
-            self._ck(self.L.tcr_rh_upload(self.h, int(slot), C.byref(rg), _dp(rh)))
+        # one call, one transfer per slot (tcr_slot_upload): the planes go to the device as they are and are interleaved there;
+        # m_init_fx is built on the uncropped grid in the reference (compute.py:111)
+        rh = _f64(rh_mid) if rh_mid is not None else None
+        rg = self._grid(lon, lat) if rh is not None else None
+        self._ck(self.L.tcr_slot_upload(self.h, int(slot), C.byref(wg), mean_p, cov_p, C.byref(tg), _dp(th[0]), _dp(th[1]), _dp(th[2]),
+                                        _dp(th[3]), C.byref(rg) if rg is not None else None, _dp(rh) if rh is not None else None))
 
     def stage_masks(self, mlon, mlat, run_mask, basin_masks):
         """land/<B>.nc indicator grids (compute.py:87-97); basin_masks: dict id -> plane."""
@@ -331,6 +331,19 @@ class TCEngine:
         throughput with many batches in flight.  Results do not depend on it."""
         self._ck(self.L.tcr_schedule_set(self.h, int(storms_per_lane)))
         return self
+
+    def tune(self, **kw):
+        """Launch-shape knobs (tcr_tune: waves, park, park_final, table_segments, prune, emit_grid_cap, copy_threads; a negative
+        value = the library's choice).  Results do not depend on them.  Returns the knobs now in effect."""
+        t = _lib.Tune()
+        self._ck(self.L.tcr_tune_get(self.h, C.byref(t)))
+        for k, v in kw.items():
+            if k not in dict(_lib.Tune._fields_) or k == 'reserved':
+                raise TypeError('unknown tuning knob %r' % k)
+            setattr(t, k, int(v))
+        if kw:
+            self._ck(self.L.tcr_tune_set(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in _lib.Tune._fields_ if k != 'reserved'}
 
     def stage_trace(self, on=True):
         self._ck(self.L.tcr_stage_trace_enable(self.h, 1 if on else 0))
