@@ -181,6 +181,10 @@ int tcr_slot_upload(tcr_ctx *ctx, int slot,
                     const tcr_grid *wg, const double *const mean[TCR_NW], const double *const cov[TCR_NCOV],
                     const tcr_grid *tg, const double *vpot, const double *chi, const double *mld, const double *strat,
                     const tcr_grid *rg, const double *rh_mid);
+/* measurement: host milliseconds the slot uploads of this context have spent since the last reset — [0] waiting for the pinned
+ * half a transfer two slots back was still reading, [1] copying planes into pinned memory, [2] enqueuing the transfer,
+ * [3] enqueuing the interleave kernel — and [4] the number of uploads */
+int tcr_stage_timing(tcr_ctx *ctx, double ms[5], int32_t reset);
 /* replaces: the land/<B>.nc interpolators f_b and f_basins (compute.py:87-97).
  * masks are uint8 0/1 planes on one global grid; run_mask is the run basin's. */
 int tcr_masks_upload(tcr_ctx *ctx, const tcr_grid *mg, const uint8_t *run_mask,

@@ -33,7 +33,7 @@ EXPORTS = ('tcr_abi_version', 'tcr_ctx_create', 'tcr_ctx_destroy', 'tcr_last_err
            'tcr_integrate_probe_host', 'tcr_integrate_f32_dev', 'tcr_integrate_f32_host', 'tcr_pack_tracks_f32_dev',
            'tcr_wind_stats_f32_dev', 'tcr_wind_stats_f32_host', 'tcr_static_upload2', 'tcr_init_m_dev', 'tcr_init_m_host', 'tcr_cell_order_dev',
            'tcr_round_dev', 'tcr_round_graph_stats', 'tcr_schedule_set', 'tcr_stage_trace_enable', 'tcr_stage_trace_sum', 'tcr_seed_hist_dev', 'tcr_pack_tracks_meta_dev',
-           'tcr_static_store', 'tcr_static_info', 'tcr_tune_set', 'tcr_tune_get', 'tcr_slot_upload')
+           'tcr_static_store', 'tcr_static_info', 'tcr_tune_set', 'tcr_tune_get', 'tcr_slot_upload', 'tcr_stage_timing')
 
 
 class Grid(C.Structure):
@@ -148,6 +148,7 @@ def lib():
     L.tcr_params_set.argtypes = [C.c_void_p, C.POINTER(Params)]
     L.tcr_static_upload.argtypes = [C.c_void_p, C.POINTER(Grid), DP, DP]
     L.tcr_static_upload2.argtypes = [C.c_void_p, C.POINTER(Grid), DP, C.POINTER(Grid), DP]
+    L.tcr_stage_timing.argtypes = [C.c_void_p, DP, C.c_int32]
     L.tcr_tune_set.argtypes = [C.c_void_p, C.POINTER(Tune)]
     L.tcr_tune_get.argtypes = [C.c_void_p, C.POINTER(Tune)]
     L.tcr_static_store.argtypes = [C.c_void_p, C.c_int32]

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <memory>
@@ -192,16 +193,14 @@ struct tcr_ctx {
     // holds the workspaces' addresses and the parameters by value)
     int storms_per_lane = 1;                    // tcr_schedule_set
     tcr_tune tune;                              // launch-shape knobs: the environment at tcr_ctx_create, then tcr_tune_set
-    // field staging: two pinned halves (the host fills one while the other crosses the link), one device landing buffer for the
-    // planes as they are, and the kernel that interleaves them into the slot layouts; nothing waits on the host until the
-    // fields are used (fields_pending)
+    // field staging: two pinned halves (the host fills one while the interleave kernel reads the other over the link); nothing
+    // waits on the host until the fields are used (fields_pending)
     double *h_stage[2] = {nullptr, nullptr};
     size_t h_stage_cap = 0;                     // doubles per half
     hipEvent_t h_stage_ev[2] = {nullptr, nullptr};
     int h_stage_next = 0;
-    double *d_stage = nullptr;
-    size_t d_stage_cap = 0;
     bool fields_pending = false;
+    double stage_ms[5] = {0, 0, 0, 0, 0};       // host time of the slot uploads: wait for the pinned half, copy, enqueue transfer, enqueue kernel; [4] calls
     std::unique_ptr<CopyPool> pool;
     RoundKey *d_round_key = nullptr;
     uint64_t epoch = 0;
@@ -554,8 +553,8 @@ __global__ __launch_bounds__(256) void k_static_widen(int mode, const void *__re
     }
 }
 
-// The planes of one month slot as they came over the link — src = 14 wind planes [nw], 4 thermo planes [nt], rh [nr] —
-// into the slot layouts of tcr_device.h: wind [point][16] (NaN -> 0: _interp_basin_field, bam_track.py:72-74; two pads),
+// The planes of one month slot — src = 14 wind planes [nw], 4 thermo planes [nt], rh [nr], in PINNED HOST memory: the
+// coalesced plane reads are the transfer — into the slot layouts of tcr_device.h: wind [point][16] (NaN -> 0: _interp_basin_field, bam_track.py:72-74; two pads),
 // thermo [point][4], rh as it is.  One thread per grid point.
 struct StageSlotArgs {
     const double *src;
@@ -1063,7 +1062,6 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     for (auto &g : ctx->graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
     (void)hipFree(ctx->d_round_key);
     for (int i = 0; i < 2; ++i) { if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]); if (ctx->h_stage_ev[i]) (void)hipEventDestroy(ctx->h_stage_ev[i]); }
-    (void)hipFree(ctx->d_stage);
     (void)hipFree(ctx->d_hist_partial); (void)hipFree(ctx->d_cell); (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_seg_sids); (void)hipFree(ctx->d_screen_skip); (void)hipFree(ctx->d_und_list); (void)hipFree(ctx->d_und_count); (void)hipFree(ctx->d_tab);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1228,17 +1226,16 @@ int slot_stage(tcr_ctx *ctx, int slot, const tcr_grid *wg, const double *const m
         }
         ctx->h_stage_cap = need;
     }
-    if (need > ctx->d_stage_cap) {
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        if (grow(ctx, &ctx->d_stage, &ctx->d_stage_cap, need)) return -1;
-    }
     if (fields && !s.wind && dev_alloc(ctx, &s.wind, nw * kWindStride)) return -1;
     if (fields && !s.thermo && dev_alloc(ctx, &s.thermo, nt * kThermoStride)) return -1;
     if (rh && !s.rh && dev_alloc(ctx, &s.rh, nr)) return -1;
     if (!ctx->pool) ctx->pool.reset(new CopyPool((ctx->tune.copy_threads > 0 ? std::min(ctx->tune.copy_threads, 16) : 4) - 1));
     const int half = ctx->h_stage_next;
     ctx->h_stage_next ^= 1;
-    HIPCHK(ctx, hipEventSynchronize(ctx->h_stage_ev[half]));           // the transfer that last read this half (long done)
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    HIPCHK(ctx, hipEventSynchronize(ctx->h_stage_ev[half]));           // the kernel that last read this half, two uploads ago (long done)
+    const double t1 = now();
     double *h = ctx->h_stage[half];
     std::vector<CopyPool::Seg> segs;
     auto add = [&](double *dst, const double *src, size_t n) {
@@ -1253,13 +1250,21 @@ int slot_stage(tcr_ctx *ctx, int slot, const tcr_grid *wg, const double *const m
     }
     if (rh) add(h + 14 * nw + 4 * nt, rh_mid, nr);
     ctx->pool->run(segs);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage, h, sizeof(double) * need, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipEventRecord(ctx->h_stage_ev[half], ctx->stream));
+    const double t2 = now();
+    // The interleave kernel reads the pinned half ITSELF, over the link (hipHostMalloc memory is mapped into the device's
+    // address space): no copy engine, no landing buffer, one stream.  A transfer followed by the kernel that consumes it makes
+    // the next transfer wait for that kernel — a copy-engine job depending on a compute-queue signal, which the runtime
+    // resolves on a host thread: inside run_downscaling that hop took 1-2 ms per slot (tools/stage_in_run_probe.py) although
+    // the 9.9 MB transfer itself takes 0.26 ms.
+    const double t3 = now();
     StageSlotArgs a{};
-    a.src = ctx->d_stage; a.nw = nw; a.nt = nt; a.nr = nr; a.wind = s.wind; a.thermo = s.thermo; a.rh = s.rh;
+    a.src = h; a.nw = nw; a.nt = nt; a.nr = nr; a.wind = s.wind; a.thermo = s.thermo; a.rh = s.rh;
     const size_t nmax = std::max(nw, std::max(nt, nr));
     hipLaunchKernelGGL(k_stage_slot, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, ctx->stream, a);
     HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->h_stage_ev[half], ctx->stream));
+    const double t4 = now();
+    ctx->stage_ms[0] += t1 - t0; ctx->stage_ms[1] += t2 - t1; ctx->stage_ms[2] += t3 - t2; ctx->stage_ms[3] += t4 - t3; ctx->stage_ms[4] += 1.0;
     if (fields) s.f32_stale = true;
     ctx->slots_dirty = true;
     ctx->fields_pending = true;
@@ -1296,6 +1301,13 @@ int tcr_rh_upload(tcr_ctx *ctx, int slot, const tcr_grid *rg, const double *rh_m
     if (slot < 0 || slot >= 4096) return fail(ctx, "tcr_rh_upload: slot out of range");
     if (!rg || !rh_mid) return fail(ctx, "tcr_rh_upload: NULL plane");
     return slot_stage(ctx, slot, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rg, rh_mid);
+}
+
+int tcr_stage_timing(tcr_ctx *ctx, double ms[5], int32_t reset)
+{
+    if (!ctx || !ms) return -1;
+    for (int i = 0; i < 5; ++i) { ms[i] = ctx->stage_ms[i]; if (reset) ctx->stage_ms[i] = 0.0; }
+    return 0;
 }
 
 int tcr_masks_upload(tcr_ctx *ctx, const tcr_grid *mg, const uint8_t *run_mask,

@@ -345,6 +345,12 @@ class TCEngine:
             self._ck(self.L.tcr_tune_set(self.h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in _lib.Tune._fields_ if k != 'reserved'}
 
+    def stage_timing(self, reset=True):
+        """Host milliseconds of this engine's slot uploads since the last reset (tcr_stage_timing)."""
+        ms = (C.c_double * 5)()
+        self._ck(self.L.tcr_stage_timing(self.h, ms, 1 if reset else 0))
+        return dict(wait_pinned_ms=ms[0], copy_ms=ms[1], enqueue_transfer_ms=ms[2], enqueue_kernel_ms=ms[3], uploads=int(ms[4]))
+
     def stage_trace(self, on=True):
         self._ck(self.L.tcr_stage_trace_enable(self.h, 1 if on else 0))
 

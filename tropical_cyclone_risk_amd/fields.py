@@ -392,7 +392,8 @@ def write_reference_files(env, out_dir, year, nl=None, calendar='standard', last
             put(f, 'lat', glat, ('lat',)); put(f, 'lon', glon, ('lon',))
             put(f, var, arr, ('lat', 'lon'))
     files['basin_dir'] = out_dir + '/land'
-    mlon, mlat = getattr(env, 'mlon', env.hlon), getattr(env, 'mlat', env.hlat)
+    mlon, mlat = getattr(env, 'mlon', None), getattr(env, 'mlat', None)
+    mlon, mlat = (env.hlon if mlon is None else mlon), (env.hlat if mlat is None else mlat)
     for b, m in env.basin_masks.items():
         with new('%s/land/%s.nc' % (out_dir, b), dict(lat=len(mlat), lon=len(mlon))) as f:
             put(f, 'lat', mlat, ('lat',)); put(f, 'lon', mlon, ('lon',))
