@@ -204,27 +204,42 @@ def test_run_downscaling_writes_reference_schema(golden_env, built_lib, tmp_path
 
 @pytest.mark.gpu
 def test_run_tracks_from_reference_files(golden_env, built_lib, tmp_path):
-    """fields written in the reference's file schema and read back through
-    fields.load_year_env drive run_tracks to the tracks the in-memory fields give."""
+    """SURVEY section 8 f-1, the at-GPU test of the file path: fields written in the reference's file schema and read back
+    through fields.FileEnvironment (util/compute.py:64-121: time interpolation to the 15th, PI_reduc, the chi transform,
+    climatologies regridded; coupled_fast.py:217-225) drive run_tracks —
+
+      * the LOADED fields equal the in-memory ones to 1e-14 relative (the files hold vmax without the PI factor and chi before
+        its transform, and the 15th is reached by interp1d's slope formula: ~1e-15, not bit for bit);
+      * the GPU on the loaded fields against the ORACLE on the SAME loaded fields (round 4 compared the GPU with
+        itself on two field sets whose last bits differ, and had to accept forked trajectories): the sequential loop of
+        oracle/run_tracks.py keeps the same candidates, months, basins and n_seeds, and every kept track is compared pointwise
+        over its whole length through parity.check_tracks with the replayer — full tiers."""
     import copy
+    from oracle import run_tracks as RT
     from tropical_cyclone_risk_amd import compute, fields, namelist
     from tropical_cyclone_risk_amd.basins import TC_Basin
+    from tropical_cyclone_risk_amd.engine import TCEngine
     env = copy.copy(golden_env)
     files = fields.write_reference_files(env, str(tmp_path), 2004, namelist)
-    loaded = fields.FileEnvironment(namelist, files)
-    b = TC_Basin('NA')
-    ref = compute.run_tracks(2004, 8, b, env=env, per_rank=4096)
-    got = compute.run_tracks(2004, 8, b, env=loaded.for_year(2004), per_rank=4096)
-    # The files hold vmax without the PI factor and chi before its transform, and the 15th is reached by
-    # interp1d's slope formula, so the fields agree to ~1e-15 — not bit for bit.  Seeds and accept decisions
-    # are the same; a track whose RK step sequence flips on such a perturbation differs at the integrator's
-    # own tolerance, the others agree closely.
-    assert got[0].shape == ref[0].shape
-    assert np.array_equal(got[6], ref[6]) and list(got[7]) == list(ref[7]) and np.array_equal(got[8], ref[8])
-    close = [np.allclose(np.nan_to_num(got[0][i]), np.nan_to_num(ref[0][i]), rtol=0, atol=1e-6) and
-             np.allclose(np.nan_to_num(got[2][i]), np.nan_to_num(ref[2][i]), rtol=0, atol=1e-6) for i in range(8)]
-    assert sum(close) >= 6, close
-    assert np.nanmax(np.abs(got[0] - ref[0])) < 0.5 and np.nanmax(np.abs(got[2] - ref[2])) < 2.0
+    loaded = fields.FileEnvironment(namelist, files).for_year(2004)
+    for name in ('wnd_mean', 'wnd_cov', 'vpot', 'chi', 'mld', 'strat', 'rh_mid', 'land', 'bathy'):
+        a, b = np.asarray(getattr(loaded, name), dtype=np.float64), np.asarray(getattr(env, name), dtype=np.float64)
+        assert a.shape == b.shape, name
+        assert np.abs(a - b).max() <= 1e-14 * max(1.0, np.abs(b).max()), (name, np.abs(a - b).max())
+    for name in ('lon', 'lat', 'wlon', 'wlat', 'hlon', 'hlat'):
+        assert np.array_equal(getattr(loaded, name), getattr(env, name)), name
+    for k in env.basin_masks:
+        assert np.array_equal(np.asarray(loaded.basin_masks[k]) > 0.5, np.asarray(env.basin_masks[k]) > 0.5), k
+    eng = TCEngine('NA', device=0).stage_env(loaded)
+    info = {}
+    got = compute.run_tracks(2004, 24, TC_Basin('NA'), engine=eng, per_rank=4096, info=info)
+    ref = RT.run_tracks(loaded, 'NA', 2004, 24, int(namelist.gpu_experiment_seed))
+    r = ref['tuple9']
+    assert np.array_equal(info['cand'], ref['cand'])
+    assert np.array_equal(got[6], r[6]) and list(got[7]) == list(r[7]) and np.array_equal(got[8], r[8])
+    s = _rows_vs_sequential_oracle('run_tracks-from-files', eng, loaded, 'NA', 2004, info['cand'], got, ref)
+    eng.close()
+    assert s['pointwise'] == 24
 
 
 @pytest.mark.gpu

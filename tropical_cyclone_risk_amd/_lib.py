@@ -159,7 +159,7 @@ def lib():
     L.tcr_fields_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Grid), C.POINTER(DP), C.POINTER(DP),
                                     C.POINTER(Grid), DP, DP, DP, DP]
     L.tcr_rh_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Grid), DP]
-    L.tcr_slot_upload.argtypes = L.tcr_fields_upload.argtypes + [C.POINTER(Grid), DP]
+    L.tcr_slot_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Grid), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(Grid)] + [C.c_void_p] * 4 + [C.POINTER(Grid), C.c_void_p]
     L.tcr_masks_upload.argtypes = [C.c_void_p, C.POINTER(Grid), U8P, C.POINTER(U8P)]
     L.tcr_integrate_host.argtypes = [C.c_void_p, C.POINTER(Storms), C.POINTER(Tracks)]
     L.tcr_integrate_probe_host.argtypes = [C.c_void_p, C.POINTER(Storms), C.POINTER(Tracks), C.c_void_p, C.c_int32]

@@ -61,10 +61,14 @@ class TC_Basin:
         """Column / row selection of `transform_global_field` for one pair of axes: (lon_b, lat_b, ix, iy, sx, sy) with ix / iy
         the source columns / rows in output order and sx / sy the equivalent slices when they are contiguous runs (else None).
         Cached per axes: a year's 216 planes share two or three grids."""
+        cache = self.__dict__.setdefault('_plans', [])
+        for c_lon, c_lat, plan, o_lon, o_lat in cache:           # the very same axis objects: no comparison at all
+            if o_lon is lon and o_lat is lat:
+                return plan
+        o_lon, o_lat = lon, lat
         lon = np.asarray(lon)
         lat = np.asarray(lat)
-        cache = self.__dict__.setdefault('_plans', [])
-        for c_lon, c_lat, plan in cache:
+        for c_lon, c_lat, plan, _, _ in cache:
             if c_lon.shape == lon.shape and c_lat.shape == lat.shape and np.array_equal(c_lon, lon) and np.array_equal(c_lat, lat):
                 return plan
         x0, y0, x1, y1 = self.get_bounds()
@@ -85,7 +89,7 @@ class TC_Basin:
         def as_slice(i):
             return slice(int(i[0]), int(i[-1]) + 1) if i.size and np.array_equal(i, np.arange(i[0], i[0] + i.size)) else None
         plan = (rot[keep_x], lat[keep_y], ix, iy, as_slice(ix), as_slice(iy))
-        cache.append((lon.copy(), lat.copy(), plan))
+        cache.append((lon.copy(), lat.copy(), plan, o_lon, o_lat))
         if len(cache) > 16:
             del cache[0]
         return plan
@@ -96,10 +100,16 @@ class TC_Basin:
         field is [lat, lon]; returns (lon_b, lat_b, field_b) (basins.py:57-75).  The selection is computed once per pair of
         axes; a plane whose selection is a contiguous block comes back as a view of `field` (no copy).
         """
+        plan = self._crop_plan(lon, lat)
+        return plan[0], plan[1], self._apply_plan(plan, field)
+
+    @staticmethod
+    def _apply_plan(plan, field):
+        """The selection of `_crop_plan` applied to one [lat, lon] plane."""
         field = np.asarray(field)
-        lon_b, lat_b, ix, iy, sx, sy = self._crop_plan(lon, lat)
+        _, _, ix, iy, sx, sy = plan
         if sx is not None and sy is not None:
-            return lon_b, lat_b, field[sy, sx]
+            return field[sy, sx]
         if sy is not None:
-            return lon_b, lat_b, field[sy][:, ix]
-        return lon_b, lat_b, field[iy][:, ix]
+            return field[sy][:, ix]
+        return field[iy][:, ix]

@@ -149,24 +149,34 @@ class TCEngine:
         """One month's field set: `_load_wnd_stat` (bam_track.py:76-91) + `init_fields`
         (coupled_fast.py:217-225).  wnd_mean [4,nlat,nlon]; wnd_cov packed lower triangle
         [10,nlat,nlon]; thermo planes [nlat,nlon] on the global grid."""
-        tf = self.basin.transform_global_field
-        planes = []
-        wlo = wla = None
-        for k in range(4):
-            wlo, wla, x = tf(wlon, wlat, wnd_mean[k]); planes.append(_f64(x))
-        for k in range(10):
-            _, _, x = tf(wlon, wlat, wnd_cov[k]); planes.append(_f64(x))
-        mean_p = (_lib.DP * 4)(*[_dp(x) for x in planes[:4]])
-        cov_p = (_lib.DP * 10)(*[_dp(x) for x in planes[4:]])
-        tlo, tla, vp = tf(lon, lat, vpot)
-        th = [_f64(vp)] + [_f64(tf(lon, lat, x)[2]) for x in (chi, mld, strat)]
-        wg, tg = self._grid(wlo, wla), self._grid(tlo, tla)
+        # (the selection of transform_global_field is looked up once per grid, not once per plane; raw addresses instead of
+        # typed ctypes pointers: 25 ctypes.cast calls per slot were a third of a slot's host time)
+        wplan, tplan = self.basin._crop_plan(wlon, wlat), self.basin._crop_plan(lon, lat)
+        crop = self.basin._apply_plan
+        planes = [_f64(crop(wplan, wnd_mean[k])) for k in range(4)] + [_f64(crop(wplan, wnd_cov[k])) for k in range(10)]
+        th = [_f64(crop(tplan, x)) for x in (vpot, chi, mld, strat)]
+        addr = lambda a: a.__array_interface__['data'][0]
+        mean_p = (C.c_void_p * 4)(*[addr(x) for x in planes[:4]])
+        cov_p = (C.c_void_p * 10)(*[addr(x) for x in planes[4:]])
+        wg, tg = self._grid_cached(wplan[0], wplan[1]), self._grid_cached(tplan[0], tplan[1])
         # one call, one transfer per slot (tcr_slot_upload): the planes go to the device as they are and are interleaved there;
         # m_init_fx is built on the uncropped grid in the reference (compute.py:111)
         rh = _f64(rh_mid) if rh_mid is not None else None
-        rg = self._grid(lon, lat) if rh is not None else None
-        self._ck(self.L.tcr_slot_upload(self.h, int(slot), C.byref(wg), mean_p, cov_p, C.byref(tg), _dp(th[0]), _dp(th[1]), _dp(th[2]),
-                                        _dp(th[3]), C.byref(rg) if rg is not None else None, _dp(rh) if rh is not None else None))
+        rg = self._grid_cached(lon, lat) if rh is not None else None
+        self._ck(self.L.tcr_slot_upload(self.h, int(slot), C.byref(wg), mean_p, cov_p, C.byref(tg), addr(th[0]), addr(th[1]), addr(th[2]),
+                                        addr(th[3]), C.byref(rg) if rg is not None else None, addr(rh) if rh is not None else None))
+
+    def _grid_cached(self, lon, lat):
+        """tcr_grid of a pair of axes, kept while the same axis arrays come again (a year's twelve slots share them)."""
+        cache = self.__dict__.setdefault('_grids', [])
+        for a, b, g in cache:
+            if a is lon and b is lat:
+                return g
+        g = self._grid(lon, lat)
+        cache.append((lon, lat, g))
+        if len(cache) > 8:
+            del cache[0]
+        return g
 
     def stage_masks(self, mlon, mlat, run_mask, basin_masks):
         """land/<B>.nc indicator grids (compute.py:87-97); basin_masks: dict id -> plane."""
