@@ -107,6 +107,12 @@ def test_ensemble_vs_c_oracle(engines, golden_env, basin, n, seed):
     storms = synthetic.draw_storm_inputs(n, basin, seed=seed)
     eng = engines(basin)
     got = eng.integrate(storms, probe_cap=PROBE_CAP)
+    # one storm in 10 000 needs more accepted RK steps than the default step record holds (65 > gpu_max_rk_steps = 64; SciPy
+    # is unbounded): the library reports it (status -3) and the product's accept loop doubles the record and integrates the
+    # round again (compute.accept_loop, tests/test_configs.py::test_step_record_grows_instead_of_aborting) — so does this test
+    while (got['status'] == -3).any():
+        assert basin == 'NA' and (got['status'] == -3).sum() <= 2 and eng.grow_step_record()
+        got = eng.integrate(storms, probe_cap=PROBE_CAP)
     ref = c_oracle.run_ensemble(golden_env, basin, storms, probe=True)
     s = _check('oracle-' + basin, got, ref, eng.t_s, c_oracle.replayer(golden_env, basin, storms),
                counters=('status', 'n_valid', 'nfev', 'n_accept', 'n_reject'))
