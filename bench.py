@@ -78,9 +78,12 @@ def main():
                     help='HBM bytes per integrate launch from a separate rocprofv3 --pmc pass (see profiles/)')
     ap.add_argument('--dtype', choices=('f64', 'f32'), default='f64',
                     help='f32: the fp32 variant of the path (BASELINE config 5): fp32 fields / state / RHS / rows, fp64 time and controller')
-    ap.add_argument('--static-res', type=float, default=0.25, choices=(0.25, 0.125),
-                    help='grid of the synthetic land / bathymetry planes: 0.25 (SURVEY.md section 8d) or 0.125 = the grid and '
-                         "type of the reference's own intensity/data/land.nc (int8, 1440 x 2880)")
+    ap.add_argument('--static-res', type=float, default=0.125, choices=(0.25, 0.125),
+                    help='grid of the synthetic land / bathymetry planes: 0.125 (default since round 5) = the grid and type of the '
+                         "reference's own intensity/data/land.nc (int8, 1440 x 2880); 0.25 = SURVEY.md section 8d's float64 planes "
+                         '(rounds 1-4)')
+    ap.add_argument('--shape', choices=('era5', 'gfdl'), default='era5',
+                    help='era5: 1-degree wind = thermo grid; gfdl: 2 x 2.5 degree wind grid, 1 x 1.25 degree thermo grid (BASELINE config 5)')
     ap.add_argument('--bathy-kind', choices=('i16', 'f32', 'f64'), default=None,
                     help='what the synthetic bathymetry holds (default: f64 at 0.25 degrees, whole metres at 0.125)')
     ap.add_argument('--static-store', choices=('auto', 'f64'), default='auto',
@@ -125,7 +128,7 @@ def main():
     dev = torch.device('cuda', local)
     year = 2000
 
-    env = synthetic.make_env('era5', static_res=args.static_res, bathy_kind=args.bathy_kind)
+    env = synthetic.make_env(args.shape, static_res=args.static_res, bathy_kind=args.bathy_kind)
     from tropical_cyclone_risk_amd import namelist as _nl
     _nl.gpu_static_store = args.static_store
     n_str = max(1, args.streams)
@@ -290,6 +293,7 @@ def main():
     # (704 B x RHS evaluations of that launch) over its HIP-event duration
     # (events recorded on the launch stream by the library).  The per-sample share of the
     # algorithmic bytes (520 B x output samples) is k_emit's and is reported next to it.
+    static_tag = '%g/%s' % (args.static_res, args.static_store)
     launches = ms['calls']
     have_events = launches > 0
     if have_events:
@@ -303,7 +307,7 @@ def main():
         gpu_active_s = (ms['fourier_ms'] + ms['integrate_ms'] + ms['post_ms']) * 1e-3
     else:
         gpu_active_s = (iso['fourier_ms'] + iso['integrate_ms'] + iso['post_ms']) / iso['calls'] * args.steps * 1e-3
-    traffic, traffic_src = (args.traffic, 'command line') if args.traffic is not None else measured_traffic('k_integrate', args.storms if world == 1 else B, args.rows, args.dtype, args.order)
+    traffic, traffic_src = (args.traffic, 'command line') if args.traffic is not None else measured_traffic('k_integrate', args.storms if world == 1 else B, args.rows, args.dtype, args.order, static_tag, args.shape)
     # Exclusive duration: the same launch, one batch at a time on one stream right after the timed region
     # (3 batches).  With several streams the event-bracketed duration of a launch in the timed region
     # includes time it shared the GPU with other batches (it can exceed ms_per_step), so that figure is
@@ -312,7 +316,7 @@ def main():
     ib = BYTES_PER_RHS * iso_counts[1] / iso['calls']
     eb = BYTES_PER_SAMPLE * (iso_counts[5] if args.rows == 'tc' else iso_counts[2]) / iso['calls']
     achieved = ib / (ik * 1e-3) / 1e9
-    e_traffic, e_src = measured_traffic('k_emit', args.storms if world == 1 else B, args.rows, args.dtype, args.order)
+    e_traffic, e_src = measured_traffic('k_emit', args.storms if world == 1 else B, args.rows, args.dtype, args.order, static_tag, args.shape)
     roof = dict(bound='hbm', kernel='k_integrate', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
                 frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                 note='a launch = the chain of k_integrate passes of one batch (tail compaction); achieved = %d B x RHS ' % BYTES_PER_RHS +
@@ -355,7 +359,7 @@ def main():
     roof['step_algorithmic'] = dict(achieved=alg_gbs, unit='GB/s', peak=HBM_PEAK_GBS, frac=alg_gbs / HBM_PEAK_GBS,
                                     note='(%d B x RHS evaluations + %d B x emitted samples) of the timed region / its wall time, per GPU'
                                          % (BYTES_PER_RHS, BYTES_PER_SAMPLE))
-    step_bytes, step_src = measured_traffic('*', args.storms, args.rows, args.dtype, args.order) if world == 1 else (None, None)
+    step_bytes, step_src = measured_traffic('*', args.storms, args.rows, args.dtype, args.order, static_tag, args.shape) if world == 1 else (None, None)
     if step_bytes and world == 1:
         gbs = step_bytes / (dt / args.steps) / 1e9
         ceil_gbs, ceil_src = scattered_line_fill_ceiling()
@@ -389,12 +393,14 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'gpu_active_s': gpu_active_s,
-            'config': {'workload': '%s basin, %s, synthetic ERA5-shaped monthly fields '
-                                   '(1 deg thermo/wind, %s deg land/bathymetry), 15-day tracks, hourly output, '
+            'config': {'workload': '%s basin, %s, synthetic %s monthly fields '
+                                   '(%s deg land/bathymetry), 15-day tracks, hourly output, '
                                    'device-side seeding, %s; %s' % (args.basin, (
                                        'one ensemble of %d candidates (%.0f storms pass on average) per step, sharded over %d GPU(s), '
                                        'accepted tracks all-gathered once per ensemble' % (C_ens, storms_total / args.steps, world)) if strong
-                                       else '%d storms per GPU per step' % B, '%g' % args.static_res, 'fp64' if args.dtype == 'f64' else 'fp32 fields/state/RHS/rows with fp64 time and step controller', (
+                                       else '%d storms per GPU per step' % B,
+                                       'ERA5-shaped (1 deg thermo / wind)' if args.shape == 'era5' else 'GFDL-shaped (2 x 2.5 deg wind, 1 x 1.25 deg thermo)',
+                                       '%g' % args.static_res, 'fp64' if args.dtype == 'f64' else 'fp32 fields/state/RHS/rows with fp64 time and step controller', (
                                        'env winds, vmax and rows only for storms that pass accept test 1, as the reference '
                                        'does (compute.py:190-204)' if args.rows == 'tc' else 'rows for every integrated storm')),
                        'static_fields': dict(zip(('storage', 'bytes'), eng.static_info()), resolution_deg=args.static_res),
@@ -456,13 +462,15 @@ def scattered_line_fill_ceiling():
     return None, None
 
 
-def measured_traffic(kernel, storms, rows, dtype='f64', order='cells'):
+def measured_traffic(kernel, storms, rows, dtype='f64', order='cells', static='0.125/auto', shape='era5'):
     """(HBM bytes per batch, source) of a kernel from the committed rocprofv3 --pmc runs of this same workload
     (tools/collect_profiles.sh; counters are collected in separate passes from timing, as MI355X_MICROARCH.md
     prescribes, so they cannot be measured inside this process).  Only valid for the profiled size."""
-    fn = next((f for f in (os.path.join(ROOT, 'profiles', 'r04_pmc_hbm.json'), os.path.join(ROOT, 'profiles', 'r03_pmc_hbm.json')) if os.path.exists(f)), '')
+    # (the file of the same static-field configuration: r05 = 0.125 degrees, narrow storage; r04 = 0.25 degrees, fp64 planes)
+    fn = next((f for f in (os.path.join(ROOT, 'profiles', n) for n in ('r05_pmc_hbm.json', 'r05_pmc_hbm_res0.25.json', 'r04_pmc_hbm.json'))
+               if os.path.exists(f) and json.load(open(f)).get('static', '0.25/f64').replace('0.25/auto', '0.25/f64') == static.replace('0.25/auto', '0.25/f64')), '')
     tag = 'profiles/' + os.path.basename(fn)
-    if storms != 100_000 or dtype != 'f64' or not fn:
+    if storms != 100_000 or dtype != 'f64' or shape != 'era5' or not fn:
         return None, None
     try:
         d = json.load(open(fn))
@@ -498,7 +506,7 @@ def cpu_baseline(host, args):
         try:
             env1 = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
             r = subprocess.run([sys.executable, '-m', 'oracle.cpu_baseline', '--inputs', fn, '--basin', args.basin,
-                                '--budget', str(args.cpu_budget), '--static-res', str(args.static_res)] +
+                                '--budget', str(args.cpu_budget), '--static-res', str(args.static_res), '--shape', args.shape] +
                                (['--bathy-kind', args.bathy_kind] if args.bathy_kind else []), cwd=ROOT, capture_output=True, text=True,
                                timeout=600, env=env1)
             res = json.loads(r.stdout.strip().splitlines()[-1])

@@ -1,0 +1,54 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): everything under profiles/r05_* except the static-field probes (tools/r05_static_probe.sh).
+#   bash tools/collect_r05.sh
+# Timing (kernel-trace / stats) and counters (--pmc) are separate rocprofv3 runs, as MI355X_MICROARCH.md prescribes.
+set -u
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+OUT=gpurun_out/r05
+rm -rf "$OUT"; mkdir -p "$OUT"
+B="timeout 900 python bench.py"
+# 1. the bench line: the driver's flags, the script's own defaults, and the static-field shape of rounds 1-4 for continuity
+$B --steps 20 --warmup 5 2>"$OUT/bench.err" | tail -1 > "$OUT/bench_driver_flags.json"
+$B --no-cpu-baseline 2>>"$OUT/bench.err" | tail -1 > "$OUT/bench.json"
+$B --steps 20 --warmup 5 --no-cpu-baseline --static-res 0.25 --static-store f64 2>>"$OUT/bench.err" | tail -1 > "$OUT/bench_res0.25_f64.json"
+$B --steps 20 --warmup 5 --no-cpu-baseline --static-store f64 2>>"$OUT/bench.err" | tail -1 > "$OUT/bench_res0.125_f64.json"
+# 2. BASELINE config 5's speed claims from current code: fp32, ERA5-shaped and GFDL-shaped (two grids); fp64 GFDL-shaped next to it
+$B --steps 20 --warmup 5 --no-cpu-baseline --dtype f32 2>>"$OUT/bench.err" | tail -1 > "$OUT/bench_f32.json"
+$B --steps 20 --warmup 5 --no-cpu-baseline --dtype f32 --shape gfdl 2>>"$OUT/bench.err" | tail -1 > "$OUT/bench_f32_gfdl.json"
+$B --steps 20 --warmup 5 --no-cpu-baseline --shape gfdl 2>>"$OUT/bench.err" | tail -1 > "$OUT/bench_f64_gfdl.json"
+# 3. small batches (a rank's share of a sharded 100 000-storm ensemble at N = 2 / 4 / 8)
+for S in 50000 25000 12500; do
+  $B --no-cpu-baseline --scaling weak --storms $S --streams 16 --steps 240 --warmup 32 2>/dev/null | tail -1 > "$OUT/bench_small_$S.json"
+done
+# 4. per-kernel timing, one stream and the default twelve
+for s in 1 12; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats$s" -o s -- \
+      python bench.py --steps 10 --warmup 2 --streams $s --no-cpu-baseline > /dev/null 2>&1
+  cp "$(find "$OUT/stats$s" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_streams$s.csv"
+  rm -rf "$OUT/stats$s"
+done
+# 5. HBM-side counters, one pass per counter group (single stream so dispatches do not overlap)
+i=0
+for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $C -d "$OUT/pmc$i" -o p -- \
+      python bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > /dev/null 2>&1
+done
+python tools/summarize_pmc.py "$OUT" tc 0.125/auto > "$OUT/pmc_hbm.json"
+rm -rf "$OUT"/pmc[123]
+# 6. the product surface: BASELINE config 3's shape through run_downscaling, and where a month slot's staging time goes
+timeout 600 python tools/run_config3.py > "$OUT/config3.json" 2>/dev/null
+{ timeout 300 python tools/stage_probe.py GL; timeout 300 python tools/stage_probe.py NA; timeout 300 python tools/stage_burst_probe.py; timeout 300 python tools/stage_in_run_probe.py | grep -v "Saved\|^[0-9]"; } > "$OUT/stage_probes.txt" 2>/dev/null
+lscpu | grep -E "Model name|^CPU\(s\)|Thread|Core|Socket" > "$OUT/host_cpu.txt"
+timeout 300 python tools/pass_stats.py > "$OUT/integrate_pass_stats.txt" 2>&1
+python - <<PY
+import json, glob
+for f in sorted(glob.glob('$OUT/bench*.json')):
+    try:
+        d = json.load(open(f)); r = d['roofline']
+        print('%-40s %.4g storm-steps/s  %.4f ms/step  chain %.3f ms  frac %.3f  step_alg %.3f' % (f.split('/')[-1], d['value'], d['ms_per_step'], r['launch_ms'], r['frac'], r['step_algorithmic']['frac']))
+    except Exception as e:
+        print(f, 'failed', e)
+PY
+ls "$OUT"

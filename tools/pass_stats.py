@@ -5,7 +5,7 @@ from tropical_cyclone_risk_amd import synthetic
 from tropical_cyclone_risk_amd.engine import TCEngine
 from tropical_cyclone_risk_amd.pipeline import DevicePipeline
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
-env = synthetic.make_env('era5', seed=20250614)
+env = synthetic.make_env('era5', seed=20250614, static_res=0.125)
 eng = TCEngine('GL', device=0).stage_env(env)
 pipe = DevicePipeline(eng, int(5.6 * B), B)
 pipe.seed_round(2005, 0); pipe.select_passed(B)

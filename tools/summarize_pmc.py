@@ -56,6 +56,7 @@ for k, e in res.items():
 tot = sum(e.get('hbm_bytes_per_batch', 0.0) for e in res.values())
 tot_raw = sum(e.get('hbm_bytes_per_batch_raw', 0.0) for e in res.values())
 rows = sys.argv[2] if len(sys.argv) > 2 else 'tc'
+static = sys.argv[3] if len(sys.argv) > 3 else '0.125/auto'       # --static-res / --static-store of the profiled runs
 command = ('rocprofv3 --kernel-trace --output-format csv --pmc <FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum> -- '
            'python bench.py --steps 3 --warmup 1 --streams 1 --rows %s --no-cpu-baseline (three separate runs)' % rows)
 meta = dict(workload='GL, 100000 storms per batch; the first batch of each run pads whole plane rows (pad_state = -1)',
@@ -66,5 +67,5 @@ meta = dict(workload='GL, 100000 storms per batch; the first batch of each run p
                  'line once, 4x the Infinity Cache): 1.9986; streaming reads 2.0000.  WRITE_SIZE is exact for coalesced stores (1 GiB fill) '
                  'and over-reports scattered 112-of-128-B line writes by 1.24x.  *_raw = FETCH_SIZE + WRITE_SIZE uncorrected.  '
                  'Infinity-Cache hits are counted, so this is fabric-side traffic.')
-print(json.dumps(dict(command=command, rows=rows, order='cells', meta=meta, step_total=dict(hbm_bytes_per_batch=tot, hbm_bytes_per_batch_raw=tot_raw,
+print(json.dumps(dict(command=command, rows=rows, order='cells', static=static, meta=meta, step_total=dict(hbm_bytes_per_batch=tot, hbm_bytes_per_batch_raw=tot_raw,
                                                                           note='sum over the tcr:: kernels of one bench step'), kernels=res), indent=1))
