@@ -108,6 +108,35 @@ def _write_netcdf3(fn, data, coords, skip=()):
     return offsets
 
 
+_STREAMING_OK = None
+
+
+def _streaming_supported():
+    """`_write_netcdf3(skip=...)` leans on scipy internals (netcdf_file._write_var_data / _pack_begin, netcdf_variable._begin /
+    _vsize: stable since scipy 0.9, but private — ADVICE r4).  Checked ONCE on a scratch file: a two-track layout written with
+    its row variables skipped and then filled by hand must be byte for byte the file written whole; if scipy has changed
+    underneath, the streaming writer is not used and `TrackFileWriter` falls back to `write_tracks` at close."""
+    global _STREAMING_OK
+    if _STREAMING_OK is None:
+        import io as _io
+        try:
+            n, ns = 2, 3
+            coords = dict(n_trk=np.arange(n), time=np.linspace(0, 2.0, ns), year=np.array([2000]), basin=np.array(BASIN_IDS), month=np.arange(1, 13))
+            data = {k: np.arange(n * ns, dtype=np.float64).reshape(n, ns) + j for j, k in enumerate(TWO_D)}
+            data.update(tc_month=np.ones(n), tc_years=np.full(n, 2000, np.int32), tc_basins=np.array(['NA'] * n),
+                        seeds_per_month=np.ones((1, len(BASIN_IDS), 12)))
+            whole, holes = _io.BytesIO(), _io.BytesIO()
+            _write_netcdf3(_NoClose(whole), data, coords)
+            off = _write_netcdf3(_NoClose(holes), data, coords, skip=frozenset(TWO_D))
+            for k in TWO_D:
+                holes.seek(off[k])
+                holes.write(np.asarray(data[k], dtype='>f8').tobytes())
+            _STREAMING_OK = sorted(off) == sorted(TWO_D) and holes.getvalue() == whole.getvalue()
+        except Exception:
+            _STREAMING_OK = False
+    return _STREAMING_OK
+
+
 class TrackFileWriter:
     """The track file of `write_tracks`, written while the years are still being computed.
 
@@ -124,7 +153,7 @@ class TrackFileWriter:
         self.years, self.b, self.nl, self.out_dir = list(years), b, nl, out_dir
         self.per_year = int(nl.tracks_per_year)
         self.out = [None] * len(self.years)
-        self.streaming = _try_xarray() is None and self.per_year > 0
+        self.streaming = _try_xarray() is None and self.per_year > 0 and _streaming_supported()
         self.fn, self._err = None, None
         if not self.streaming:
             return
