@@ -27,7 +27,7 @@ def pct(x, qs=(50, 90, 99, 99.9, 100)):
 
 
 def landfall(env, basin, lon, lat, n_valid):
-    """First sample of each track that lies over land (nearest 0.25-degree cell of the land mask)."""
+    """First sample of each track that lies over land (nearest cell of the land mask)."""
     hl, ha = np.asarray(env.hlon), np.asarray(env.hlat)
     i = np.clip(np.rint((np.nan_to_num(lon) % 360.0 - hl[0]) / (hl[1] - hl[0])).astype(int), 0, hl.size - 1)
     j = np.clip(np.rint((np.nan_to_num(lat) - ha[0]) / (ha[1] - ha[0])).astype(int), 0, ha.size - 1)
@@ -42,7 +42,7 @@ def study(shape, basin, B, year):
     from tropical_cyclone_risk_amd import synthetic
     from tropical_cyclone_risk_amd.engine import TCEngine
     from tropical_cyclone_risk_amd.pipeline import DevicePipeline
-    env = synthetic.make_env(shape)
+    env = synthetic.make_env(shape, static_res=0.125)      # the reference's static-field shape (round 5)
     eng = TCEngine(basin, device=0).stage_env(env)
     out = {}
     res = {}
