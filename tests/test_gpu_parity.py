@@ -560,7 +560,19 @@ def test_parity_study_at_scale(golden_env, built_lib):
         # (the integrator's own tolerance is rtol = 1e-3)
         assert qd['p99.9'] <= max(1e-6, 10 * qu['p99.9']), (basin, qd, qu)
         assert int((d > 1e-6).sum()) <= 3 * int((u > 1e-6).sum()) + 3 and qd['max'] <= 1e-4, (basin, qd, qu, int((d > 1e-6).sum()), int((u > 1e-6).sum()))
-        out[basin] = dict(summary={k: v for k, v in s.items() if not isinstance(v, dict)}, worst=s['worst'], d_gpu=qd, d_ulp=qu,
+        # ... and storm by storm (round 5): every storm above 1e-7 is one the oracle itself amplifies — its difference at most
+        # parity.TWIN_FACTOR x what the oracle moves on THAT storm under a one-ulp change of one input (three twins walking the
+        # same decision sequence, c_oracle.replayer.twin_storms): the rule the other tests apply to every sample, here at scale
+        rp = c_oracle.replayer(golden_env, basin, storms)
+        big = np.nonzero(d > P.TOL_ALL_FLOOR)[0]
+        ratios = []
+        if len(big):
+            tw = rp.twin_storms(big, np.ascontiguousarray(got['dec'][big]))['traj']
+            ratios = [(int(i), float(d[i]), float(t), float(d[i] / t) if t > 0 else float('inf')) for i, t in zip(big, tw)]
+            print(basin, 'storms above 1e-7 (index, d, own twin, ratio):', ratios)
+            assert all(r[3] <= P.TWIN_FACTOR for r in ratios), (basin, ratios)
+        out[basin] = dict(summary={k: v for k, v in s.items() if not isinstance(v, (dict, list))}, worst=s['worst'], d_gpu=qd, d_ulp=qu,
+                          storms_over_1e7_vs_their_own_twin=[dict(storm=r[0], d_gpu=r[1], own_twin=r[2], ratio=r[3]) for r in ratios],
                           d_gpu_replayed_storms=qr, d_gpu_envw=qo['envw'], d_gpu_vmax=qo['vmax'],
                           storms_over_1e9=int((d > 1e-9).sum()), oracle_twins_over_1e9=int((u > 1e-9).sum()),
                           storms_over_1e6=int((d > 1e-6).sum()), oracle_twins_over_1e6=int((u > 1e-6).sum()),
