@@ -159,7 +159,8 @@ int tcr_static_upload2(tcr_ctx *ctx, const tcr_grid *land_grid, const double *la
  * bathymetry in [-16384, 16383] on one grid -> one uint16 per grid point (mode 2); land in 0 .. 255 and a bathymetry that
  * round-trips through float32 -> a uint8 and a float plane (mode 3); anything else the fp64 planes of pref 1 (mode 0, or 1
  * on two grids).  The kernels widen to the same doubles before any arithmetic, so results do not depend on the mode.
- * Call before tcr_static_upload*.  tcr_static_info reports the mode in use and the bytes the planes occupy. */
+ * Call before tcr_static_upload*.  tcr_static_info reports the mode in use and the bytes the planes occupy.
+ * A context may be re-staged with other planes (the mode is chosen again) — not while launches that read them are in flight. */
 int tcr_static_store(tcr_ctx *ctx, int32_t pref);
 int tcr_static_info(tcr_ctx *ctx, int32_t *mode, int64_t *bytes);
 /* replaces: BetaAdvectionTrack._load_wnd_stat (bam_track.py:76-91) +

@@ -2204,6 +2204,7 @@ int tcr_tune_set(tcr_ctx *ctx, const tcr_tune *t)
 {
     if (!ctx || !t) return -1;
     if (t->park > 63) return fail(ctx, "tcr_tune_set: park must be < 64");
+    if (t->copy_threads != ctx->tune.copy_threads) ctx->pool.reset();       // (the next slot upload starts the pool it asks for)
     ctx->tune = *t;
     ++ctx->epoch;                  // captured rounds hold the launch shape
     return 0;
