@@ -157,7 +157,8 @@ int tcr_static_upload2(tcr_ctx *ctx, const tcr_grid *land_grid, const double *la
  * (intensity/geo.py:15-19, 29-33) — its own land.nc is int8 0 / 1 on a 0.125-degree grid (1440 x 2880).  With pref 0 (auto,
  * the default) an upload inspects the VALUES and stores them narrow when that is exact: land 0 / 1 and whole-metre
  * bathymetry in [-16384, 16383] on one grid -> one uint16 per grid point (mode 2); land in 0 .. 255 and a bathymetry that
- * round-trips through float32 -> a uint8 and a float plane (mode 3); anything else the fp64 planes of pref 1 (mode 0, or 1
+ * round-trips through float32 -> eight bytes per grid point on one grid (mode 4), a uint8 and a float plane on two (mode 3);
+ * anything else the fp64 planes of pref 1 (mode 0, or 1
  * on two grids).  The kernels widen to the same doubles before any arithmetic, so results do not depend on the mode.
  * Call before tcr_static_upload*.  tcr_static_info reports the mode in use and the bytes the planes occupy.
  * A context may be re-staged with other planes (the mode is chosen again) — not while launches that read them are in flight. */

@@ -15,7 +15,7 @@ TCR_NW, TCR_NCOV, TCR_MAX_SERIES, TCR_N_BASINS = 4, 10, 32, 7
 STATUS_GATED, STATUS_FINISHED, STATUS_EVENT, STATUS_STEP_FAIL, STATUS_STEP_OVERFLOW = -1, 0, 1, -2, -3
 FLAG_IS_TC, FLAG_ACCEPTED = 1, 2
 STAGES = ('start', 'seed', 'select', 'order', 'gather', 'fourier', 'integrate', 'screen', 'select_tc', 'dense', 'emit', 'flags', 'stats', 'pack')
-STATIC_MODES = ('f64', 'f64_split', 'pack16', 'u8_f32')     # StaticMode (tcr_static_info)
+STATIC_MODES = ('f64', 'f64_split', 'pack16', 'u8_f32', 'pack64')     # StaticMode (tcr_static_info)
 N_STATS = 10        # TCR_N_STATS: words of a tcr_stats_dev / tcr_round.stats counter block
 
 DP = C.POINTER(C.c_double)

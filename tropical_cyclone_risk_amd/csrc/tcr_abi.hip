@@ -519,6 +519,7 @@ void launch_integrate_rp(const KArgsT<R> &a, bool affine, int sm, unsigned waves
         case kStatF64Split: TCR_LI(true, kStatF64Split); break;
         case kStatPack16: TCR_LI(true, kStatPack16); break;
         case kStatU8F32: TCR_LI(true, kStatU8F32); break;
+        case kStatPack64: TCR_LI(true, kStatPack64); break;
         default: TCR_LI(true, kStatF64); break;
         }
     } else if (sm == kStatF64Split) TCR_LI(false, kStatF64Split);
@@ -546,6 +547,11 @@ __global__ __launch_bounds__(256) void k_static_widen(int mode, const void *__re
         const unsigned v = reinterpret_cast<const uint16_t *>(nstat)[i];
         stat[2 * i] = (double)(int)(v & 1u);
         stat[2 * i + 1] = (double)((int)(v >> 1) - kPack16Bias);
+    } else if (mode == kStatPack64) {
+        if (i >= n_land) return;
+        const uint64_t v = reinterpret_cast<const uint64_t *>(nstat)[i];
+        stat[2 * i] = (double)(int)((v >> 32) & 0xffu);
+        stat[2 * i + 1] = (double)__uint_as_float((unsigned)v);
     } else {
         // (stat != NULL: one shared grid, interleaved; else two planes)
         if (i < n_land) { const double v = (double)reinterpret_cast<const uint8_t *>(nstat)[i]; if (stat) stat[2 * i] = v; else land[i] = v; }
@@ -631,7 +637,7 @@ int ensure_f32(tcr_ctx *ctx, hipStream_t st)
         s.f32_stale = false;
         ctx->slots_dirty = true;
     }
-    if (ctx->stat32_stale && ctx->static_mode != kStatPack16 && ctx->static_mode != kStatU8F32) {
+    if (ctx->stat32_stale && (ctx->static_mode == kStatF64 || ctx->static_mode == kStatF64Split)) {
         if (ctx->split_static) {
             if (conv(ctx->d_land, &ctx->d_land32, nh / kStaticStride)) return -1;
             if (conv(ctx->d_bathy, &ctx->d_bathy32, ctx->bg.lon.size() * ctx->bg.lat.size())) return -1;
@@ -676,7 +682,7 @@ void host_eval_k(const tcr_ctx *ctx, EvalKT<R> &K, bool *all_affine)
         K.stat = f64 ? static_cast<const void *>(ctx->d_land) : static_cast<const void *>(ctx->d_land32);
         K.bathy = f64 ? static_cast<const void *>(ctx->d_bathy) : static_cast<const void *>(ctx->d_bathy32);
         break;
-    case kStatPack16: K.stat = ctx->d_nstat; K.bathy = nullptr; break;
+    case kStatPack16: case kStatPack64: K.stat = ctx->d_nstat; K.bathy = nullptr; break;
     case kStatU8F32: K.stat = ctx->d_nstat; K.bathy = ctx->d_nbathy; break;
     default:
         K.stat = f64 ? static_cast<const void *>(ctx->d_stat) : static_cast<const void *>(ctx->d_stat32);
@@ -685,7 +691,7 @@ void host_eval_k(const tcr_ctx *ctx, EvalKT<R> &K, bool *all_affine)
     }
     eval_k_scalars<R>(ctx->prm, K);
     K.tw_same = (ctx->wg.lon == ctx->tg.lon && ctx->wg.lat == ctx->tg.lat) ? 1 : 0;       // same knots: the same cells and weights
-    K.pad_ = 0;
+    K.hb_same = ctx->split_static ? 0 : 1;
     *all_affine = K.wx.affine && K.wy.affine && K.tx.affine && K.ty.affine && K.hx.affine && K.hy.affine &&
                   K.bx.affine && K.by.affine;
 }
@@ -696,7 +702,7 @@ void host_eval_k(const tcr_ctx *ctx, EvalKT<R> &K, bool *all_affine)
 int widen_static(tcr_ctx *ctx, hipStream_t st)
 {
     const int mode = ctx->static_mode;
-    if (mode != kStatPack16 && mode != kStatU8F32) return 0;
+    if (mode != kStatPack16 && mode != kStatU8F32 && mode != kStatPack64) return 0;
     const size_t np = ctx->hg.lon.size() * ctx->hg.lat.size();
     const size_t nb = ctx->split_static ? ctx->bg.lon.size() * ctx->bg.lat.size() : np;
     if (ctx->split_static) { if (dev_alloc(ctx, &ctx->d_land, np) || dev_alloc(ctx, &ctx->d_bathy, nb)) return -1; }
@@ -718,7 +724,7 @@ template <typename R>
 int eval_k_ready(tcr_ctx *ctx, EvalKT<R> &K, bool *affine, hipStream_t st)
 {
     host_eval_k<R>(ctx, K, affine);
-    if (!*affine && (ctx->static_mode == kStatPack16 || ctx->static_mode == kStatU8F32)) {
+    if (!*affine && (ctx->static_mode == kStatPack16 || ctx->static_mode == kStatU8F32 || ctx->static_mode == kStatPack64)) {
         if (widen_static(ctx, st)) return -1;
         if (!std::is_same<R, double>::value && ensure_f32(ctx, st)) return -1;
         host_eval_k<R>(ctx, K, affine);
@@ -1148,6 +1154,7 @@ int tcr_static_upload2(tcr_ctx *ctx, const tcr_grid *lg, const double *land, con
     int mode = shared ? kStatF64 : kStatF64Split;
     if (ctx->static_pref == 0) {
         if (shared && land_u8 && land01 && bathy_f32 && bathy_i15) mode = kStatPack16;
+        else if (shared && land_u8 && bathy_f32) mode = kStatPack64;
         else if (land_u8 && bathy_f32) mode = kStatU8F32;
     }
     // a context may be re-staged with other planes (another mode, even): start from nothing
@@ -1164,6 +1171,19 @@ int tcr_static_upload2(tcr_ctx *ctx, const tcr_grid *lg, const double *land, con
         ctx->d_nstat = d;
         HIPCHK(ctx, copy_sync(ctx->stream, d, h.data(), sizeof(uint16_t) * h.size(), hipMemcpyHostToDevice));
         ctx->static_bytes = sizeof(uint16_t) * np;
+    } else if (mode == kStatPack64) {
+        std::vector<uint64_t> h(np + 2, 0);
+        for (size_t i = 0; i < np; ++i) {
+            const float b = (float)bathy[i];
+            uint32_t bits;
+            memcpy(&bits, &b, 4);
+            h[i] = (uint64_t)bits | ((uint64_t)(uint8_t)(int)land[i] << 32);
+        }
+        uint64_t *d = nullptr;
+        if (dev_alloc(ctx, &d, h.size())) return -1;
+        ctx->d_nstat = d;
+        HIPCHK(ctx, copy_sync(ctx->stream, d, h.data(), sizeof(uint64_t) * h.size(), hipMemcpyHostToDevice));
+        ctx->static_bytes = sizeof(uint64_t) * np;
     } else if (mode == kStatU8F32) {
         std::vector<uint8_t> hl(np + 8, 0);
         std::vector<float> hb(nb + 4, 0.f);
@@ -1692,6 +1712,7 @@ int tcr_probe_rhs_host(tcr_ctx *ctx, int slot, double h_bl, const double *Fs, in
     const int sm = ctx->static_mode;
     if (affine && sm == kStatPack16) PROBE_RHS(true, kStatPack16);
     else if (affine && sm == kStatU8F32) PROBE_RHS(true, kStatU8F32);
+    else if (affine && sm == kStatPack64) PROBE_RHS(true, kStatPack64);
     else if (affine && sm == kStatF64) PROBE_RHS(true, kStatF64);
     else if (affine) PROBE_RHS(true, kStatF64Split);
     else if (sm == kStatF64) PROBE_RHS(false, kStatF64);
@@ -1719,6 +1740,7 @@ int init_m_launch(tcr_ctx *ctx, const tcr_storms *in, double dvdt, double *m_out
     const int sm = ctx->static_mode;
     if (affine && sm == kStatPack16) INIT_M(true, kStatPack16);
     else if (affine && sm == kStatU8F32) INIT_M(true, kStatU8F32);
+    else if (affine && sm == kStatPack64) INIT_M(true, kStatPack64);
     else if (affine && sm == kStatF64) INIT_M(true, kStatF64);
     else if (affine) INIT_M(true, kStatF64Split);
     else if (sm == kStatF64) INIT_M(false, kStatF64);

@@ -39,7 +39,7 @@ constexpr double kPi = 3.141592653589793;
 constexpr int kWindStride = 16;     // 14 fields + 2 pad  -> one 128-B (fp64) / 64-B (fp32) line per grid point
 constexpr int kThermoStride = 4;    // vpot, chi, mld, strat
 constexpr int kStaticStride = 2;    // land, bathy
-enum StaticMode { kStatF64 = 0, kStatF64Split = 1, kStatPack16 = 2, kStatU8F32 = 3 };
+enum StaticMode { kStatF64 = 0, kStatF64Split = 1, kStatPack16 = 2, kStatU8F32 = 3, kStatPack64 = 4 };
 constexpr int kPack16Bias = 16384;  // kStatPack16: stored = (bathymetry + bias) * 2 + land
 constexpr int kStepHdr = 4;         // accepted-step record: doubles t_old, h, t_new, - ; then R y_old[4], K[7][4]
 constexpr int kStepBody = 32;
@@ -101,7 +101,10 @@ struct EvalKT {
     //   kStatPack16   one grid, `stat` = [lat][lon] uint16 = ((int)bathymetry + 16384) * 2 + land: exact when land is 0 / 1 and
     //                 the bathymetry is whole metres in [-16384, 16383] (ETOPO / GEBCO); the two lon-adjacent corners of a
     //                 row are ONE 4-byte gather;
-    //   kStatU8F32    `stat` = the land plane as uint8 (values 0 .. 255, the reference's int8 land.nc) on (hx, hy), `bathy` a
+    //   kStatPack64   one grid, `stat` = [lat][lon] 8 bytes: the bathymetry as float32, then the land value as a byte (3 pad bytes):
+    //                 exact when land is in 0 .. 255 and every bathymetry value round-trips through float32; a row's two corners
+    //                 are ONE 16-byte gather;
+    //   kStatU8F32    two grids: `stat` = the land plane as uint8 (values 0 .. 255, the reference's int8 land.nc) on (hx, hy), `bathy` a
     //                 float plane on (bx, by) (exact when every value round-trips through float32); a row's two corners are
     //                 one 2-byte and one 8-byte gather.
     // The narrow forms hold exactly the values the fp64 planes would: the kernels widen them to R before FITPACK's arithmetic.
@@ -113,7 +116,7 @@ struct EvalKT {
     double total_time, tstep, inv_tstep;        // time stays fp64 in both instantiations
     int n_steps, coupled_track;
     int tw_same;             // the thermo grid IS the wind grid (ERA5: both 1 degree): one cell search serves both
-    int pad_;
+    int hb_same;             // land and bathymetry share one grid (bx / by == hx / hy): kStatU8F32 searches the cell once
 };
 using EvalK = EvalKT<double>;
 
@@ -484,6 +487,12 @@ __device__ __forceinline__ uint32_t ldg_u32_pair_u16(const uint16_t *p)
     typedef uint32_t u32_a2 __attribute__((aligned(2)));
     return *(const __attribute__((address_space(1))) u32_a2 *)(p);
 }
+__device__ __forceinline__ uint4 ldg_pair_u64(const uint64_t *p)
+{
+    typedef uint32_t u4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+    const u4_a8 v = *(const __attribute__((address_space(1))) u4_a8 *)(p);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
 __device__ __forceinline__ float2 ldg_pair_f32(const float *p)
 {
     typedef float f2_a4 __attribute__((ext_vector_type(2), aligned(4)));
@@ -512,6 +521,7 @@ struct StaticLookup {
     CornersT<R, 1, 1> CL, CB;               // kStatF64Split
     uint32_t p0, p1;                        // kStatPack16: rows y0 / y1, elements (x0, x1); kStatU8F32: the land bytes likewise
     float2 b0, b1;                          // kStatU8F32: bathymetry rows y0 / y1
+    uint4 q0, q1;                           // kStatPack64: rows y0 / y1, (bathymetry bits, land) of x0 then of x1
     __device__ __forceinline__ void issue(const EvalKT<R> &K, R lon, R lat)
     {
         hx = locate_t<R, AFFINE>(K.hx, lon); hy = locate_t<R, AFFINE>(K.hy, lat);
@@ -523,8 +533,13 @@ struct StaticLookup {
             const int nl = RD(K.hx.n);
             const uint16_t *q = reinterpret_cast<const uint16_t *>(RD(K.stat)) + ((size_t)hy.i * nl + hx.i);
             p0 = ldg_u32_pair_u16(q); p1 = ldg_u32_pair_u16(q + nl);
+        } else if (SM == kStatPack64) {
+            const int nl = RD(K.hx.n);
+            const uint64_t *q = reinterpret_cast<const uint64_t *>(RD(K.stat)) + ((size_t)hy.i * nl + hx.i);
+            q0 = ldg_pair_u64(q); q1 = ldg_pair_u64(q + nl);
         } else if (SM == kStatU8F32) {
-            bx = locate_t<R, AFFINE>(K.bx, lon); by = locate_t<R, AFFINE>(K.by, lat);
+            bx = hx; by = hy;
+            if (!RD(K.hb_same)) { bx = locate_t<R, AFFINE>(K.bx, lon); by = locate_t<R, AFFINE>(K.by, lat); }      // wave-uniform
             const int nl = RD(K.hx.n), nb = RD(K.bx.n);
             const uint8_t *q = reinterpret_cast<const uint8_t *>(RD(K.stat)) + ((size_t)hy.i * nl + hx.i);
             const float *f = reinterpret_cast<const float *>(RD(K.bathy)) + ((size_t)by.i * nb + bx.i);
@@ -547,6 +562,9 @@ struct StaticLookup {
             lb[0] = blend4<R>((R)(int)(c00 & 1u), (R)(int)(c01 & 1u), (R)(int)(c10 & 1u), (R)(int)(c11 & 1u), hx, hy);
             lb[1] = blend4<R>((R)((int)(c00 >> 1) - kPack16Bias), (R)((int)(c01 >> 1) - kPack16Bias),
                               (R)((int)(c10 >> 1) - kPack16Bias), (R)((int)(c11 >> 1) - kPack16Bias), hx, hy);
+        } else if (SM == kStatPack64) {
+            lb[0] = blend4<R>((R)(int)(q0.y & 0xffu), (R)(int)(q1.y & 0xffu), (R)(int)(q0.w & 0xffu), (R)(int)(q1.w & 0xffu), hx, hy);
+            lb[1] = blend4<R>((R)__uint_as_float(q0.x), (R)__uint_as_float(q1.x), (R)__uint_as_float(q0.z), (R)__uint_as_float(q1.z), hx, hy);
         } else if (SM == kStatU8F32) {
             lb[0] = blend4<R>((R)(int)(p0 & 0xffu), (R)(int)(p1 & 0xffu), (R)(int)((p0 >> 8) & 0xffu), (R)(int)((p1 >> 8) & 0xffu), hx, hy);
             lb[1] = blend4<R>((R)b0.x, (R)b1.x, (R)b0.y, (R)b1.y, bx, by);
