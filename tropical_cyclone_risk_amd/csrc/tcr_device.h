@@ -16,7 +16,7 @@
 //
 // Performance shape of one evaluation of fun(t, y) (the unit everything is made of):
 // all six cell searches are pure ALU on affine grids, then the gathers (fp64: 28 wind, 4 forcing
-// table, 8 thermo, 4 land/bathymetry 16-byte loads; fp32: 16 + 2 + 4 16-byte and 4 8-byte) are
+// table, 8 thermo, 4 land/bathymetry 16-byte loads — 2 narrow ones with the exact narrow static storage, StaticLookup —; fp32: 16 + 2 + 4 16-byte and 4 8-byte) are
 // independent of each other and are issued back to back — ONE memory round trip per evaluation —
 // and the rest is straight-line math with selects instead of branches, so the
 // lanes of a wave never diverge inside an evaluation.
