@@ -190,7 +190,8 @@ class TCEngine:
     def stage_env(self, env, months=range(12)):
         """Stage a ``synthetic.SyntheticEnv``-shaped object (12 monthly field sets).  The static planes (land, bathymetry,
         basin masks) do not change from year to year: they are staged again only when the environment hands over other
-        arrays than the ones already on the device."""
+        arrays than the ones already on the device.  The test is object IDENTITY (`is`), not content: an array modified in
+        place must be staged explicitly (`stage_static` / `stage_masks`, which also reset this shortcut)."""
         blon, blat = getattr(env, 'blon', None), getattr(env, 'blat', None)
         static = (env.hlon, env.hlat, env.land, env.bathy, blon, blat)
         if not self._same(getattr(self, '_staged_static', None), static):
