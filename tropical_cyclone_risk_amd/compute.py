@@ -73,7 +73,8 @@ def accept_loop(round_fn, n_tracks, per_rank, n_steps, max_rounds=10000, ops=Non
     and the collective; the loop synchronises with the host ONCE per round — to read the per-rank (count,
     overflow) pairs that size the all-gather — and the result is copied to the host once, at the end.
     Returns dict(rows [n_tracks, 9*n_steps], month, basin_idx, cand, n_seeds [7, 12], rounds); every rank
-    returns the same result.  ops: the collectives (default: the process group's, `distributed`; `distributed.Local` when
+    returns the same result.  (With a GpuRound, `rows` is a view of its pinned host buffer: valid until that round function's next
+    accept_loop — `rows_to_tuple` copies what it keeps.)  ops: the collectives (default: the process group's, `distributed`; `distributed.Local` when
     this rank works the whole year on its own).  device_result: nothing is copied to the host — the return value is
     dict(rows_dev [n_tracks, 9*n_steps + 3] (records + candidate index, month, basin index), n_seeds_dev [7*12], rounds), both on
     the round function's device (year-sharded runs keep a year's tracks in HBM until the all-gather of final tracks).
