@@ -86,6 +86,8 @@ def main():
                     help='era5: 1-degree wind = thermo grid; gfdl: 2 x 2.5 degree wind grid, 1 x 1.25 degree thermo grid (BASELINE config 5)')
     ap.add_argument('--bathy-kind', choices=('i16', 'f32', 'f64'), default=None,
                     help='what the synthetic bathymetry holds (default: f64 at 0.25 degrees, whole metres at 0.125)')
+    ap.add_argument('--bathy-res', type=float, default=None, choices=(0.25, 0.125),
+                    help='put the bathymetry on its own grid (two independent interpolators, intensity/geo.py:9-34); default: the land grid')
     ap.add_argument('--static-store', choices=('auto', 'f64'), default='auto',
                     help='auto: exact narrow storage of land / bathymetry where the values allow it (tcr_static_upload); '
                          'f64: the fp64 planes of rounds 1-4')
@@ -129,6 +131,10 @@ def main():
     year = 2000
 
     env = synthetic.make_env(args.shape, static_res=args.static_res, bathy_kind=args.bathy_kind)
+    if args.bathy_res is not None and args.bathy_res != args.static_res:
+        import dataclasses
+        e2 = synthetic.make_env(args.shape, static_res=args.bathy_res, bathy_kind=args.bathy_kind or ('i16' if args.static_res == 0.125 else 'f64'))
+        env = dataclasses.replace(env, bathy=e2.bathy, blon=e2.hlon, blat=e2.hlat)
     from tropical_cyclone_risk_amd import namelist as _nl
     _nl.gpu_static_store = args.static_store
     n_str = max(1, args.streams)
