@@ -64,6 +64,8 @@ def main():
     ap.add_argument('--stage-trace', action='store_true', help='record a HIP event behind every stage of every (directly enqueued) round of '
                     'the timed region and report the per-stage stream time under load (tcr_stage_trace_*; implies --graph off)')
     ap.add_argument('--staged', action='store_true', help="round 3's step: one library call per stage instead of tcr_round_dev")
+    ap.add_argument('--dup-seed', type=int, default=1, help=argparse.SUPPRESS)
+    ap.add_argument('--dup-select', type=int, default=1, help=argparse.SUPPRESS)
     ap.add_argument('--basin', default='GL')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--order', choices=('cells', 'candidate'), default='cells',
@@ -192,8 +194,12 @@ def main():
         graph = use_graph if graph is None else graph
         cand0 = D.round_block(k, C, rank, world)                       # = k * C * world + rank * C
         if args.staged:
-            pipe.seed_round(year, cand0)
-            pipe.select_passed(B)
+            # (--dup-seed / --dup-select: run a stage several times — same inputs, same outputs — to read its marginal cost in
+            # the pipelined step off the difference; measurement aid)
+            for _ in range(args.dup_seed):
+                pipe.seed_round(year, cand0)
+            for _ in range(args.dup_select):
+                pipe.select_passed(B)
             pipe.integrate(B, n_dev=pipe.n_passed if strong else None)
             pipe.add_stats(acc, n_dev=pipe.n_passed)
             if gather is not None:
