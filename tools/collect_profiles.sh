@@ -1,4 +1,5 @@
 #!/bin/bash
+# Rounds 2-4 (round 5: tools/collect_r05.sh + tools/r05_static_probe.sh).
 # Runs on the GPU box (gpurun): regenerates everything under profiles/ for one round tag.
 #   bash tools/collect_profiles.sh r02 [tc|all]
 # Timing (kernel-trace/stats) and counters (--pmc) are separate rocprofv3 runs, as MI355X_MICROARCH.md prescribes.
