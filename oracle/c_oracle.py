@@ -39,7 +39,8 @@ class _Params(C.Structure):
                 ('atol', C.c_double), ('max_step', C.c_double),
                 ('v_thresh', C.c_double), ('v_2d_thresh', C.c_double),
                 ('vmax_thresh', C.c_double), ('earth_R', C.c_double),
-                ('n_series', C.c_int), ('n_steps', C.c_int)]
+                ('n_series', C.c_int), ('n_steps', C.c_int),
+                ('coupled_track', C.c_int), ('steering_coefs', C.c_double * 2)]
 
 
 def build(force=False):
@@ -77,8 +78,9 @@ def c_params(prm=None):
     for k in ('Ck', 'epsilon', 'kappa', 'u_beta', 'v_beta', 'T_Fs', 'dt_out', 'total_time',
               'rtol', 'atol', 'max_step', 'v_thresh', 'v_2d_thresh', 'vmax_thresh'):
         setattr(p, k, float(getattr(prm, k)))
-    for k in ('y_alpha', 'm_alpha', 'alpha_max', 'alpha_min'):
+    for k in ('y_alpha', 'm_alpha', 'alpha_max', 'alpha_min', 'steering_coefs'):
         setattr(p, k, (C.c_double * 2)(*getattr(prm, k)))
+    p.coupled_track = 1 if prm.coupled_track else 0
     p.earth_R = 6.3781e6
     p.n_series = prm.N_series
     p.n_steps = prm.n_steps

@@ -53,6 +53,8 @@ class Params:
     m_alpha: tuple = (0.0025, -0.0025)
     alpha_max: tuple = (0.41, 0.78)
     alpha_min: tuple = (0.22, 0.59)
+    coupled_track: bool = True            # namelist.py:72
+    steering_coefs: tuple = (0.2, 0.8)    # namelist.py:71 (used when not coupled_track)
     dt_out: float = 3600.0
     total_time: float = 15 * 86400.0
     rtol: float = 1e-3
@@ -169,6 +171,8 @@ class Storm:
     # -- coupled_fast.py:183-192
     def steering(self, v):
         p = self.prm
+        if not p.coupled_track:
+            return np.array(p.steering_coefs)
         a = (v * KT_PER_MS) * np.array(p.m_alpha) + np.array(p.y_alpha)
         a = np.maximum(np.minimum(a, p.alpha_max), p.alpha_min)
         if np.any(np.isnan(a)):

@@ -60,6 +60,8 @@ typedef struct {
     double dt_out, total_time, rtol, atol, max_step;
     double v_thresh, v_2d_thresh, vmax_thresh, earth_R;
     int n_series, n_steps;
+    int coupled_track;                /* namelist.py:72; 0: constant steering_coefs (coupled_fast.py:190-191) */
+    double steering_coefs[2];         /* namelist.py:71 */
 } orc_params;
 
 /* ------------------------------------------------------------------ bilinear */
@@ -243,9 +245,11 @@ typedef struct {
     long n_hard;            /* differing decisions at evaluations that are NOT rounding-sensitive */
 } orc_storm;
 
+/* coupled_fast.py:183-192 */
 static void steering(const orc_params *p, double v, double *c)
 {
     int bad = 0;
+    if (!p->coupled_track) { c[0] = p->steering_coefs[0]; c[1] = p->steering_coefs[1]; return; }
     for (int k = 0; k < 2; k++) {
         double a = (v * 1.94384) * p->m_alpha[k] + p->y_alpha[k];
         a = (a != a) ? a : (a < p->alpha_max[k] ? a : p->alpha_max[k]);

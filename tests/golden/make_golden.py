@@ -65,9 +65,12 @@ def classify(ref, f, inp, res):
     return tags or ['other']
 
 
-def run_set(ref, env, basin, n_scan, seed, per_class, extra=()):
-    """Scan random seeds, keep a class-balanced subset, return fixture arrays."""
+def run_set(ref, env, basin, n_scan, seed, per_class, extra=(), mutate=None):
+    """Scan random seeds, keep a class-balanced subset, return fixture arrays.
+    mutate (make_golden_namelist.py): callable applied to the drawn storm inputs before they are handed to the reference."""
     S = synthetic.draw_storm_inputs(n_scan, basin, seed)
+    if mutate is not None:
+        mutate(S)
     fast = {}
     keep, counts = [], {}
     cands = [dict(lon=S['lon'][i], lat=S['lat'][i], month=int(S['month'][i]), v0=S['v0'][i],

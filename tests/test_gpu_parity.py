@@ -85,6 +85,29 @@ def test_tracks_vs_reference_golden(engines, golden_env, basin):
     assert s['exposed'] == int((c_oracle.run_ensemble(golden_env, basin, _storms(g), post=False)['flicker'] > 0).sum())
 
 
+@pytest.mark.parametrize('case', ['uncoupled', 'physics'])
+def test_tracks_vs_reference_golden_namelist_variations(golden_env, built_lib, case):
+    """The kernel's uncoupled-steering branch (tcr_device.h rhs_track: namelist.coupled_track = False -> steering_coefs,
+    coupled_fast.py:190-191) and the physics scalars that reach the kernels through tcr_params (u_beta, v_beta, Ck,
+    v_2d_thresh; PI_reduc through the staged PI; atm_bl_depth through h_bl), against tracks the reference itself produced
+    with those namelist values (tests/golden/make_golden_namelist.py) — same bar as the default-namelist golden sets."""
+    from oracle import c_oracle
+    from tests.test_oracle_golden import namelist_case
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    g, prm, env = namelist_case(golden_env, case)
+    if case == 'uncoupled':
+        nl = _namelist_with(coupled_track=False, steering_coefs=[float(x) for x in g['nl_steering_coefs']])
+    else:
+        nl = _namelist_with(u_beta=float(g['nl_u_beta']), v_beta=float(g['nl_v_beta']), Ck=float(g['nl_Ck']),
+                            PI_reduc=float(g['nl_PI_reduc']), seed_v_2d_threshold_ms=float(g['nl_seed_v_2d_threshold_ms']))
+    eng = TCEngine('NA', device=0, nl=nl).stage_env(env)
+    out = eng.integrate(_storms(g), probe_cap=PROBE_CAP)
+    t_s = eng.t_s
+    eng.close()
+    s = _check('golden-' + case, out, g, t_s, c_oracle.replayer(env, 'NA', _storms(g), prm=prm), tol_95=1e-10)
+    assert s['n'] == len(g['status']) >= 24          # (status, n_valid, nfev, is_tc, accepted are part of the check)
+
+
 @pytest.mark.parametrize('name,slot', [('NA', 8), ('SI', 1)])
 def test_rhs_vs_reference_golden(engines, name, slot):
     g = np.load(os.path.join(GOLDEN, 'rhs_%s.npz' % name))

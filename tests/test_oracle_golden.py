@@ -328,3 +328,49 @@ def test_oracles_vs_reference_on_its_static_shape():
     tags = ','.join(g['tags'])
     for needed in ('full', 'dissipated', 'basin_exit', 'gated', 'v0_le_4', 'land', 'shelf', 'chol_fail'):
         assert needed in tags, needed
+
+
+def namelist_case(golden_env, case):
+    """tests/golden/tracks_NA_<case>.npz (make_golden_namelist.py: the reference run with non-default namelist physics):
+    the fixture, the oracle Params and the environment it was produced on."""
+    import copy
+    from oracle import scipy_port as P
+    g = np.load(os.path.join(GOLDEN, 'tracks_NA_%s.npz' % case))
+    if case == 'uncoupled':
+        prm = P.Params(coupled_track=bool(g['nl_coupled_track']), steering_coefs=tuple(g['nl_steering_coefs']))
+        env = golden_env
+    else:
+        prm = P.Params(u_beta=float(g['nl_u_beta']), v_beta=float(g['nl_v_beta']), Ck=float(g['nl_Ck']),
+                       v_2d_thresh=float(g['nl_seed_v_2d_threshold_ms']))
+        env = copy.copy(golden_env)
+        env.vpot = golden_env.vpot * float(g['vpot_scale'])      # PI_reduc * sqrt(Ck / Cd) relative to the default namelist's
+    return g, prm, env
+
+
+@pytest.mark.parametrize('case', ['uncoupled', 'physics'])
+def test_oracles_reproduce_reference_namelist_variations(golden_env, case):
+    """namelist.coupled_track = False (constant steering_coefs, coupled_fast.py:190-191) and a set of non-default physics
+    scalars (u_beta, v_beta, Ck, PI_reduc, seed_v_2d_threshold_ms, atm_bl_depth): both oracles against the reference's own
+    tracks, and a negative control — the default Params do NOT reproduce them."""
+    from oracle import c_oracle as CO, parity, scipy_port as P
+    g, prm, env = namelist_case(golden_env, case)
+    assert str(g['meta_scipy']) == '1.15.3'
+    storms = _storms(g)
+    if case == 'physics':
+        assert set(storms['h_bl']) <= {1600.0, 1700.0, 1800.0, 2000.0, 2200.0}      # namelist.atm_bl_depth values + 200 m
+    o = P.run_ensemble(env, 'NA', storms, prm=prm)
+    for k in ('status', 'n_valid', 'nfev', 'is_tc', 'accepted'):
+        assert np.array_equal(o[k], g[k]), k
+    for k in ('traj', 'envw', 'vmax'):
+        assert _maxdiff(o[k], g[k]) <= 1e-12, k
+    c = CO.run_ensemble(env, 'NA', storms, prm=prm, probe=True)
+    dec_ref = parity.ragged_to_padded(g['dec'], g['dec_off'], CO.PROBE_CAP)
+    t0_ref = parity.ragged_to_padded(g['dec_t0'], g['dec_off'], CO.PROBE_CAP, fill=np.nan, dtype=np.float64)
+    s = parity.check_tracks('c-oracle-' + case, c, g, c['dec'], dec_ref, t0_ref, np.linspace(0, 15 * 86400.0, 361),
+                            replay=CO.replayer(env, 'NA', storms, prm=prm), replay_as='got', tol_95=1e-10)
+    assert s['pointwise'] == s['n'] and s['unreplayed'] == 0 and s['hard_mismatch'] == 0
+    assert np.array_equal(c['is_tc'], g['is_tc']) and np.array_equal(c['accepted'], g['accepted'])
+    # negative control: the default namelist's oracle is far from these tracks
+    d = CO.run_ensemble(golden_env, 'NA', storms, post=False)
+    far = np.abs(np.nan_to_num(d['traj']) - np.nan_to_num(g['traj'])).reshape(len(g['status']), -1).max(axis=1)
+    assert (far[g['n_valid'] > 24] > 1e-3).mean() > 0.9
