@@ -311,7 +311,10 @@ int tcr_pack_tracks_meta_dev(tcr_ctx *ctx, const tcr_tracks *src_dev, int32_t f3
 /* replaces: `n_seeds[basin_idx, month - 1] += 1` (compute.py:165-167) for a finished round of candidates: out_dev[7][12]
  * (int64, SET) = candidates [cand0, cand0 + cand_dev->n) that count toward n_seeds (seed_flags bit 0) per (genesis basin,
  * month); with cutoff_dev (device scalar, a candidate index held as a double as the survivor records hold it) only the
- * candidates with global index <= *cutoff_dev — the candidate that completed the quota. */
+ * candidates with global index <= *cutoff_dev — the candidate that completed the quota.
+ * One stream per context: the reduction goes through a scratch block (partial counts + a ticket word) the CONTEXT owns, like
+ * every workspace of the integrator, so two calls of the same context — this one or a tcr_round_dev with seed_hist — must be
+ * enqueued on the same stream (or ordered by events); calls of different contexts are independent. */
 int tcr_seed_hist_dev(tcr_ctx *ctx, const tcr_seeds *cand_dev, int64_t cand0, const double *cutoff_dev,
                       int64_t *out_dev, void *stream);
 

@@ -72,7 +72,7 @@ def test_single_process_matches_sequential(per_rank):
     assert np.array_equal(res['n_seeds'], n_seeds)
 
 
-@pytest.mark.parametrize('world,per_rank', [(2, 64), (2, 150)])
+@pytest.mark.parametrize('world,per_rank', [(2, 64), (2, 150), (4, 37), (8, 16)])
 def test_gloo_ranks_match_sequential(world, per_rank):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -80,9 +80,9 @@ def test_gloo_ranks_match_sequential(world, per_rank):
     procs = [ctx.Process(target=_worker, args=(r, world, port, per_rank, 25, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(world)]
+    got = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     rows, cands, n_seeds = sequential(25)
     for rank, r_rows, r_cand, r_seeds, rounds in got:

@@ -86,3 +86,43 @@ def test_run_py_through_rccl_on_one_rank(built_lib, tmp_path, shard_years):
     for k in ('lon_trks', 'lat_trks', 'v_trks', 'm_trks', 'vmax_trks', 'u250_trks', 'v850_trks', 'tc_month', 'tc_basins', 'tc_years', 'seeds_per_month'):
         assert np.array_equal(out['plain'][k], out['forced'][k], equal_nan=(out['plain'][k].dtype.kind == 'f')), k
     assert out['plain']['lon_trks'].shape == (72, 361)
+
+
+def _bench_cmd(n, *flags, timeout=1500):
+    """`python bench.py --gpus N ...` exactly as the driver types it for N = 1 — no launcher: bench.py starts its N ranks itself
+    (self_launch).  TCR_DIST_BACKEND=gloo lets the ranks share this box's one GPU."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '4', '--warmup', '1', '--storms', '12000'] + list(flags)
+    r = subprocess.run(cmd, env=_env(TCR_DIST_BACKEND='gloo'), cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, 'exactly one JSON line on stdout (rank 0), got %d' % len(lines)
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_launcherless_bench_at_2_4_8_ranks(built_lib):
+    """the command shape the driver runs (`python bench.py --gpus N --steps K --warmup W`, no launcher), at every
+    rank count of the scaling table, with the N > 1 defaults (strong scaling, 16 streams): rc 0, ONE JSON line, n_gpus = N,
+    every accepted track through the all-gather, and — the ensemble being fixed — the integer totals of the N = 1 line at every N."""
+    one = _bench_cmd(1, '--no-cpu-baseline')
+    c1 = one['config']
+    assert one['n_gpus'] == 1 and c1['allgather_rows'] is None
+    for n in (2, 4, 8):
+        d = _bench_cmd(n, '--no-cpu-baseline')
+        c = d['config']
+        assert d['n_gpus'] == n and d['steps'] == 4 and d['warmup'] == 1 and d['scaling'] == 'strong' and d['value'] > 0
+        assert 'sharded over %d GPU' % n in c['workload']
+        assert c['allgather_rows'] == c['accepted_total'] > 0 and c['allgather_rows_clipped'] == 0
+        for k in ('storm_steps_total', 'accepted_total', 'storms_per_step'):
+            assert c[k] == c1[k], (n, k, c[k], c1[k])
+        assert abs(c['storms_per_gpu'] * n - c['storms_per_step']) < 1e-6
+        assert d['roofline']['frac'] > 0 and d['cpu_baseline'] is None
+
+
+@pytest.mark.gpu
+def test_launcherless_bench_two_ranks_with_cpu_baseline(built_lib):
+    """... and once at N = 2 WITH the CPU baseline: rank 0 times it after the process group is gone; the line carries both objects."""
+    d = _bench_cmd(2, '--cpu-budget', '1.0')
+    assert d['n_gpus'] == 2 and d['roofline']['frac'] > 0 and d['roofline']['achieved'] > 0
+    cpu = d['cpu_baseline']
+    assert cpu is not None and cpu['value'] and cpu['value'] > 0 and cpu['cores'] >= 1 and cpu['kind'] == 'port'

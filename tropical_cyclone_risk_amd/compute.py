@@ -286,7 +286,9 @@ def rows_to_tuple(res, n_steps):
     n = rows.shape[0]
     ns = n_steps
     tc_lon, tc_lat, tc_v, tc_m, tc_vmax = (rows[:, k * ns:(k + 1) * ns].copy() for k in range(5))
-    tc_env_wnds = np.ascontiguousarray(rows[:, 5 * ns:9 * ns]).reshape(n, ns, 4)       # (one copy: the slice of a wider row is not contiguous)
+    # one copy, always: `rows` may be a view of GpuRound's reused pinned buffer, and with a single row the slice of a wider row
+    # IS contiguous (np.ascontiguousarray would hand back a view that the next year's round overwrites — ADVICE r5)
+    tc_env_wnds = np.array(rows[:, 5 * ns:9 * ns], dtype=np.float64, order='C', copy=True).reshape(n, ns, 4)
     tc_month = res['month'].astype(np.float64)
     tc_basin = np.array([BASIN_IDS[i] for i in res['basin_idx']], dtype='U2')
     return (tc_lon, tc_lat, tc_v, tc_m, tc_vmax, tc_env_wnds, tc_month, tc_basin, res['n_seeds'])
