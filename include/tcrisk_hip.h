@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TCR_ABI_VERSION 6
+#define TCR_ABI_VERSION 7
 #define TCR_NW 4            /* ua250, va250, ua850, va850  (track/env_wind.py:22-26) */
 #define TCR_NCOV 10         /* packed lower triangle (0,0),(1,0),(1,1),(2,0)..(3,3) (env_wind.py:31-42) */
 #define TCR_MAX_SERIES 32
@@ -462,6 +462,40 @@ int tcr_timing_sum(tcr_ctx *ctx, double ms[3], int64_t *n_calls);
  * cycles / (64 x wave cycles) is the lane utilisation.  Returns the number of passes. */
 int tcr_integrate_pass_stats(tcr_ctx *ctx, int64_t *out, int max_passes);
 int tcr_sync(tcr_ctx *ctx, void *stream);
+
+/* ---- multi-GPU: the exchange of final tracks, RCCL over xGMI ---------------------------------------------------- */
+/* replaces: the fan-out / collection of run_downscaling (util/compute.py:223-242) — the reference hands run_tracks calls to
+ * dask worker processes and gets their 9-tuples pickled back.  Here one process owns one GPU and one context; every rank
+ * integrates its share (a block of each round's candidate indices, or whole years) and the survivor records are exchanged with
+ * ONE fixed-shape ncclAllGather per round / per run, device to device.  RCCL is loaded at run time (dlopen of librccl.so.1 —
+ * the copy the process already holds, e.g. PyTorch's, when there is one): a single-GPU user never needs it.
+ *   rank 0: tcr_comm_unique_id(id) -> the 128 bytes travel to the other ranks by any host channel (a file, MPI, a TCP store)
+ *   all   : tcr_comm_create(ctx, id, rank, world, &comm)       collective: every rank of the job calls it
+ * Calls on one communicator are collective and must be issued in the same order on every rank; they are asynchronous on
+ * `stream` (NULL: the context's).  Ragged contributions travel padded to a common row count (`cap`), each rank's real count
+ * next to them (tcr_allgather_counts_dev); tcr_concat_rows_dev packs the received blocks in rank order — which is candidate
+ * order when ranks own contiguous candidate blocks in rank order (the order the reference's sequential loop meets them). */
+#define TCR_COMM_ID_BYTES 128
+typedef struct tcr_comm tcr_comm;
+int tcr_comm_unique_id(uint8_t id[TCR_COMM_ID_BYTES]);     /* errors: tcr_last_error(NULL) */
+int tcr_comm_create(tcr_ctx *ctx, const uint8_t id[TCR_COMM_ID_BYTES], int32_t rank, int32_t world, tcr_comm **out);
+int tcr_comm_destroy(tcr_comm *comm);
+int tcr_comm_rank(const tcr_comm *comm);
+int tcr_comm_world(const tcr_comm *comm);
+/* recv_dev[world][bytes] <- every rank's send_dev[bytes] (the same size on every rank) */
+int tcr_allgather_dev(tcr_comm *comm, const void *send_dev, void *recv_dev, int64_t bytes, void *stream);
+/* gathered_dev[world][n_rows][row_stride] <- every rank's rows_dev[n_rows][row_stride] (survivor records: row_stride =
+ * 9 * n_steps (+ 3 meta columns), tcr_pack_tracks[_meta]_dev) */
+int tcr_allgather_rows_dev(tcr_comm *comm, const double *rows_dev, int64_t n_rows, int64_t row_stride, double *gathered_dev, void *stream);
+/* counts_dev[world] <- every rank's *count_dev */
+int tcr_allgather_counts_dev(tcr_comm *comm, const int64_t *count_dev, int64_t *counts_dev, void *stream);
+/* buf_dev[n] <- sum over ranks, in place (n_seeds[7][12], compute.py:167; round control) */
+int tcr_allreduce_sum_i64_dev(tcr_comm *comm, int64_t *buf_dev, int64_t n, void *stream);
+/* out_dev[sum_r min(counts[r], cap)][row_stride] <- the first min(counts[r], cap) rows of every rank's block of
+ * gathered_dev[n_blocks][cap][row_stride] (n_blocks = world), in rank order; at most out_cap rows are written;
+ * *n_out_dev (optional) = rows written.  Local to the calling rank (no communication). */
+int tcr_concat_rows_dev(tcr_ctx *ctx, int32_t n_blocks, const double *gathered_dev, const int64_t *counts_dev, int64_t cap, int64_t row_stride,
+                        double *out_dev, int64_t out_cap, int64_t *n_out_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -582,7 +582,7 @@ def test_parity_study_at_scale(golden_env, built_lib):
         # basins and runs), so: p99.9 within 10x of the twin's, storms above 1e-6 at most 3x the twin's count + 3, none above 1e-4
         # (the integrator's own tolerance is rtol = 1e-3)
         assert qd['p99.9'] <= max(1e-6, 10 * qu['p99.9']), (basin, qd, qu)
-        assert int((d > 1e-6).sum()) <= 3 * int((u > 1e-6).sum()) + 3 and qd['max'] <= 1e-4, (basin, qd, qu, int((d > 1e-6).sum()), int((u > 1e-6).sum()))
+        assert int((d > 1e-6).sum()) <= 3 * int((u > 1e-6).sum()) + 3 and qd['max'] <= P.TOL_TAIL_CAP, (basin, qd, qu, int((d > 1e-6).sum()), int((u > 1e-6).sum()))
         # ... and storm by storm (round 5): every storm above 1e-7 is one the oracle itself amplifies — its difference at most
         # parity.TWIN_FACTOR x what the oracle moves on THAT storm under a one-ulp change of one input (three twins walking the
         # same decision sequence, c_oracle.replayer.twin_storms): the rule the other tests apply to every sample, here at scale
@@ -595,13 +595,14 @@ def test_parity_study_at_scale(golden_env, built_lib):
             print(basin, 'storms above 1e-7 (index, d, own twin, ratio):', ratios)
             assert all(r[3] <= P.TWIN_FACTOR for r in ratios), (basin, ratios)
         out[basin] = dict(summary={k: v for k, v in s.items() if not isinstance(v, (dict, list))}, worst=s['worst'], d_gpu=qd, d_ulp=qu,
+                          max_ratio_to_own_twin=max([r[3] for r in ratios], default=0.0), twin_factor=P.TWIN_FACTOR, tail_cap=P.TOL_TAIL_CAP,
                           storms_over_1e7_vs_their_own_twin=[dict(storm=r[0], d_gpu=r[1], own_twin=r[2], ratio=r[3]) for r in ratios],
                           d_gpu_replayed_storms=qr, d_gpu_envw=qo['envw'], d_gpu_vmax=qo['vmax'],
                           storms_over_1e9=int((d > 1e-9).sum()), oracle_twins_over_1e9=int((u > 1e-9).sum()),
                           storms_over_1e6=int((d > 1e-6).sum()), oracle_twins_over_1e6=int((u > 1e-6).sum()),
                           replayed_over_1e9=int((d[~agree] > 1e-9).sum()),
                           accepted=int(ref['accepted'].sum()), is_tc=int(ref['is_tc'].sum()))
-        print(basin, 'd_gpu', qd, 'd_ulp', qu)
+        print(basin, 'd_gpu', qd, 'd_ulp', qu, 'max ratio to own twin %.2f' % out[basin]['max_ratio_to_own_twin'])
     os.makedirs('gpurun_out', exist_ok=True)
     with open('gpurun_out/parity_study.json', 'w') as f:
         json.dump(out, f, indent=1, default=lambda o: o.item() if hasattr(o, 'item') else str(o))

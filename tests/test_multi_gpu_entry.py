@@ -104,14 +104,16 @@ def test_launcherless_bench_at_2_4_8_ranks(built_lib):
     """the command shape the driver runs (`python bench.py --gpus N --steps K --warmup W`, no launcher), at every
     rank count of the scaling table, with the N > 1 defaults (strong scaling, 16 streams): rc 0, ONE JSON line, n_gpus = N,
     every accepted track through the all-gather, and — the ensemble being fixed — the integer totals of the N = 1 line at every N."""
-    one = _bench_cmd(1, '--no-cpu-baseline')
+    # (N = 1 with the N > 1 default of 16 streams: the timed steps are the ensembles behind `max(warmup, streams)` untimed ones,
+    # so the same stream count makes them the same ensembles at every N)
+    one = _bench_cmd(1, '--no-cpu-baseline', '--streams', '16')
     c1 = one['config']
-    assert one['n_gpus'] == 1 and c1['allgather_rows'] is None
+    assert one['n_gpus'] == 1 and c1['allgather_rows'] is None and c1['streams'] == 16
     for n in (2, 4, 8):
         d = _bench_cmd(n, '--no-cpu-baseline')
         c = d['config']
         assert d['n_gpus'] == n and d['steps'] == 4 and d['warmup'] == 1 and d['scaling'] == 'strong' and d['value'] > 0
-        assert 'sharded over %d GPU' % n in c['workload']
+        assert 'sharded over %d GPU' % n in c['workload'] and c['streams'] == 16 and c['warmup_effective'] == c1['warmup_effective']
         assert c['allgather_rows'] == c['accepted_total'] > 0 and c['allgather_rows_clipped'] == 0
         for k in ('storm_steps_total', 'accepted_total', 'storms_per_step'):
             assert c[k] == c1[k], (n, k, c[k], c1[k])
@@ -126,3 +128,55 @@ def test_launcherless_bench_two_ranks_with_cpu_baseline(built_lib):
     assert d['n_gpus'] == 2 and d['roofline']['frac'] > 0 and d['roofline']['achieved'] > 0
     cpu = d['cpu_baseline']
     assert cpu is not None and cpu['value'] and cpu['value'] > 0 and cpu['cores'] >= 1 and cpu['kind'] == 'port'
+
+
+@pytest.mark.gpu
+def test_library_allgather_through_rccl_on_one_rank(built_lib):
+    """The C ABI's own multi-GPU exchange (tcr_comm_* / tcr_allgather_rows_dev / tcr_allgather_counts_dev / tcr_concat_rows_dev /
+    tcr_allreduce_sum_i64_dev; SURVEY section 8(b) lists `allgather` among the exports): a one-rank RCCL communicator created
+    from the library — RCCL loaded at run time, no torch.distributed involved — moves a ragged block of survivor records and
+    packs it; `tcr_concat_rows_dev` is also checked as a multi-rank packer on a hand-made [world][cap] block (odd and even row
+    strides, clipping at cap and at out_cap)."""
+    import ctypes as C
+    import torch
+    from tropical_cyclone_risk_amd import _lib, distributed as D, synthetic
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    eng = TCEngine('NA', device=0)
+    comm = D.LibComm(eng, rank_=0, world_=1)
+    L = _lib.lib()
+    assert L.tcr_comm_rank(comm.h) == 0 and L.tcr_comm_world(comm.h) == 1
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device='cpu').manual_seed(3)
+    for width in (9 * 361 + 3, 9 * 361):
+        rows = torch.rand(40, width, dtype=torch.float64, generator=g).to(dev)
+        cnt = torch.tensor([27], dtype=torch.int64, device=dev)
+        counts = comm.allgather_counts(cnt)
+        out, n_out = comm.allgather_rows(rows, counts)
+        torch.cuda.synchronize()
+        assert counts.tolist() == [27] and int(n_out) == 27
+        assert torch.equal(out[:27], rows[:27])
+    t = torch.arange(84, dtype=torch.int64, device=dev)
+    comm.allreduce_sum_(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(84, dtype=torch.int64))
+    # the packer alone, as four ranks would feed it: counts 3, 0, 7 (clipped to cap = 5), 2; then out_cap = 8 of the 10 rows
+    for width in (12, 13):
+        world, cap = 4, 5
+        blk = torch.rand(world, cap, width, dtype=torch.float64, generator=g).to(dev)
+        counts = torch.tensor([3, 0, 7, 2], dtype=torch.int64, device=dev)
+        want = torch.cat([blk[0, :3], blk[2, :5], blk[3, :2]], dim=0)
+        for out_cap in (20, 8):
+            o = torch.full((out_cap, width), -1.0, dtype=torch.float64, device=dev)
+            n = torch.zeros(1, dtype=torch.int64, device=dev)
+            comm._chk(L.tcr_concat_rows_dev(eng.h, world, blk.data_ptr(), counts.data_ptr(), cap, width, o.data_ptr(), out_cap, n.data_ptr(), None))
+            torch.cuda.synchronize()
+            k = min(10, out_cap)
+            assert int(n) == k and torch.equal(o[:k], want[:k]) and bool((o[k:] == -1.0).all())
+    # out_cap smaller than the total: rows beyond it are dropped, the count says so
+    rows = torch.rand(8, 16, dtype=torch.float64, generator=g).to(dev)
+    counts = torch.tensor([8], dtype=torch.int64, device=dev)
+    out, n_out = comm.allgather_rows(rows, counts, out_cap=5)
+    torch.cuda.synchronize()
+    assert int(n_out) == 5 and torch.equal(out, rows[:5])
+    comm.close()
+    eng.close()

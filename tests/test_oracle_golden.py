@@ -254,18 +254,19 @@ def test_checker_is_not_vacuous(golden_env):
     assert check(under)['amplified'] == []
     real = replay.twin_storms
     try:
-        replay.twin_storms = lambda idx, dec=None: {k: np.where(np.asarray(idx) == i, 1e-8, v) for k, v in real(idx, dec).items()}
-        s = check(one)                                           # the same storm, were it one the oracle amplifies to 1e-8
+        replay.twin_storms = lambda idx, dec=None: {k: np.where(np.asarray(idx) == i, 2e-8, v) for k, v in real(idx, dec).items()}
+        s = check(one)                                           # the same storm, were it one the oracle amplifies to 2e-8 (25 x)
         assert [a[0] for a in s['amplified']] == [i]
         two = {kk: (vv.copy() if hasattr(vv, 'copy') else vv) for kk, vv in ref.items()}
-        two['traj'][i, 0, 50] += 2e-6                            # 200 x its twin
+        two['traj'][i, 0, 50] += 1e-6                            # 50 x its twin: passed the round-5 factor of 100, fails round 6's 30
         with pytest.raises(AssertionError, match='storm %d' % i):
             check(two)
         replay.twin_storms = lambda idx, dec=None: {k: np.full(len(idx), 1.0) for k in ('traj', 'envw', 'vmax')}
-        far = {kk: (vv.copy() if hasattr(vv, 'copy') else vv) for kk, vv in ref.items()}
-        far['traj'][i, 0, 50] += 2e-4                            # above the cap, whatever the twin says
-        with pytest.raises(AssertionError, match='storm %d' % i):
-            check(far)
+        for off in (2e-4, 7e-5):                                 # above the cap (5e-5 since round 6), whatever the twin says
+            far = {kk: (vv.copy() if hasattr(vv, 'copy') else vv) for kk, vv in ref.items()}
+            far['traj'][i, 0, 50] += off
+            with pytest.raises(AssertionError, match='storm %d' % i):
+                check(far)
     finally:
         replay.twin_storms = real
 

@@ -10,7 +10,7 @@ import os
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, 'libtcrisk_hip.so')
 
-TCR_ABI_VERSION = 6
+TCR_ABI_VERSION = 7
 TCR_NW, TCR_NCOV, TCR_MAX_SERIES, TCR_N_BASINS = 4, 10, 32, 7
 STATUS_GATED, STATUS_FINISHED, STATUS_EVENT, STATUS_STEP_FAIL, STATUS_STEP_OVERFLOW = -1, 0, 1, -2, -3
 FLAG_IS_TC, FLAG_ACCEPTED = 1, 2
@@ -33,7 +33,10 @@ EXPORTS = ('tcr_abi_version', 'tcr_ctx_create', 'tcr_ctx_destroy', 'tcr_last_err
            'tcr_integrate_probe_host', 'tcr_integrate_f32_dev', 'tcr_integrate_f32_host', 'tcr_pack_tracks_f32_dev',
            'tcr_wind_stats_f32_dev', 'tcr_wind_stats_f32_host', 'tcr_static_upload2', 'tcr_init_m_dev', 'tcr_init_m_host', 'tcr_cell_order_dev',
            'tcr_round_dev', 'tcr_round_graph_stats', 'tcr_schedule_set', 'tcr_stage_trace_enable', 'tcr_stage_trace_sum', 'tcr_seed_hist_dev', 'tcr_pack_tracks_meta_dev',
-           'tcr_static_store', 'tcr_static_info', 'tcr_tune_set', 'tcr_tune_get', 'tcr_slot_upload', 'tcr_stage_timing')
+           'tcr_static_store', 'tcr_static_info', 'tcr_tune_set', 'tcr_tune_get', 'tcr_slot_upload', 'tcr_stage_timing',
+           'tcr_comm_unique_id', 'tcr_comm_create', 'tcr_comm_destroy', 'tcr_comm_rank', 'tcr_comm_world', 'tcr_allgather_dev',
+           'tcr_allgather_rows_dev', 'tcr_allgather_counts_dev', 'tcr_allreduce_sum_i64_dev', 'tcr_concat_rows_dev')
+TCR_COMM_ID_BYTES = 128
 
 
 class Grid(C.Structure):
@@ -202,6 +205,16 @@ def lib():
     L.tcr_pack_tracks_f32_dev.argtypes = L.tcr_pack_tracks_dev.argtypes
     L.tcr_wind_stats_f32_dev.argtypes = L.tcr_wind_stats_dev.argtypes
     L.tcr_wind_stats_f32_host.argtypes = L.tcr_wind_stats_host.argtypes
+    L.tcr_comm_unique_id.argtypes = [U8P]
+    L.tcr_comm_create.argtypes = [C.c_void_p, U8P, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.tcr_comm_destroy.argtypes = [C.c_void_p]
+    L.tcr_comm_rank.argtypes = [C.c_void_p]
+    L.tcr_comm_world.argtypes = [C.c_void_p]
+    L.tcr_allgather_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.tcr_allgather_rows_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    L.tcr_allgather_counts_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tcr_allreduce_sum_i64_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.tcr_concat_rows_dev.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     if L.tcr_abi_version() != TCR_ABI_VERSION:
         raise TcrError('libtcrisk_hip.so ABI version %d != binding version %d'
                        % (L.tcr_abi_version(), TCR_ABI_VERSION))

@@ -3,7 +3,8 @@
     python -m tropical_cyclone_risk_amd.build [--force]
 
 -ffp-contract=off: bilinear weights/sums and the `land == 1` test must keep
-FITPACK's operation order without fused multiply-adds (tcr_device.h).
+FITPACK's operation order without fused multiply-adds; the one place that opts in to
+contraction (the RK45 step of k_integrate) does so with a pragma (tcr_device.h, "Arithmetic policy").
 -mllvm -disable-machine-licm: see FLAGS.
 """
 import os
@@ -14,7 +15,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 OUT = os.path.join(PKG, 'libtcrisk_hip.so')
-SOURCES = ['tcr_abi.hip', 'tcr_kernels.hip', 'tcr_seed.hip', 'tcr_compact.hip', 'tcr_prep.hip', 'tcr_thermo.hip', 'tcr_device.h', 'tcr_experiments.h',
+SOURCES = ['tcr_abi.hip', 'tcr_kernels.hip', 'tcr_seed.hip', 'tcr_compact.hip', 'tcr_prep.hip', 'tcr_thermo.hip', 'tcr_comm.hip', 'tcr_device.h', 'tcr_experiments.h',
            os.path.join('..', '..', 'include', 'tcrisk_hip.h')]
 # -disable-machine-licm: the kernels here are register-bound loops around libm-heavy bodies; hoisting the bodies' constant
 # materialisations out of the loops costs k_emit 40 VGPRs + spills (0.36 instead of 0.15 ms) and k_integrate 70 AGPRs.

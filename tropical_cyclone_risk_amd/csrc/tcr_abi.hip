@@ -445,7 +445,7 @@ tcr_tune tune_from_env()
 {
     tcr_tune t;
     t.waves = (int32_t)env_long("TCR_WAVES", -1);
-    t.park = (int32_t)env_long("TCR_PARK", -1);
+    t.park = (int32_t)std::min<long>(env_long("TCR_PARK", -1), 63);     // (tcr_tune_set's own bound: a get / modify / set round trip must not fail on it)
     t.park_final = (int32_t)env_long("TCR_PARK_FINAL", -1);
     t.table_segments = (int32_t)env_long("TCR_TABLE_SEGMENTS", -1);
     t.prune = (int32_t)env_long("TCR_PRUNE", -1);
@@ -703,6 +703,9 @@ int widen_static(tcr_ctx *ctx, hipStream_t st)
 {
     const int mode = ctx->static_mode;
     if (mode != kStatPack16 && mode != kStatU8F32 && mode != kStatPack64) return 0;
+    // (synchronises and frees: never legal inside a stream capture.  tcr_round_dev runs every new descriptor directly before it
+    // captures it, and a static re-upload changes the epoch, so the widening always happens in that direct run — guarded anyway)
+    if (ctx->capturing) return fail(ctx, "internal: static fields would be widened inside a stream capture");
     const size_t np = ctx->hg.lon.size() * ctx->hg.lat.size();
     const size_t nb = ctx->split_static ? ctx->bg.lon.size() * ctx->bg.lat.size() : np;
     if (ctx->split_static) { if (dev_alloc(ctx, &ctx->d_land, np) || dev_alloc(ctx, &ctx->d_bathy, nb)) return -1; }
@@ -1238,6 +1241,7 @@ int slot_stage(tcr_ctx *ctx, int slot, const tcr_grid *wg, const double *const m
     const size_t need = nw * 14 + nt * 4 + nr;
     if (need > ctx->h_stage_cap) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->h_stage_cap = 0;             // a failure below leaves "no staging buffer", never a half-built pair at the old capacity
         for (int i = 0; i < 2; ++i) {
             if (ctx->h_stage[i]) HIPCHK(ctx, hipHostFree(ctx->h_stage[i]));
             ctx->h_stage[i] = nullptr;
@@ -2276,3 +2280,5 @@ int tcr_round_graph_stats(tcr_ctx *ctx, int64_t *n_graphs, int64_t *n_replays)
 }
 
 }  // extern "C"
+
+#include "tcr_comm.hip"                  // multi-GPU exchange (RCCL, loaded at run time)

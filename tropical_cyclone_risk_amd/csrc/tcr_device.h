@@ -33,6 +33,67 @@
 // made register allocation worse, not better.
 #define RD(x) (x)
 
+// Arithmetic policy of the hot path (round 6; the A / B behind every line is in DESIGN.md section 9 and profiles/r06_ab_variants.txt).
+// The translation unit is compiled with -ffp-contract=off: unless a function opts in below, every multiply and add is rounded
+// on its own, in the reference's operation order.
+//   exact (never fused, never substituted)
+//                         everything a discrete decision of the reference is taken on, or that two kernels must reproduce
+//                         bit for bit: the cell search and bilinear weights (locate_t), every FITPACK bilinear sum (`land == 1`,
+//                         coupled_fast.py:35-38; `PI != 0`, `t_strat == 0`, `-h_m <= bathymetry`), the output grid (ts_k, fs_bracket),
+//                         dense output (dense_at and the integrator's in-flight 2-day sample, which k_screen must reproduce),
+//                         seeding, wind statistics, thermodynamics;
+//   same value, fewer instructions (on by default)
+//                         TCR_FAST_DIV / TCR_FAST_SQRT: division and square root of fun(t, y) without the range-scaling instructions
+//                         (qdiv_nz, qsqrt: the compiler's own Newton sequences; identical results for the operands of this path);
+//                         0.5 Ck / h_bl once per storm instead of once per evaluation (ck_over_h: the same expression);
+//   libm-class substitutions, each within 2 ulp of the function it replaces (on by default)
+//                         TCR_FAST_POW: t_strat ** -0.4 and err ** -0.2 as a Newton iteration for a ** (-1/5) (inv_fifth_root);
+//                         TCR_FAST_COS: cos(lat pi / 180) as a polynomial on [-pi / 2, pi / 2] (cos_lat);
+//                         TCR_SHARE_COS: dlon/dt divides by the beta drift's cos(deg2rad(lat)) instead of a second cosine of
+//                         lat * pi / 180, and multiplies by the host-computed 180 / (pi R) (rhs_track);
+//   fused multiply-adds   TCR_FUSE_RK (on): the RK45 step — stage inputs, y_new, error norm, initial-step norms (k_integrate);
+//                         TCR_FUSE_RHS (off): the continuous arithmetic inside fun(t, y) — wind blend, forcing blend, Cholesky,
+//                         beta-advection, _dvdt / _dmdt.  Measured: with it the isolated chain is 3-8 % shorter and the pipelined
+//                         step and the small batches do not move, the parity distribution of a 10 000-storm ensemble does not move
+//                         either, but a second storm of the 48 curated NA golden tracks crosses 1e-9 where the tier allows one —
+//                         so it stays off.
+// TCR_FUSE=0 switches both fusion knobs off at once; every knob at 0 is the arithmetic of rounds 1-5.
+#ifndef TCR_FUSE
+#define TCR_FUSE 1
+#endif
+#ifndef TCR_FAST_DIV
+#define TCR_FAST_DIV 1
+#endif
+#ifndef TCR_FAST_SQRT
+#define TCR_FAST_SQRT 1
+#endif
+#ifndef TCR_SHARE_COS
+#define TCR_SHARE_COS 1
+#endif
+#ifndef TCR_FAST_POW
+#define TCR_FAST_POW 1
+#endif
+#ifndef TCR_FAST_COS
+#define TCR_FAST_COS 1
+#endif
+#ifndef TCR_FUSE_RHS
+#define TCR_FUSE_RHS 0
+#endif
+#ifndef TCR_FUSE_RK
+#define TCR_FUSE_RK TCR_FUSE
+#endif
+#if TCR_FUSE_RHS
+#define TCR_FP_FUSE _Pragma("clang fp contract(fast)")
+#else
+#define TCR_FP_FUSE
+#endif
+#if TCR_FUSE_RK
+#define TCR_FP_FUSE_RK _Pragma("clang fp contract(fast)")
+#else
+#define TCR_FP_FUSE_RK
+#endif
+#define TCR_FP_EXACT _Pragma("clang fp contract(off)")
+
 namespace tcr {
 
 constexpr double kPi = 3.141592653589793;
@@ -112,6 +173,7 @@ struct EvalKT {
     const void *stat;
     const void *bathy;
     R earth_R, Ck, epsilon, kappa, u_beta, v_beta;
+    R deg_per_m;             // 1 / earth_R * 180 / pi (rhs_track)
     R y_alpha[2], m_alpha[2], alpha_max[2], alpha_min[2], steering_coefs[2];
     double total_time, tstep, inv_tstep;        // time stays fp64 in both instantiations
     int n_steps, coupled_track;
@@ -127,6 +189,7 @@ __host__ __device__ inline void eval_k_scalars(const tcr_params &P, EvalKT<R> &K
 {
     K.earth_R = (R)P.earth_R; K.Ck = (R)P.Ck; K.epsilon = (R)P.epsilon; K.kappa = (R)P.kappa;
     K.u_beta = (R)P.u_beta; K.v_beta = (R)P.v_beta;
+    K.deg_per_m = (R)(1.0 / P.earth_R * 180. / kPi);
     for (int i = 0; i < 2; ++i) {
         K.y_alpha[i] = (R)P.y_alpha[i]; K.m_alpha[i] = (R)P.m_alpha[i]; K.alpha_max[i] = (R)P.alpha_max[i];
         K.alpha_min[i] = (R)P.alpha_min[i]; K.steering_coefs[i] = (R)P.steering_coefs[i];
@@ -156,6 +219,101 @@ __device__ __forceinline__ typename VecT<R, L>::type ldg(const R *p)
     return *(const __attribute__((address_space(1))) V *)(p);
 }
 
+// Division and square root of the continuous arithmetic of fun(t, y) (see the policy above).  IEEE fp64 division on gfx950 is v_div_scale x 2,
+// v_rcp_f64, five fmas, a mul, v_div_fmas, v_div_fixup (12 VALU instructions, 10 of them one dependent chain); the scale / fmas /
+// fixup instructions only serve operands whose quotient leaves the normal range, and ocml's sqrt spends 8 of its 22 on the same.
+//   qdiv_nz(a, b)   a / b for a divisor that is finite, non-zero and normal (grid steps, cos(lat) equatorward of 80 deg, h_bl, the
+//                   error scale atol + rtol |y|, standard deviations of a positive-definite covariance) and a finite or NaN
+//                   dividend: v_rcp_f64, two Newton steps, q = a r, one residual correction — LLVM's own sequence without the
+//                   range scaling, within 1 ulp of a / b.  Divisions whose divisor can be zero (`/ v`) stay IEEE.
+//   qsqrt(a)        v_rsq_f64, one coupled Newton step and two residual corrections (LLVM's fp64 sqrt without the denormal scaling),
+//                   zero and +inf passed through; negative and NaN give NaN.  Arguments are sums of squares of speeds in m/s and
+//                   variances of winds: never denormal.
+//   qsqrt_pos(a)    the same without the zero / inf select, for an argument already tested > 0 whose result is discarded otherwise
+//                   (the Cholesky pivots).
+template <typename R> __device__ __forceinline__ R qdiv_nz(R a, R b) { return a / b; }
+template <typename R> __device__ __forceinline__ R qsqrt(R a) { return sqrt(a); }
+template <typename R> __device__ __forceinline__ R qsqrt_pos(R a) { return sqrt(a); }
+#if TCR_FAST_DIV
+template <> __device__ __forceinline__ double qdiv_nz<double>(double a, double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = a * r;
+    const double res = __builtin_fma(-b, q, a);
+    return __builtin_fma(res, r, q);
+}
+#endif
+#if TCR_FAST_SQRT
+template <> __device__ __forceinline__ double qsqrt_pos<double>(double a)
+{
+    const double y = __builtin_amdgcn_rsq(a);
+    const double g0 = a * y, h0 = 0.5 * y;
+    const double r0 = __builtin_fma(-h0, g0, 0.5);
+    const double g1 = __builtin_fma(g0, r0, g0), h1 = __builtin_fma(h0, r0, h0);
+    const double d0 = __builtin_fma(-g1, g1, a);
+    const double g2 = __builtin_fma(d0, h1, g1);
+    const double d1 = __builtin_fma(-g2, g2, a);
+    return __builtin_fma(d1, h1, g2);
+}
+template <> __device__ __forceinline__ double qsqrt<double>(double a)
+{
+    const double g = qsqrt_pos<double>(a);
+    return (a == 0.0 || a == __builtin_inf()) ? a : g;      // rsq(0) = inf, rsq(inf) = 0: the products above are NaN
+}
+#endif
+
+// The two powers of the path — t_strat ** -0.4 (coupled_fast.py:91, every evaluation) and err ** -0.2 (rk.py:160, every attempt) —
+// are both a ** (-1/5): of t_strat ** 2 and of err.  ocml's pow is a general double-double log / exp (~220 VALU instructions);
+// a ** (-1/5) is the root of f(y) = y ** -5 - a, whose Newton step y <- y + 0.2 y (1 - a y ** 5) needs six multiply-adds and
+// converges quadratically: seeded with the fp32 hardware exp2(-0.2 log2(a)) (relative error ~1e-6), two steps reach fp64 round-off
+// (measured against 80-bit pow on 2 M arguments in [1e-4, 1e3] ** 2: at most 1.8 ulp; ocml / glibc: 0.6).  Domain: a within the fp32
+// range (t_strat between 1e-19 and 1e19 K / 100 m); a <= 0, inf and NaN give NaN or the limit value like pow, except a = 0 -> NaN
+// (not inf) — callers select on `t_strat == 0` / `err == 0` before they use the value, as the reference does.
+template <typename R> __device__ __forceinline__ R inv_fifth_root(R a) { return pow(a, R(-0.2)); }
+template <typename R> __device__ __forceinline__ R strat_pow(R g) { return pow(g, R(-0.4)); }
+#if TCR_FAST_POW
+template <> __device__ __forceinline__ double inv_fifth_root<double>(double a)
+{
+    double y = (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)a));       // v_log_f32 is log2, v_exp_f32 is exp2
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double y2 = y * y, y4 = y2 * y2, y5 = y4 * y;
+        const double r = __builtin_fma(-a, y5, 1.0);
+        y = __builtin_fma(y * 0.2, r, y);
+    }
+    return y;
+}
+template <> __device__ __forceinline__ double strat_pow<double>(double g) { return inv_fifth_root<double>(g * g); }
+#endif
+
+// cos(lat pi / 180) for a latitude on the sphere: the argument is within [-pi / 2, pi / 2], so no range reduction is needed and
+// the Taylor polynomial to x ** 22 is below fp64 round-off in absolute terms (relative: 0.3 ulp on average, at most 1 ulp equatorward
+// of 60 degrees and 4.4 ulp at 80 degrees, where cos = 0.17; the track stops there, bam_track.py:134).  ocml's cos spends ~150
+// instructions, most of them on arguments this path never has.
+template <typename R> __device__ __forceinline__ R cos_lat(R x) { return cos(x); }
+#if TCR_FAST_COS
+template <> __device__ __forceinline__ double cos_lat<double>(double x)
+{
+    const double z = x * x;
+    double p = -1.0 / 1124000727777607680000.0;                   // -1 / 22!
+    p = __builtin_fma(p, z, 1.0 / 2432902008176640000.0);         //  1 / 20!
+    p = __builtin_fma(p, z, -1.0 / 6402373705728000.0);           // -1 / 18!
+    p = __builtin_fma(p, z, 1.0 / 20922789888000.0);              //  1 / 16!
+    p = __builtin_fma(p, z, -1.0 / 87178291200.0);                // -1 / 14!
+    p = __builtin_fma(p, z, 1.0 / 479001600.0);                   //  1 / 12!
+    p = __builtin_fma(p, z, -1.0 / 3628800.0);                    // -1 / 10!
+    p = __builtin_fma(p, z, 1.0 / 40320.0);                       //  1 / 8!
+    p = __builtin_fma(p, z, -1.0 / 720.0);                        // -1 / 6!
+    p = __builtin_fma(p, z, 1.0 / 24.0);                          //  1 / 4!
+    p = __builtin_fma(p, z, -0.5);
+    return __builtin_fma(p, z, 1.0);
+}
+#endif
+
 // fpbisp.f (clamp + interval search) and fpbspl.f (k = 1 weights).
 // Affine axes (ERA5's 1 deg / 0.25 deg grids, CMIP regular grids) need no memory
 // traffic at all: the host has verified that x0 + i*dx reproduces every knot
@@ -163,6 +321,7 @@ __device__ __forceinline__ typename VecT<R, L>::type ldg(const R *p)
 template <typename R, bool AFFINE>
 __device__ __forceinline__ CellT<R> locate_t(const AxisT<R> &A, R arg)
 {
+    TCR_FP_EXACT
     const R ax0 = RD(A.x0), axn = RD(A.xn);
     arg = (arg < ax0) ? ax0 : arg;
     arg = (arg > axn) ? axn : arg;
@@ -221,22 +380,36 @@ __device__ __forceinline__ void gather(const R *__restrict__ base, int nlon, con
 }
 
 // ... and their bilinear sums in fpbisp.f's order: (x0,y0), (x0,y1), (x1,y0), (x1,y1),
-// each term (c*hx)*hy.
-template <typename R, int NF, int L>
+// each term (c*hx)*hy.  FUSED (wind means and covariances inside fun(t, y) only — fields no discrete decision reads): the
+// same terms in the same order, each accumulated with one fma.
+template <typename R, int NF, int L, bool FUSED = false>
 __device__ __forceinline__ void blend(const CornersT<R, NF, L> &C, const CellT<R> &cx, const CellT<R> &cy, R (&out)[NF])
 {
+    if (FUSED && TCR_FUSE_RHS) {
+        TCR_FP_FUSE
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        const R a = C.c00[f / L][f % L];
-        const R b = C.c01[f / L][f % L];
-        const R c = C.c10[f / L][f % L];
-        const R d = C.c11[f / L][f % L];
-        R sp = R(0.0);
-        sp = sp + a * cx.w0 * cy.w0;
-        sp = sp + b * cx.w0 * cy.w1;
-        sp = sp + c * cx.w1 * cy.w0;
-        sp = sp + d * cx.w1 * cy.w1;
-        out[f] = sp;
+        for (int f = 0; f < NF; ++f) {
+            R sp = C.c00[f / L][f % L] * cx.w0 * cy.w0;
+            sp = sp + C.c01[f / L][f % L] * cx.w0 * cy.w1;
+            sp = sp + C.c10[f / L][f % L] * cx.w1 * cy.w0;
+            sp = sp + C.c11[f / L][f % L] * cx.w1 * cy.w1;
+            out[f] = sp;
+        }
+    } else {
+        TCR_FP_EXACT
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const R a = C.c00[f / L][f % L];
+            const R b = C.c01[f / L][f % L];
+            const R c = C.c10[f / L][f % L];
+            const R d = C.c11[f / L][f % L];
+            R sp = R(0.0);
+            sp = sp + a * cx.w0 * cy.w0;
+            sp = sp + b * cx.w0 * cy.w1;
+            sp = sp + c * cx.w1 * cy.w0;
+            sp = sp + d * cx.w1 * cy.w1;
+            out[f] = sp;
+        }
     }
 }
 
@@ -312,12 +485,13 @@ __device__ __forceinline__ void fs_gather(const R *__restrict__ fs, const FsBrac
 template <typename R>
 __device__ __forceinline__ void fs_blend(const FsPairT<R> &p, const FsBracket &b, double t, R (&F)[4])
 {
+    TCR_FP_FUSE
     constexpr int L = FsPairT<R>::L;
     const R dt = (R)(t - b.x_lo), dx = (R)b.dx;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const R ya = p.a[s / L][s % L], yb = p.b[s / L][s % L];
-        F[s] = (yb - ya) / dx * dt + ya;
+        F[s] = qdiv_nz<R>(yb - ya, dx) * dt + ya;
     }
 }
 
@@ -327,6 +501,7 @@ __device__ __forceinline__ void fs_blend(const FsPairT<R> &p, const FsBracket &b
 template <typename R>
 __device__ __forceinline__ void winds_from_lookups(const R (&q)[14], const R (&F)[4], R lon, double t, R (&w)[4])
 {
+    TCR_FP_FUSE
     // packed lower triangle: q[4]=a00 q[5]=a10 q[6]=a11 q[7]=a20 q[8]=a21 q[9]=a22 q[10]=a30 q[11]=a31 q[12]=a32 q[13]=a33
     const R z = R(0.0), one = R(1.0);
     bool ok = !(lon != lon) && !(t != t);
@@ -334,29 +509,29 @@ __device__ __forceinline__ void winds_from_lookups(const R (&q)[14], const R (&F
     {
         const R ajj = q[4] - z;
         ok = ok && (ajj > z);
-        l00 = sqrt(ajj);
-        const R r = one / l00;
+        l00 = qsqrt_pos<R>(ajj);
+        const R r = qdiv_nz<R>(one, l00);
         l10 = (q[5] - z) * r; l20 = (q[7] - z) * r; l30 = (q[10] - z) * r;
     }
     {
         const R ajj = q[6] - (z + l10 * l10);
         ok = ok && (ajj > z);
-        l11 = sqrt(ajj);
-        const R r = one / l11;
+        l11 = qsqrt_pos<R>(ajj);
+        const R r = qdiv_nz<R>(one, l11);
         l21 = (q[8] - (z + l20 * l10)) * r;
         l31 = (q[11] - (z + l30 * l10)) * r;
     }
     {
         const R ajj = q[9] - ((z + l20 * l20) + l21 * l21);
         ok = ok && (ajj > z);
-        l22 = sqrt(ajj);
-        const R r = one / l22;
+        l22 = qsqrt_pos<R>(ajj);
+        const R r = qdiv_nz<R>(one, l22);
         l32 = (q[12] - ((z + l30 * l20) + l31 * l21)) * r;
     }
     {
         const R ajj = q[13] - (((z + l30 * l30) + l31 * l31) + l32 * l32);
         ok = ok && (ajj > z);
-        l33 = sqrt(ajj);
+        l33 = qsqrt_pos<R>(ajj);
     }
     const R w0 = q[0] + ((((z + l00 * F[0]) + z * F[1]) + z * F[2]) + z * F[3]);
     const R w1 = q[1] + ((((z + l10 * F[0]) + l11 * F[1]) + z * F[2]) + z * F[3]);
@@ -378,7 +553,7 @@ __device__ __forceinline__ void env_winds(const EvalKT<R> &K, const R *__restric
     gather<R, 14, kWindStride, Widths<R>::W>(wind, RD(K.wx.n), cx, cy, CW);
     fs_gather<R>(fs, fb, fp);
     R q[14], F[4];
-    blend<R, 14, Widths<R>::W>(CW, cx, cy, q);
+    blend<R, 14, Widths<R>::W, true>(CW, cx, cy, q);
     fs_blend<R>(fp, fb, t, F);
     winds_from_lookups<R>(q, F, lon, t, w);
 }
@@ -406,6 +581,7 @@ struct TrackMidT {
 template <typename R>
 __device__ __forceinline__ void rhs_track(const EvalKT<R> &K, R lat, R v, RhsT<R> &r, TrackMidT<R> &mid)
 {
+    TCR_FP_FUSE
     const R z = R(0.0);
     // steering coefficients
     R c0, c1;
@@ -424,22 +600,39 @@ __device__ __forceinline__ void rhs_track(const EvalKT<R> &K, R lat, R v, RhsT<R
     const bool polar = fabs(lat) >= R(80);
     const R w0 = polar ? z : r.w[0], w1 = polar ? z : r.w[1];
     const R w2 = polar ? z : r.w[2], w3 = polar ? z : r.w[3];
-    const R cl = cos(lat * R(kPi / 180.0));                            // np.deg2rad
+    const R cl = cos_lat<R>(lat * R(kPi / 180.0));                     // np.deg2rad
     R vb0 = (w0 * c0 + w2 * c1) + RD(K.u_beta) * cl;
     R vb1 = (w1 * c0 + w3 * c1) + (sign_of(lat) * RD(K.v_beta)) * cl;
     vb0 = polar ? z : vb0;
     vb1 = polar ? z : vb1;
-    r.d[0] = vb0 / RD(K.earth_R) * R(180.) / R(kPi) / cos(lat * R(kPi) / R(180.));
-    r.d[1] = vb1 / RD(K.earth_R) * R(180.) / R(kPi);
+    // bam_track.py / coupled_fast.py:203-204: dlon/dt = v / R * 180 / pi / cos(lat * pi / 180), dlat/dt = v / R * 180 / pi
+#if TCR_SHARE_COS
+    // the factor 180 / (pi R) is one host-computed constant and cos(lat pi / 180) is the beta-drift's cos(deg2rad(lat)): the two
+    // arguments differ by at most one rounding of lat * pi / 180 (2 ulp of the cosine at 80 deg)
+    r.d[0] = polar ? z : qdiv_nz<R>(vb0 * RD(K.deg_per_m), cl);
+    r.d[1] = vb1 * RD(K.deg_per_m);
+#else
+    r.d[0] = qdiv_nz<R>(qdiv_nz<R>(qdiv_nz<R>(vb0, RD(K.earth_R)) * R(180.), R(kPi)), cos(qdiv_nz<R>(lat * R(kPi), R(180.))));
+    r.d[1] = qdiv_nz<R>(qdiv_nz<R>(vb1, RD(K.earth_R)) * R(180.), R(kPi));
+#endif
     mid.vb0 = vb0; mid.vb1 = vb1;
 }
 
 // Part 2 — intensity and moisture: _dvdt (coupled_fast.py:141-150) with _get_current_vpot (:54-58),
-// _calc_alpha / _calc_z (:65-94), _dmdt (:175-180).
+// _calc_alpha / _calc_z (:65-94), _dmdt (:175-180).  ck_h = 0.5 * Ck / h_bl, the common prefix of both expressions
+// (:148, :179): constant over a storm's life, so the integrator divides once per storm (ck_over_h), not per evaluation.
 template <typename R>
-__device__ __forceinline__ void rhs_intensity(const EvalKT<R> &K, R h_bl, R lat, R v, R m, const R (&th)[4],
+__device__ __forceinline__ R ck_over_h(const EvalKT<R> &K, R h_bl)
+{
+    TCR_FP_EXACT
+    return R(0.5) * RD(K.Ck) / h_bl;
+}
+
+template <typename R>
+__device__ __forceinline__ void rhs_intensity(const EvalKT<R> &K, R ck_h, R lat, R v, R m, const R (&th)[4],
                                               const R (&lb)[2], const TrackMidT<R> &mid, RhsT<R> &r)
 {
+    TCR_FP_FUSE
     const R z = R(0.0);
     const bool polar = fabs(lat) >= R(80);
     const R w0 = polar ? z : r.w[0], w1 = polar ? z : r.w[1];
@@ -449,20 +642,20 @@ __device__ __forceinline__ void rhs_intensity(const EvalKT<R> &K, R h_bl, R lat,
     r.dec = (lb[0] == R(1.0) ? 1 : 0) | (th[0] != z ? 2 : 0) | (fabs(lb[0] - R(1.0)) <= R(1e-12) ? 4 : 0);
     const R h_m = th[2], gam = th[3], bathy = lb[1];
     const bool no_mix = (bathy >= z) || (-h_m <= bathy) || (gam == z);
-    const R uT = sqrt(vb0 * vb0 + vb1 * vb1);
-    const R zz = R(0.01) * pow(gam, R(-0.4)) * h_m * uT * vp / v;
+    const R uT = qsqrt<R>(vb0 * vb0 + vb1 * vb1);
+    const R zz = R(0.01) * strat_pow<R>(gam) * h_m * uT * vp / v;
     const R zc = np_min(np_max(zz, z), R(100.0));
     const R al = no_mix ? R(1.0) : R(1) - R(0.87) * exp(-zc);
     r.alpha = al;
     const R beta = R(1) - RD(K.epsilon) - RD(K.kappa);
     const R gamma = RD(K.epsilon) + al * RD(K.kappa);
     const R m3 = m * m * m;
-    const R dv = R(0.5) * RD(K.Ck) / h_bl * (al * beta * (vp * vp) * m3 - (R(1) - gamma * m3) * (v * v));
+    const R dv = ck_h * (al * beta * (vp * vp) * m3 - (R(1) - gamma * m3) * (v * v));
     const R du = w0 - w2, dw = w1 - w3;
-    const R venti = sqrt(du * du + dw * dw) * th[1];
+    const R venti = qsqrt<R>(du * du + dw * dw) * th[1];
     r.vpot = vp; r.chi = th[1];
     r.d[2] = (dv != dv) ? z : dv;
-    r.d[3] = R(0.5) * RD(K.Ck) / h_bl * ((R(1) - m) * v - venti * m);
+    r.d[3] = ck_h * ((R(1) - m) * v - venti * m);
 }
 
 template <typename R>
@@ -471,7 +664,7 @@ __device__ __forceinline__ void rhs_tail(const EvalKT<R> &K, R h_bl, R lat, R v,
 {
     TrackMidT<R> mid;
     rhs_track<R>(K, lat, v, r, mid);
-    rhs_intensity<R>(K, h_bl, lat, v, m, th, lb, mid, r);
+    rhs_intensity<R>(K, ck_over_h<R>(K, h_bl), lat, v, m, th, lb, mid, r);
 }
 
 // loads of 2 / 4 / 8 bytes at the natural alignment of the *element* (1 / 2 / 4 bytes), i.e. possibly straddling the
@@ -599,7 +792,7 @@ __device__ __forceinline__ RhsT<R> rhs_eval(const EvalKT<R> &K, const R *__restr
     // ---- straight-line math
     RhsT<R> r;
     R q[14], F[4], th[4], lb[2];
-    blend<R, 14, Wd::W>(CW, wx, wy, q);
+    blend<R, 14, Wd::W, true>(CW, wx, wy, q);
     fs_blend<R>(fp, fb, t, F);
     winds_from_lookups<R>(q, F, lon, t, r.w);
     blend<R, 4, Wd::T>(CT, tx, ty, th);
@@ -707,7 +900,7 @@ struct RhsPipeT {
                                           RhsT<R> &r, TrackMidT<R> &mid, R (&th)[4], R (&lb)[2]) const
     {
         R q[14], F[4];
-        blend<R, 14, Wd::W>(C.CW, wx, wy, q);
+        blend<R, 14, Wd::W, true>(C.CW, wx, wy, q);
         fs_blend<R>(fp, fb, t, F);
         winds_from_lookups<R>(q, F, lon, t, r.w);
         blend<R, 4, Wd::T>(CT, tx, ty, th);

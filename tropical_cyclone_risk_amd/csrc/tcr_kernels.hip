@@ -74,7 +74,7 @@ struct KArgsT {
 using KArgs = KArgsT<double>;
 constexpr int kVRec = 12;
 constexpr int kMaxPasses = 16;
-constexpr int kParkRec = 18;     // doubles per parked storm: t, h, t_new, ha, g, y[4], f[4], 6 x int32, h_bl, field slot
+constexpr int kParkRec = 18;     // doubles per parked storm: t, h, t_new, ha, g, y[4], f[4], 6 x int32, 0.5 Ck / h_bl, field slot
 
 // ---------------------------------------------------------------------------
 // gen_f (track/bam_track.py:23-31), direct form: one thread per (storm, sample),
@@ -487,8 +487,9 @@ __device__ constexpr double RK_P[7][4] = {
 
 __device__ __forceinline__ double rms4(double a, double b, double c, double d)
 {
+    TCR_FP_FUSE_RK
     // np.linalg.norm(x) / x.size ** 0.5
-    return sqrt(a * a + b * b + c * c + d * d) / 2.0;
+    return qsqrt<double>(a * a + b * b + c * c + d * d) / 2.0;
 }
 
 // Number of t_eval samples <= t_emit: np.searchsorted(t_eval, t, side='right') (ivp.py:708)
@@ -550,6 +551,9 @@ template <typename R> constexpr int int_wps() { return sizeof(R) == 8 ? TCR_INT_
 template <typename R, bool AFFINE, bool PROBE, int SM>
 __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate(KArgsT<R> a)
 {
+    // TCR_FUSE_RK (tcr_device.h): stage inputs, y_new, the error norm and the initial-step norms below contract to fmas; the
+    // in-flight 2-day sample does not (k_screen must reproduce it bit for bit), nor does anything inlined from another function
+    TCR_FP_FUSE_RK
     // Kl[(stage*4 + component)*64 + lane]
     __shared__ R Kl[7 * 4 * kWave];
     __shared__ EvalKT<R> K;
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
     const R *wind = nullptr, *thermo = nullptr;
     const R *fs = nullptr;
     double *srec = nullptr;
-    R h_bl = R(0.0);
+    R ck_h = R(0.0);                        // 0.5 Ck / h_bl of the lane's storm (ck_over_h; travels in the park record)
     int cur_slot = 0;                       // the storm's field slot (travels in the park record)
     bool doomed = false;                    // failed the 2-day test already (prune_sample): no more records
     R y[4] = {0, 0, 0, 0}, f[4] = {0, 0, 0, 0}, yn[4] = {0, 0, 0, 0};
@@ -646,7 +650,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
             o[5] = make_double2((double)f[1], (double)f[2]);
             o[6] = make_double2((double)f[3], __longlong_as_double(sid));
             o[7] = make_double2(__longlong_as_double(c0), __longlong_as_double(c1));
-            o[8] = make_double2((double)h_bl, __longlong_as_double((long long)cur_slot));
+            o[8] = make_double2((double)ck_h, __longlong_as_double((long long)cur_slot));
         }
     };
     // occupancy accounting lives in LDS (lane 0 only): the kernel has no register to spare
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
                         sid = item;
                         const double lo0 = a.lon0[sid], la0 = a.lat0[sid], vv0 = a.v0[sid], mm0 = a.m0[sid], hb0 = a.h_bl[sid];
                         slot_id = a.slot[sid];
-                        y[0] = (R)lo0; y[1] = (R)la0; y[2] = (R)vv0; y[3] = (R)mm0; h_bl = (R)hb0;
+                        y[0] = (R)lo0; y[1] = (R)la0; y[2] = (R)vv0; y[3] = (R)mm0; ck_h = ck_over_h<R>(K, (R)hb0);
                         status = kRunning; nfev = 0; nacc = 0; nrej = 0; next_out = 0; doomed = false;
                         t = 0.0;
                         et = 0.0; e[0] = y[0]; e[1] = y[1]; e[2] = y[2]; e[3] = y[3];
@@ -706,7 +710,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
                         const long long c0 = __double_as_longlong(r7.x), c1 = __double_as_longlong(r7.y);
                         nfev = (int)(c0 & 0xffffffffll); nacc = (int)(c0 >> 32);
                         nrej = (int)(c1 & 0x3fffffffll); doomed = (c1 >> 30) & 1; rejected = (c1 >> 31) & 1; next_out = (int)(c1 >> 32);
-                        h_bl = (R)r8.x; slot_id = (int)__double_as_longlong(r8.y);
+                        ck_h = (R)r8.x; slot_id = (int)__double_as_longlong(r8.y);
                         status = kRunning;
                         // stage-2 input exactly as attempt_setup left it
                         for (int i = 0; i < 4; ++i) {
@@ -791,7 +795,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
                 if (TCR_INT_PIPELINE) { PIPE.issue(CC, Kq, wind, thermo, fs, etn, en[0], en[1]); pre = true; }
             }
             TCR_PHASE_CLK(3);
-            if (live) rhs_intensity<R>(Kq, h_bl, lat_e, v_e, m_e, th, lb, mid, r);
+            if (live) rhs_intensity<R>(Kq, ck_h, lat_e, v_e, m_e, th, lb, mid, r);
             TCR_PHASE_CLK(4);
             if (PROBE && live) {
                 const int ev = fresh ? slot : nfev;          // index of this evaluation in the storm's call order
@@ -812,10 +816,10 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
                         const double sc = P.atol + fmax(fabs((double)y[i]), fabs((double)yn[i])) * P.rtol;
                         double acc = 0.0;
                         for (int j = 0; j < 7; ++j) acc += (double)KS(j, i) * RK_E[j];
-                        er[i] = (acc * h) / sc;
+                        er[i] = qdiv_nz<double>(acc * h, sc);
                     }
                     const double err = rms4(er[0], er[1], er[2], er[3]);
-                    const double pw = 0.9 * pow(err, -0.2);
+                    const double pw = 0.9 * inv_fifth_root<double>(err);
                     if (err < 1) {
                         double fac = (err == 0) ? 10.0 : fmin(10.0, pw);
                         if (rejected && fac > 1) fac = 1;
@@ -869,6 +873,7 @@ __global__ __launch_bounds__(kWave, (int_wps<R>())) TCR_INT_CAP void k_integrate
                             else if (status != kRunning && next_out <= a.prune_sample && first_out < next_out) s2d = next_out - 1;
                         }
                         if (s2d >= 0) {
+                            TCR_FP_EXACT
                             // its v exactly as dense_at / k_screen form it (row 2 of Q = K^T P, x = (t_i - t_old) / h), and
                             // accept test 1's second half on it
                             R Qv[4];
@@ -1531,7 +1536,7 @@ __global__ __launch_bounds__(64) void k_init_m(tcr_params P, DevFields D, EvalK 
         blend<double, 4, 2>(CT, tx, ty, th);
         SL.finish(lb);
     }
-    rhs_intensity<double>(K, h_bl[i], lat, v, 0.5, th, lb, mid, r);
+    rhs_intensity<double>(K, ck_over_h<double>(K, h_bl[i]), lat, v, 0.5, th, lb, mid, r);
     const double al = r.alpha;
     const double gamma = K.epsilon + al * K.kappa;
     const double beta = 1 - K.epsilon - K.kappa;

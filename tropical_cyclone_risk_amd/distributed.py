@@ -306,3 +306,73 @@ def sum_over_ranks(x, device):
     if collective():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+class LibComm:
+    """The library's own RCCL communicator (include/tcrisk_hip.h, multi-GPU section: tcr_comm_* / tcr_allgather_* /
+    tcr_concat_rows_dev) — the exchange of final tracks behind the C ABI, for hosts that do not bring torch.distributed.
+    Here it is bootstrapped from the process group that is already up: rank 0 makes the 128-byte id, everybody receives it
+    through `broadcast_object_list` (any backend); a host without torch hands the id over by file / MPI instead.
+    One rank per GPU (RCCL); every method is collective and asynchronous on `stream` (None: torch's current stream)."""
+
+    def __init__(self, engine, rank_=None, world_=None, unique_id=None):
+        import ctypes as C
+        from . import _lib
+        self.L = _lib.lib()
+        self.eng = engine
+        self.rank = rank() if rank_ is None else int(rank_)
+        self.world = world() if world_ is None else int(world_)
+        if unique_id is None:
+            ident = [None]
+            if self.rank == 0:
+                buf = (C.c_uint8 * _lib.TCR_COMM_ID_BYTES)()
+                if self.L.tcr_comm_unique_id(buf) != 0:
+                    raise _lib.TcrError(self.L.tcr_last_error(None).decode())
+                ident = [bytes(buf)]
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                dist.broadcast_object_list(ident, src=0)
+            unique_id = ident[0]
+        idb = (C.c_uint8 * _lib.TCR_COMM_ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        if self.L.tcr_comm_create(engine.h, idb, self.rank, self.world, C.byref(h)) != 0:
+            raise _lib.TcrError(self.L.tcr_last_error(engine.h).decode())
+        self.h = h
+
+    def _st(self, stream):
+        import ctypes as C
+        return C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+
+    def _chk(self, rc):
+        if rc != 0:
+            from . import _lib
+            raise _lib.TcrError(self.L.tcr_last_error(self.eng.h).decode())
+
+    def allgather_counts(self, count, stream=None):
+        """count: int64 [1] device tensor -> int64 [world] device tensor."""
+        out = torch.empty(self.world, dtype=torch.int64, device=count.device)
+        self._chk(self.L.tcr_allgather_counts_dev(self.h, count.data_ptr(), out.data_ptr(), self._st(stream)))
+        return out
+
+    def allgather_rows(self, rows, counts_dev, out_cap=None, stream=None):
+        """rows: [cap, width] float64 (the same cap on every rank) with this rank's valid rows in front; counts_dev: int64 [world]
+        (allgather_counts).  Returns (packed [out_cap, width] in rank order, n_out int64 [1] on the device) — no host sync."""
+        cap, width = rows.shape
+        out_cap = self.world * cap if out_cap is None else int(out_cap)
+        recv = torch.empty(self.world * cap, width, dtype=torch.float64, device=rows.device)
+        out = torch.empty(out_cap, width, dtype=torch.float64, device=rows.device)
+        n_out = torch.zeros(1, dtype=torch.int64, device=rows.device)
+        st = self._st(stream)
+        self._chk(self.L.tcr_allgather_rows_dev(self.h, rows.data_ptr(), cap, width, recv.data_ptr(), st))
+        self._chk(self.L.tcr_concat_rows_dev(self.eng.h, self.world, recv.data_ptr(), counts_dev.data_ptr(), cap, width, out.data_ptr(), out_cap,
+                                             n_out.data_ptr(), st))
+        return out, n_out
+
+    def allreduce_sum_(self, t, stream=None):
+        assert t.dtype == torch.int64 and t.is_contiguous()
+        self._chk(self.L.tcr_allreduce_sum_i64_dev(self.h, t.data_ptr(), t.numel(), self._st(stream)))
+        return t
+
+    def close(self):
+        if getattr(self, 'h', None) is not None:
+            self.L.tcr_comm_destroy(self.h)
+            self.h = None
