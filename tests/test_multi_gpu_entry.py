@@ -75,7 +75,12 @@ def test_run_py_through_rccl_on_one_rank(built_lib, tmp_path, shard_years):
     write the plain run's track file bit for bit."""
     from tropical_cyclone_risk_amd import io as tio
     out = {}
-    for tag, env in (('plain', _env()), ('forced', _env(TCR_FORCE_COLLECTIVES='1'))):
+    cases = [('plain', _env()), ('forced', _env(TCR_FORCE_COLLECTIVES='1'))]
+    if shard_years:
+        # ... and once more with the all-gather of final tracks going through the LIBRARY's RCCL communicator
+        # (tcr_comm_create / tcr_allgather_dev behind the C ABI; distributed.LibComm) instead of torch.distributed's
+        cases.append(('lib', _env(TCR_FORCE_COLLECTIVES='1', TCR_COLLECTIVES='lib')))
+    for tag, env in cases:
         nlf = tmp_path / ('nl_%s.py' % tag)
         nlf.write_text("start_year = 2001\nend_year = 2003\ntracks_per_year = 24\noutput_directory = %r\nexp_name = %r\ngpu_shard_years = %r\n"
                        % (str(tmp_path), tag, shard_years))
@@ -84,7 +89,8 @@ def test_run_py_through_rccl_on_one_rank(built_lib, tmp_path, shard_years):
         assert r.returncode == 0, r.stderr[-3000:]
         out[tag] = tio.read_tracks(str(tmp_path / tag / 'tracks_GL_era5_200101_200312.nc'))
     for k in ('lon_trks', 'lat_trks', 'v_trks', 'm_trks', 'vmax_trks', 'u250_trks', 'v850_trks', 'tc_month', 'tc_basins', 'tc_years', 'seeds_per_month'):
-        assert np.array_equal(out['plain'][k], out['forced'][k], equal_nan=(out['plain'][k].dtype.kind == 'f')), k
+        for tag in out:
+            assert np.array_equal(out['plain'][k], out[tag][k], equal_nan=(out['plain'][k].dtype.kind == 'f')), (tag, k)
     assert out['plain']['lon_trks'].shape == (72, 361)
 
 

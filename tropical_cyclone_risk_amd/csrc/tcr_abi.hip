@@ -176,8 +176,6 @@ struct tcr_ctx {
     int32_t *d_und_list = nullptr;    // ... and the storms accept test 1 is still open for (k_screen's work list)
     size_t und_list_cap = 0;
     unsigned long long *d_und_count = nullptr;
-    int64_t *d_seg_sids = nullptr;    // storm ids of the park list the table's second segment is written for
-    size_t seg_sids_cap = 0;
     float *d_stat32 = nullptr;                  // fp32 copy of the land / bathymetry planes
     bool stat32_stale = true;
     int32_t *d_tc_idx = nullptr;                // storms that passed accept test 1 (k_screen -> compaction), tc_rows_only
@@ -777,26 +775,30 @@ int launch_fourier(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const double *
     if (ctx->fs_period > 0) {
         const size_t lds = sizeof(double2) * (size_t)ctx->fs_period;
         const int64_t nf = n * 4 * (int64_t)P.n_series;
-        {
+        if (part != kFsRest) {          // (kFsRest reads what the first segment's call left in d_pf: no reallocation in between)
             double *p = reinterpret_cast<double *>(ctx->d_pf);
             if (grow(ctx, &p, &ctx->pf_cap, (size_t)nf * 2)) { ctx->d_pf = nullptr; return -1; }
             ctx->d_pf = reinterpret_cast<double2 *>(p);
-        }
+        } else if (!ctx->d_pf) return fail(ctx, "internal: second table segment without the first");
         if (fourier_on_matrix_cores(ctx)) {
             // matrix-core form: phase factors in MFMA fragment order (4 KB per 4 storms <= the 3.84 KB of d_pf's layout + padding)
             const int64_t tiles = (n + 3) / 4;
-            double *p = reinterpret_cast<double *>(ctx->d_pf);
-            if (grow(ctx, &p, &ctx->pf_cap, (size_t)tiles * kFsMfmaKSteps * 64)) { ctx->d_pf = nullptr; return -1; }
-            ctx->d_pf = reinterpret_cast<double2 *>(p);
+            // kFsRest: the second segment for the parked storms is ONE launch (round 6; three until then): the table kernel reads the
+            // storm ids straight out of the park records (word 13 of each, k_integrate's park()) and picks every storm's phase
+            // factors out of the fragments the first segment's k_phase_factors_frag wrote for the whole batch — d_pf is not written
+            // between the two segments (only this function writes it, and a batch's two calls are on one stream)
             const int64_t *list = nullptr;
+            int list_stride = 1;
             if (part == kFsRest) {
-                double *q = reinterpret_cast<double *>(ctx->d_seg_sids);
-                if (grow(ctx, &q, &ctx->seg_sids_cap, (size_t)n)) { ctx->d_seg_sids = nullptr; return -1; }
-                ctx->d_seg_sids = reinterpret_cast<int64_t *>(q);
-                hipLaunchKernelGGL(k_park_sids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, park, park_count, n, ctx->d_seg_sids);
-                list = ctx->d_seg_sids;
+                list = reinterpret_cast<const int64_t *>(park) + 13;
+                list_stride = kParkRec;
+            } else {
+                double *p0 = reinterpret_cast<double *>(ctx->d_pf);
+                if (grow(ctx, &p0, &ctx->pf_cap, (size_t)tiles * kFsMfmaKSteps * 64)) { ctx->d_pf = nullptr; return -1; }
+                ctx->d_pf = reinterpret_cast<double2 *>(p0);
+                hipLaunchKernelGGL(k_phase_factors_frag, dim3((unsigned)std::min<int64_t>(tiles, 8192)), dim3(256), 0, st, P, n, n_dev, phases, p0, nullptr, nullptr, z);
             }
-            hipLaunchKernelGGL(k_phase_factors_frag, dim3((unsigned)std::min<int64_t>(tiles, 8192)), dim3(256), 0, st, P, n, n_dev, phases, p, list, park_count, z);
+            double *p = reinterpret_cast<double *>(ctx->d_pf);
             const int groups = part == kFsAll ? kFsMfmaColGroups : 1;
             // workgroups per launch: TCR_FS_WGS=<total> overrides (scheduling experiment: a workgroup's two 191-register waves
             // keep integrator waves of other batches off their SIMDs)
@@ -807,10 +809,10 @@ int launch_fourier(tcr_ctx *ctx, int64_t n, const int64_t *n_dev, const double *
             const unsigned wgs = (unsigned)std::min<int64_t>(tiles, std::max<int64_t>(1, want));
             if (part == kFsRest)
                 hipLaunchKernelGGL((k_fourier_mfma<R, true>), dim3(wgs, groups), dim3(64 * kFsMfmaWaves), 0, st, P, n, n_dev, ctx->fs_period,
-                                   ctx->d_sc_table, p, fs, 1, list, park_count);
+                                   ctx->d_sc_table, p, fs, 1, list, list_stride, park_count);
             else
                 hipLaunchKernelGGL((k_fourier_mfma<R, false>), dim3(wgs, groups), dim3(64 * kFsMfmaWaves), 0, st, P, n, n_dev, ctx->fs_period,
-                                   ctx->d_sc_table, p, fs, 0, list, park_count);
+                                   ctx->d_sc_table, p, fs, 0, list, list_stride, park_count);
         } else {
             hipLaunchKernelGGL(k_phase_factors, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, P, n, n_dev, phases, ctx->d_pf);
             hipLaunchKernelGGL(k_fourier_periodic<R>, dim3((unsigned)n), dim3(kFsThreads), lds, st, P, n, n_dev,
@@ -1071,7 +1073,7 @@ int tcr_ctx_destroy(tcr_ctx *ctx)
     for (auto &g : ctx->graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
     (void)hipFree(ctx->d_round_key);
     for (int i = 0; i < 2; ++i) { if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]); if (ctx->h_stage_ev[i]) (void)hipEventDestroy(ctx->h_stage_ev[i]); }
-    (void)hipFree(ctx->d_hist_partial); (void)hipFree(ctx->d_cell); (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_seg_sids); (void)hipFree(ctx->d_screen_skip); (void)hipFree(ctx->d_und_list); (void)hipFree(ctx->d_und_count); (void)hipFree(ctx->d_tab);
+    (void)hipFree(ctx->d_hist_partial); (void)hipFree(ctx->d_cell); (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_tc_idx); (void)hipFree(ctx->d_tc_count); (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_sidx); (void)hipFree(ctx->d_park[0]); (void)hipFree(ctx->d_park[1]); (void)hipFree(ctx->d_sc_table); (void)hipFree(ctx->d_pf); (void)hipFree(ctx->d_screen_skip); (void)hipFree(ctx->d_und_list); (void)hipFree(ctx->d_und_count); (void)hipFree(ctx->d_tab);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;

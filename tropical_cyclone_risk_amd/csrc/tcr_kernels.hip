@@ -249,8 +249,9 @@ constexpr int kFsMfmaMaxSamples = 24 * 16;
 
 // A fragments: [row tile of 4 storms][k step][lane]; lane l supplies A[i = l & 15][k = (l >> 4) + 4 * kstep],
 // i = series * 4 + storm_in_tile, k = 2 * harmonic + (0: weight * cos 2 pi x, 1: weight * sin 2 pi x); zero padding.
-// list != NULL: row r of the product is storm list[r], r < *list_count (the second segment of the table, written only for
-// the storms the first integration pass parked); otherwise row r is storm r.
+// k_fourier_mfma<LIST>: row r of the product is storm list[r * list_stride], r < *list_count (the second segment of the table, written
+// only for the storms the first integration pass parked: `list` points at the storm-id word of k_integrate's park records, stride
+// kParkRec); otherwise row r is storm r.
 // What a batch's kernels accumulate into, zeroed by the first kernel of the batch that runs anyway (k_phase_factors_frag;
 // k_batch_reset when the forcing table takes another path): k_integrate's queue heads / parked counts / occupancy counters
 // and — when the 2-day test is decided in flight — flags[0 .. n_flags) and the count of storms accept test 1 is still open for.
@@ -303,20 +304,12 @@ __global__ __launch_bounds__(256) void k_phase_factors_frag(tcr_params P, int64_
     }
 }
 
-// storm ids of a park list (k_integrate's records), for the list mode of the table kernels
-__global__ __launch_bounds__(256) void k_park_sids(const double *__restrict__ park, const unsigned long long *__restrict__ count,
-                                                   int64_t cap, int64_t *__restrict__ sids)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = (int64_t)*count < cap ? (int64_t)*count : cap;
-    if (i < n) sids[i] = __double_as_longlong(park[i * kParkRec + 13]);
-}
-
 template <typename R, bool LIST>
 __global__ __launch_bounds__(64 * kFsMfmaWaves, TCR_FS_MFMA_WPS) void k_fourier_mfma(tcr_params P, int64_t n, const int64_t *__restrict__ n_dev,
                                                          int period, const double2 *__restrict__ sc_table,
                                                          const double *__restrict__ frag, R *__restrict__ fs, int group0,
-                                                         const int64_t *__restrict__ list, const unsigned long long *__restrict__ list_count)
+                                                         const int64_t *__restrict__ list, int list_stride,
+                                                         const unsigned long long *__restrict__ list_count)
 {
     typedef double D4 __attribute__((ext_vector_type(4)));
     __shared__ double stage[kFsMfmaWaves][4 * 16 * 4];     // per wave: one output tile, [storm][sample][series]
@@ -415,23 +408,36 @@ __global__ __launch_bounds__(64 * kFsMfmaWaves, TCR_FS_MFMA_WPS) void k_fourier_
                 store_fs<R>(fs + (storm * (int64_t)ns + k) * 4, amp * ep.v[0], amp * ep.v[1], amp * ep.v[2], amp * ep.v[3]);
         }
     };
+    // A fragment of row tile `t`.  Plain: the tile's own 4 KB of `frag`, coalesced.  LIST: `frag` holds the fragments of the WHOLE
+    // batch (written before the first segment; row = storm), and row r of this product is storm list[r * list_stride] — the lane
+    // that supplies (series, storm-in-tile) of the list tile picks the same (series, k) element out of that storm's own tile:
+    // no second pass over the phases (k_phase_factors_frag ran for the list again until round 6), the same numbers
+    auto load_frag = [&](int64_t t, double (&dst)[kFsMfmaKSteps]) {
+        if (LIST) {
+            const int i = lane & 15;
+            const int64_t r = t * 4 + (i & 3);
+            const bool have = t < tiles && r < ne;
+            const int64_t storm = have ? list[r * (int64_t)list_stride] : 0;
+            const double *src = frag + (storm >> 2) * (kFsMfmaKSteps * 64) + (lane >> 4) * 16 + ((i & ~3) | (int)(storm & 3));
+#pragma unroll
+            for (int ks = 0; ks < kFsMfmaKSteps; ++ks) { const double v = src[ks * 64]; dst[ks] = have ? v : 0.0; }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < kFsMfmaKSteps; ++ks) dst[ks] = (t < tiles) ? frag[t * (kFsMfmaKSteps * 64) + ks * 64 + lane] : 0.0;
+        }
+    };
     double A[kFsMfmaKSteps];
     int64_t tile = blockIdx.x;
-    if (tile < tiles) {
-#pragma unroll
-        for (int ks = 0; ks < kFsMfmaKSteps; ++ks) A[ks] = frag[tile * (kFsMfmaKSteps * 64) + ks * 64 + lane];
-    }
+    load_frag(tile, A);
     for (; tile < tiles; tile += gridDim.x) {
         // the storms behind this row tile's rows (LIST: loaded here, with the fragment loads, long before the stores need
         // them — a load next to the stores would put a vmcnt(0), i.e. the stores' whole write latency, in front of each)
         const int64_t r0 = tile * 4 + (sizeof(R) == 8 ? (lane >> 5) : q), r1 = r0 + 2;
         int64_t cs0 = r0, cs1 = r1;
-        if (LIST) { cs0 = list[r0 < ne ? r0 : ne - 1]; cs1 = list[r1 < ne ? r1 : ne - 1]; }
+        if (LIST) { cs0 = list[(r0 < ne ? r0 : ne - 1) * (int64_t)list_stride]; cs1 = list[(r1 < ne ? r1 : ne - 1) * (int64_t)list_stride]; }
         // next row tile's fragment while this one multiplies
         double An[kFsMfmaKSteps];
-        const int64_t nxt = tile + gridDim.x;
-#pragma unroll
-        for (int ks = 0; ks < kFsMfmaKSteps; ++ks) An[ks] = (nxt < tiles) ? frag[nxt * (kFsMfmaKSteps * 64) + ks * 64 + lane] : 0.0;
+        load_frag(tile + gridDim.x, An);
 #pragma unroll
         for (int t = 0; t < kFsMfmaColTiles; ++t) {
             const int k0 = (((blockIdx.y + group0) * kFsMfmaWaves + wave) * kFsMfmaColTiles + t) * 16;

@@ -267,6 +267,10 @@ def allgather_year_blocks(block, n_mine, device):
     (gathered [world, k_max, ...], counts per rank) — one collective over the whole result, device to device."""
     w = world()
     cnt = torch.tensor([int(n_mine)], dtype=torch.int64, device=device)
+    if collective() and use_lib_collectives() and block.is_cuda:
+        comm = lib_comm(device)
+        counts = [int(x) for x in comm.allgather_counts(cnt).tolist()]
+        return comm.allgather(block.contiguous()), counts
     counts = allgather_counts(cnt)
     if not collective():
         return block.unsqueeze(0), counts
@@ -338,9 +342,34 @@ class LibComm:
             raise _lib.TcrError(self.L.tcr_last_error(engine.h).decode())
         self.h = h
 
+    @classmethod
+    def for_device(cls, device, rank_=None, world_=None):
+        """A communicator on a context of its own (the exchange needs no staged fields): `device` is the GPU index."""
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+
+        class _Ctx:
+            pass
+        holder = _Ctx()
+        h = C.c_void_p()
+        if L.tcr_ctx_create(int(device), C.byref(h)) != 0:
+            raise _lib.TcrError(L.tcr_last_error(None).decode())
+        holder.h = h
+        comm = cls(holder, rank_, world_)
+        comm._own_ctx = True
+        return comm
+
     def _st(self, stream):
         import ctypes as C
         return C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+
+    def allgather(self, t, stream=None):
+        """t: contiguous device tensor, the same shape on every rank -> [world, *t.shape] (tcr_allgather_dev)."""
+        assert t.is_contiguous()
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        self._chk(self.L.tcr_allgather_dev(self.h, t.data_ptr(), out.data_ptr(), t.numel() * t.element_size(), self._st(stream)))
+        return out
 
     def _chk(self, rc):
         if rc != 0:
@@ -376,3 +405,22 @@ class LibComm:
         if getattr(self, 'h', None) is not None:
             self.L.tcr_comm_destroy(self.h)
             self.h = None
+            if getattr(self, '_own_ctx', False):
+                self.L.tcr_ctx_destroy(self.eng.h)
+
+
+_LIB_COMM = {}
+
+
+def use_lib_collectives():
+    """TCR_COLLECTIVES=lib: the data-path exchange (the all-gather of final tracks) goes through the library's own RCCL
+    communicator (tcr_comm_* of include/tcrisk_hip.h) instead of torch.distributed's; the process group only bootstraps it."""
+    return os.environ.get('TCR_COLLECTIVES', '') == 'lib'
+
+
+def lib_comm(device):
+    """The process's LibComm on `device` (created on first use; collective: every rank reaches this together)."""
+    idx = torch.device(device).index if not isinstance(device, int) else device
+    if idx not in _LIB_COMM:
+        _LIB_COMM[idx] = LibComm.for_device(idx)
+    return _LIB_COMM[idx]
