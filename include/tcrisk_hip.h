@@ -429,6 +429,12 @@ int tcr_init_m_dev(tcr_ctx *ctx, const tcr_storms *storms_dev, double dvdt, doub
 int tcr_init_m_host(tcr_ctx *ctx, const tcr_storms *storms_host, double dvdt, double *m_out_host);
 
 /* ---- single-point probes (parity tests of the seam's leaf methods) -------- */
+/* (tests) the arithmetic helpers of the integrator on their own (csrc/tcr_device.h, "Arithmetic policy"): out[i] = fn(a[i][, b[i]]),
+ * fn 0: a / b without range scaling (qdiv_nz), 1: sqrt (qsqrt), 2: sqrt of a positive argument (qsqrt_pos), 3: a ** (-1/5)
+ * (inv_fifth_root: err ** -0.2 of scipy/integrate/_ivp/rk.py:160), 4: a ** -0.4 (strat_pow: t_strat ** -0.4,
+ * intensity/coupled_fast.py:91), 5: cos(a) for a in [-pi / 2, pi / 2] (cos_lat: np.cos(np.deg2rad(lat)), track/bam_track.py:139).
+ * Host arrays; b may be NULL except for fn 0. */
+int tcr_probe_math_host(tcr_ctx *ctx, int32_t fn, int64_t n, const double *a, const double *b, double *out);
 /* replaces: Coupled_FAST.dydt (coupled_fast.py:196-207), ._env_winds
  * (bam_track.py:116-128) and ._calc_alpha (coupled_fast.py:65-94) at n points
  * of one slot with one forcing table Fs[4][n_steps] (host buffers). */

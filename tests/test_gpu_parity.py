@@ -606,3 +606,73 @@ def test_parity_study_at_scale(golden_env, built_lib):
     os.makedirs('gpurun_out', exist_ok=True)
     with open('gpurun_out/parity_study.json', 'w') as f:
         json.dump(out, f, indent=1, default=lambda o: o.item() if hasattr(o, 'item') else str(o))
+
+
+def test_integrator_arithmetic_helpers_against_numpy(built_lib):
+    """Round 6: the integrator's division / square root without range scaling and its three libm-class substitutions
+    (csrc/tcr_device.h, "Arithmetic policy"), each on its own through tcr_probe_math_host, against NumPy in extended precision:
+      * qdiv_nz, qsqrt, qsqrt_pos: the IEEE result bit for bit on the operands the path has (what makes them parity-neutral);
+      * inv_fifth_root (err ** -0.2, rk.py:160) and strat_pow (t_strat ** -0.4, coupled_fast.py:91): within 2 ulp;
+      * cos_lat (np.cos(np.deg2rad(lat)), bam_track.py:139): within 1.5 ulp equatorward of 60 degrees, 5 ulp up to 80 degrees
+        (where the track stops, bam_track.py:134);
+    and the special values the callers rely on."""
+    import ctypes as C
+    from tropical_cyclone_risk_amd import _lib
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.tcr_ctx_create(0, C.byref(h)) == 0
+
+    def run(fn, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        out = np.empty_like(a)
+        bb = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None
+        rc = L.tcr_probe_math_host(h, fn, a.size, a.ctypes.data_as(_lib.DP), bb.ctypes.data_as(_lib.DP) if bb is not None else None,
+                                   out.ctypes.data_as(_lib.DP))
+        assert rc == 0, L.tcr_last_error(h).decode()
+        return out
+
+    def ulps(got, want_ld):
+        want = want_ld.astype(np.float64)
+        return np.abs((got.astype(np.longdouble) - want_ld) / np.spacing(np.abs(want)).astype(np.longdouble)).astype(np.float64)
+    rng = np.random.default_rng(6)
+    n = 400_000
+    # ---- division: dividends of either sign over 40 decades, divisors the path has (grid steps, cos(lat), h_bl, error scales, sigma)
+    a = rng.normal(size=n) * 10.0 ** rng.uniform(-20, 20, n)
+    b = np.concatenate([rng.uniform(0.17, 1.0, n // 4), rng.uniform(500, 3000, n // 4), 10.0 ** rng.uniform(-6, 2, n // 4),
+                        rng.uniform(0.5, 30, n - 3 * (n // 4))])
+    q = run(0, a, b)
+    assert np.array_equal(q, a / b), 'qdiv_nz differs from IEEE division on %d of %d operands' % ((q != a / b).sum(), n)
+    assert np.isnan(run(0, [np.nan, 1.0], [2.0, np.nan])).all()
+    # ---- square roots: sums of squares of speeds, variances
+    x = 10.0 ** rng.uniform(-12, 8, n)
+    for fn in (1, 2):
+        assert np.array_equal(run(fn, x), np.sqrt(x)), fn
+    s = run(1, [0.0, np.inf, -1.0, np.nan, 4.0])
+    assert s[0] == 0.0 and s[1] == np.inf and np.isnan(s[2]) and np.isnan(s[3]) and s[4] == 2.0
+    # ---- a ** (-1/5): error norms from 1e-14 to 1e6, stratifications from 1e-4 to 1e3 K / 100 m
+    # (what the reference computes is pow with the DOUBLE exponents -0.2 and -0.4, which are not -1/5 and -2/5: |ln a| x 1.1e-17 resp.
+    # 2.2e-17 relative, up to 3 ulp over these ranges — the helper corrects for it, tcr_device.h; ue / u4e: against the exact roots)
+    e = 10.0 ** rng.uniform(-14, 6, n)
+    u = ulps(run(3, e), np.power(e.astype(np.longdouble), np.longdouble(-0.2)))
+    ue = ulps(run(3, e), np.power(e.astype(np.longdouble), -np.longdouble(1) / np.longdouble(5)))
+    assert u.max() <= 2.0, (u.max(), ue.max())
+    g = 10.0 ** rng.uniform(-4, 3, n)
+    u4 = ulps(run(4, g), np.power(g.astype(np.longdouble), np.longdouble(-0.4)))
+    u4e = ulps(run(4, g), np.power(g.astype(np.longdouble), -np.longdouble(2) / np.longdouble(5)))
+    assert u4.max() <= 2.0, (u4.max(), u4e.max())
+    sp = run(4, [-1.0, np.nan, 1.0, 32.0])
+    assert np.isnan(sp[0]) and np.isnan(sp[1]) and sp[2] == 1.0 and abs(sp[3] - 0.25) <= 2 * np.spacing(0.25)
+    # step-size control at the ends of the range: a tiny / huge error norm ends at the clamps like pow does (rk.py:157-165)
+    pw = 0.9 * run(3, [1e-300, 0.0, 1e300, np.nan])
+    assert np.fmin(10.0, pw[0]) == 10.0 and np.fmin(10.0, pw[1]) == 10.0 and np.fmax(0.2, pw[2]) == 0.2 and np.fmax(0.2, pw[3]) == 0.2
+    # ---- cos(lat)
+    lat = rng.uniform(-80, 80, n)
+    xr = lat * (np.pi / 180.0)
+    u = ulps(run(5, xr), np.cos(xr.astype(np.longdouble)))
+    assert u[np.abs(lat) <= 60].max() <= 1.5 and u.max() <= 5.0, (u[np.abs(lat) <= 60].max(), u.max())
+    c = run(5, [0.0, np.nan, np.pi / 2])
+    assert c[0] == 1.0 and np.isnan(c[1]) and abs(c[2]) < 1e-15 and c[2] != 0.0
+    print('arithmetic helpers: division / sqrt bit-identical on %d operands each; a ** (-1/5): %.2f ulp from the exact root, %.2f from '
+          'pow(a, -0.2) over 20 decades; t_strat ** -0.4: %.2f / %.2f; cos(lat) max %.2f ulp (%.2f within 60 degrees)'
+          % (n, ue.max(), ulps(run(3, e), np.power(e.astype(np.longdouble), np.longdouble(-0.2))).max(), u4e.max(), u4.max(), u.max(), u[np.abs(lat) <= 60].max()))
+    L.tcr_ctx_destroy(h)

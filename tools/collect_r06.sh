@@ -50,3 +50,11 @@ for f in sorted(glob.glob('$OUT/bench*.json')):
         print(f, 'failed', e)
 PY
 cat "$OUT/timeline_streams12.txt"
+# 7. (optional, `bash tools/collect_r06.sh studies`) the product surface and the studies
+if [ "${1:-}" = studies ]; then
+  timeout 600 python tools/run_config3.py > "$OUT/config3.json" 2>/dev/null
+  timeout 600 python tools/fp32_study.py > "$OUT/fp32_study.json" 2>/dev/null
+  TCR_PARITY_STUDY=20000 timeout 2400 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k parity_study > "$OUT/parity_study_20000.log" 2>&1
+  cp gpurun_out/parity_study.json "$OUT/parity_study.json"
+  tail -3 "$OUT/parity_study_20000.log"
+fi

@@ -34,7 +34,7 @@ EXPORTS = ('tcr_abi_version', 'tcr_ctx_create', 'tcr_ctx_destroy', 'tcr_last_err
            'tcr_wind_stats_f32_dev', 'tcr_wind_stats_f32_host', 'tcr_static_upload2', 'tcr_init_m_dev', 'tcr_init_m_host', 'tcr_cell_order_dev',
            'tcr_round_dev', 'tcr_round_graph_stats', 'tcr_schedule_set', 'tcr_stage_trace_enable', 'tcr_stage_trace_sum', 'tcr_seed_hist_dev', 'tcr_pack_tracks_meta_dev',
            'tcr_static_store', 'tcr_static_info', 'tcr_tune_set', 'tcr_tune_get', 'tcr_slot_upload', 'tcr_stage_timing',
-           'tcr_comm_unique_id', 'tcr_comm_create', 'tcr_comm_destroy', 'tcr_comm_rank', 'tcr_comm_world', 'tcr_allgather_dev',
+           'tcr_probe_math_host', 'tcr_comm_unique_id', 'tcr_comm_create', 'tcr_comm_destroy', 'tcr_comm_rank', 'tcr_comm_world', 'tcr_allgather_dev',
            'tcr_allgather_rows_dev', 'tcr_allgather_counts_dev', 'tcr_allreduce_sum_i64_dev', 'tcr_concat_rows_dev')
 TCR_COMM_ID_BYTES = 128
 
@@ -205,6 +205,7 @@ def lib():
     L.tcr_pack_tracks_f32_dev.argtypes = L.tcr_pack_tracks_dev.argtypes
     L.tcr_wind_stats_f32_dev.argtypes = L.tcr_wind_stats_dev.argtypes
     L.tcr_wind_stats_f32_host.argtypes = L.tcr_wind_stats_host.argtypes
+    L.tcr_probe_math_host.argtypes = [C.c_void_p, C.c_int32, C.c_int64, DP, DP, DP]
     L.tcr_comm_unique_id.argtypes = [U8P]
     L.tcr_comm_create.argtypes = [C.c_void_p, U8P, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     L.tcr_comm_destroy.argtypes = [C.c_void_p]

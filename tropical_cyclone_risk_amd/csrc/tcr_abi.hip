@@ -1689,6 +1689,23 @@ int tcr_wind_stats_f32_host(tcr_ctx *ctx, int64_t n_samples, int64_t n_points, c
     return wind_stats_host_impl<float>(ctx, n_samples, n_points, wnd, day_start, n_days, out);
 }
 
+int tcr_probe_math_host(tcr_ctx *ctx, int32_t fn, int64_t n, const double *a, const double *b, double *out)
+{
+    if (!ctx) return -1;
+    if (fn < 0 || fn > 5 || n < 0 || (n > 0 && (!a || !out)) || (fn == 0 && n > 0 && !b)) return fail(ctx, "tcr_probe_math_host: bad argument");
+    if (n == 0) return 0;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevBuf B;
+    const double *d_a = B.put(a, n), *d_b = b ? B.put(b, n) : nullptr;
+    double *d_o = B.get<double>(n);
+    if (!d_a || (b && !d_b) || !d_o) return fail(ctx, "tcr_probe_math_host: device allocation failed");
+    hipLaunchKernelGGL(k_probe_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)fn, n, d_a, d_b, d_o);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, copy_sync(ctx->stream, out, d_o, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int tcr_probe_rhs_host(tcr_ctx *ctx, int slot, double h_bl, const double *Fs, int64_t n, const double *t,
                        const double *lon, const double *lat, const double *v, const double *m,
                        double *dydt, double *envw, double *alpha)

@@ -270,7 +270,8 @@ template <> __device__ __forceinline__ double qsqrt<double>(double a)
 // are both a ** (-1/5): of t_strat ** 2 and of err.  ocml's pow is a general double-double log / exp (~220 VALU instructions);
 // a ** (-1/5) is the root of f(y) = y ** -5 - a, whose Newton step y <- y + 0.2 y (1 - a y ** 5) needs six multiply-adds and
 // converges quadratically: seeded with the fp32 hardware exp2(-0.2 log2(a)) (relative error ~1e-6), two steps reach fp64 round-off
-// (measured against 80-bit pow on 2 M arguments in [1e-4, 1e3] ** 2: at most 1.8 ulp; ocml / glibc: 0.6).  Domain: a within the fp32
+// (tests/test_gpu_parity.py::test_integrator_arithmetic_helpers_against_numpy: against 80-bit pow with the reference's double
+// exponents, 400 000 arguments over twenty decades; ocml / glibc: 0.6 ulp).  Domain: a within the fp32
 // range (t_strat between 1e-19 and 1e19 K / 100 m); a <= 0, inf and NaN give NaN or the limit value like pow, except a = 0 -> NaN
 // (not inf) — callers select on `t_strat == 0` / `err == 0` before they use the value, as the reference does.
 template <typename R> __device__ __forceinline__ R inv_fifth_root(R a) { return pow(a, R(-0.2)); }
@@ -278,20 +279,28 @@ template <typename R> __device__ __forceinline__ R strat_pow(R g) { return pow(g
 #if TCR_FAST_POW
 template <> __device__ __forceinline__ double inv_fifth_root<double>(double a)
 {
-    double y = (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)a));       // v_log_f32 is log2, v_exp_f32 is exp2
+    const float L = __builtin_amdgcn_logf((float)a);                          // v_log_f32 is log2, v_exp_f32 is exp2
+    double y = (double)__builtin_amdgcn_exp2f(-0.2f * L);
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const double y2 = y * y, y4 = y2 * y2, y5 = y4 * y;
         const double r = __builtin_fma(-a, y5, 1.0);
         y = __builtin_fma(y * 0.2, r, y);
     }
-    return y;
+    // What the reference raises to is the DOUBLE -0.2 = -(1/5 + 1.11e-17) (and -0.4 = -(2/5 + 2.22e-17) of a = t_strat ** 2: the same
+    // factor per unit of log2 a): a ** (-0.2_double) = a ** (-1/5) x (1 - 1.11e-17 ln 2 log2 a), a correction of up to 3e-16 over the
+    // twenty decades an error norm spans — applied with the fp32 logarithm of the seed, which is far more than it needs.
+    return __builtin_fma(y * -7.6954e-18, (double)L, y);
 }
-template <> __device__ __forceinline__ double strat_pow<double>(double g) { return inv_fifth_root<double>(g * g); }
+template <> __device__ __forceinline__ double strat_pow<double>(double g)
+{
+    const double y = inv_fifth_root<double>(g * g);
+    return g < 0.0 ? __builtin_nan("") : y;         // a negative base to a fractional power is NaN in NumPy (-> dv/dt = 0, coupled_fast.py:150)
+}
 #endif
 
 // cos(lat pi / 180) for a latitude on the sphere: the argument is within [-pi / 2, pi / 2], so no range reduction is needed and
-// the Taylor polynomial to x ** 22 is below fp64 round-off in absolute terms (relative: 0.3 ulp on average, at most 1 ulp equatorward
+// the Taylor polynomial to x ** 22 is below fp64 round-off in absolute terms (relative: 0.3 ulp on average, at most 1.2 ulp equatorward
 // of 60 degrees and 4.4 ulp at 80 degrees, where cos = 0.17; the track stops there, bam_track.py:134).  ocml's cos spends ~150
 // instructions, most of them on arguments this path never has.
 template <typename R> __device__ __forceinline__ R cos_lat(R x) { return cos(x); }

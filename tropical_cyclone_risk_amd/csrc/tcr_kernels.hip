@@ -1571,4 +1571,24 @@ __global__ __launch_bounds__(64) void k_probe_rhs(tcr_params P, DevFields D, Eva
     for (int k = 0; k < 4; ++k) envw[i * 4 + k] = w[k];
 }
 
+// The arithmetic helpers of tcr_device.h's policy on their own (tcr_probe_math_host: tests pin their accuracy against NumPy)
+__global__ __launch_bounds__(256) void k_probe_math(int fn, int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                                                    double *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = a[i], y = b ? b[i] : 0.0;
+    double r = 0.0;
+    switch (fn) {
+    case 0: r = qdiv_nz<double>(x, y); break;
+    case 1: r = qsqrt<double>(x); break;
+    case 2: r = qsqrt_pos<double>(x); break;
+    case 3: r = inv_fifth_root<double>(x); break;
+    case 4: r = strat_pow<double>(x); break;
+    case 5: r = cos_lat<double>(x); break;
+    default: break;
+    }
+    out[i] = r;
+}
+
 }  // namespace tcr
