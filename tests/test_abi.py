@@ -150,9 +150,8 @@ def test_kernel_register_budgets():
     assert seen >= set(small) - {'k_batch_reset'}, sorted(set(small) - seen)
     # The 80-register budgets are bought with a little scratch (measured as a net win).  The amounts
     # are pinned so that a compiler upgrade that starts spilling in earnest shows up here: k_seed <= 56 B per lane,
-    # k_screen<double> <= 20 B, and the production k_emit (fp64, affine grids, one list entry per workgroup) <= 16 B (none until
-    # round 6; with the fused env-wind arithmetic the allocator parks three dwords, for 7.6 % fewer VALU instructions).
-    ceilings = {'_ZN3tcr6k_seedE': 56, '_ZN3tcr8k_screenIdE': 20, '_ZN3tcr6k_emitIdLb1ELb0EE': 16}
+    # k_screen<double> <= 20 B, and the production k_emit (fp64, affine grids, one list entry per workgroup) none at all.
+    ceilings = {'_ZN3tcr6k_seedE': 56, '_ZN3tcr8k_screenIdE': 20, '_ZN3tcr6k_emitIdLb1ELb0EE': 0}
     for prefix, cap in ceilings.items():
         hit = [(n, r) for n, r in rows.items() if n.startswith(prefix)]
         assert len(hit) == 1, (prefix, [n for n, _ in hit])
