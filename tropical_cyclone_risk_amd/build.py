@@ -19,7 +19,10 @@ SOURCES = ['tcr_abi.hip', 'tcr_kernels.hip', 'tcr_seed.hip', 'tcr_compact.hip', 
            os.path.join('..', '..', 'include', 'tcrisk_hip.h')]
 # -disable-machine-licm: the kernels here are register-bound loops around libm-heavy bodies; hoisting the bodies' constant
 # materialisations out of the loops costs k_emit 40 VGPRs + spills (0.36 instead of 0.15 ms) and k_integrate 70 AGPRs.
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-DTCR_OPAQUE_K', '-mllvm', '-disable-machine-licm',
+# -DTCR_K_KERNARG: k_integrate reads its ~100 evaluation constants with scalar loads from the kernel arguments instead of from the
+# workgroup's LDS copy behind an opaque offset (-DTCR_OPAQUE_K, rounds 2-5: needed while LLVM hoisted them into registers and the
+# kernel spilled; without machine LICM neither form spills).  Round 6, same box: chain -3 %, 100 000-storm step -1.5 %, bit-identical.
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-DTCR_K_KERNARG', '-mllvm', '-disable-machine-licm',
          '-fPIC', '-shared']
 
 
