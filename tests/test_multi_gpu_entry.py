@@ -183,3 +183,38 @@ def test_library_allgather_through_rccl_on_one_rank(built_lib):
     assert int(n_out) == 5 and torch.equal(out, rows[:5])
     comm.close()
     eng.close()
+
+
+@pytest.mark.gpu
+def test_round_and_exchange_without_pytorch(built_lib, tmp_path):
+    """The C ABI is the product, PyTorch is plumbing: tools/ctypes_only_round.py runs a round of the accept loop
+    with hipMalloc'ed buffers and exchanges its accepted tracks through the library's one-rank RCCL communicator in a process
+    that never imports torch — and its survivor records, n_seeds and counters equal the torch-backed pipeline's, bit for bit."""
+    import torch
+    from tropical_cyclone_risk_amd import synthetic, _lib
+    from tropical_cyclone_risk_amd.engine import TCEngine
+    from tropical_cyclone_risk_amd.pipeline import DevicePipeline
+    out = tmp_path / 'rows.npz'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'ctypes_only_round.py'), '--basin', 'NA', '--cand', '65536', '--storms',
+                        '8192', '--year', '2003', '--cand0', '131072', '--out', str(out)], env=_env(), cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'torch imported: False' in r.stdout and 'RCCL communicator ok' in r.stdout
+    got = np.load(out)
+    env = synthetic.make_env('era5', static_res=0.125)
+    eng = TCEngine('NA', device=0).stage_env(env)
+    pipe = DevicePipeline(eng, 65536, 8192, sort_storms=2.0, tc_rows_only=True)
+    dev = torch.device('cuda', 0)
+    ns = eng.n_steps
+    cap = 8192 // 4
+    packed = torch.empty(cap, 9 * ns + 3, dtype=torch.float64, device=dev)
+    stats = torch.zeros(_lib.N_STATS, dtype=torch.int64, device=dev)
+    hist = torch.zeros(84, dtype=torch.int64, device=dev)
+    pipe.round(2003, 131072, stats=stats, accepted=True, packed=packed, pack_cap=cap, seed_hist=hist)
+    torch.cuda.synchronize()
+    n_acc = int(pipe.n_accepted.item())
+    assert n_acc == int(got['n_accepted']) > 0 and int(pipe.n_passed.item()) == int(got['n_passed'])
+    assert np.array_equal(stats.cpu().numpy(), got['stats'])
+    assert np.array_equal(hist.cpu().numpy().reshape(7, 12), got['n_seeds'])
+    assert np.array_equal(packed[:n_acc].cpu().numpy(), got['rows'], equal_nan=True)
+    eng.close()
