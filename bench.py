@@ -279,14 +279,21 @@ def main():
         acc_keep = acc.clone()
         for e in engs:
             e.timing_enable(True)
-        for k in range(w_eff + args.steps, w_eff + args.steps + 3):
+        iso_each = []
+        for k in range(w_eff + args.steps, w_eff + args.steps + 5):
             with torch.cuda.stream(streams[0]):
                 _step(k, pipes[0], graph=False)          # direct enqueue: the library's timing events are recorded
             torch.cuda.synchronize()
+            iso_each.append(engs[0].timing_last())
         drain()                                          # (nothing of the isolated batches stays in flight in the collective backend)
         torch.cuda.synchronize()
-        iso = sum_timings()
-        iso_counts = (acc - acc_keep).tolist()
+        # five batches, one at a time; per component the MEDIAN of the five (round 6: the chip idles between isolated batches and
+        # its clock sags on some boxes — one run in four showed a 1.92 ms chain next to 1.6-1.7 in every other; the mean of three
+        # carried that into roofline.frac).  `iso` keeps the fields of a timing sum over ONE call.
+        med = lambda key: sorted(x[key] for x in iso_each)[len(iso_each) // 2]
+        iso = dict(fourier_ms=med('fourier_ms'), integrate_ms=med('integrate_ms'), post_ms=med('post_ms'), calls=1)
+        n_iso = len(iso_each)
+        iso_counts = [x / n_iso for x in (acc - acc_keep).tolist()]      # per isolated batch
         acc.copy_(acc_keep)
         iso_passes = engs[0].pass_stats()
     D.allreduce_sum_(acc)
@@ -333,7 +340,7 @@ def main():
                 frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                 note='a launch = the chain of k_integrate passes of one batch (tail compaction); achieved = %d B x RHS ' % BYTES_PER_RHS +
                      'evaluations of the batch / exclusive HIP-event duration of the chain (one batch at a time on one '
-                     'stream, after the timed region); profiles/ lists k_integrate once per pass',
+                     'stream, after the timed region: median of five); profiles/ lists k_integrate once per pass',
                 algorithmic_bytes_per_launch=ib, launch_ms=ik,
                 kernel_ms=dict(fourier=iso['fourier_ms'] / iso['calls'], integrate=ik, post=ie),
                 pipelined_events=(dict(note='event-bracketed durations inside the timed region, %d streams overlapping' % n_str,
