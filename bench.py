@@ -64,6 +64,11 @@ def main():
     ap.add_argument('--stage-trace', action='store_true', help='record a HIP event behind every stage of every (directly enqueued) round of '
                     'the timed region and report the per-stage stream time under load (tcr_stage_trace_*; implies --graph off)')
     ap.add_argument('--staged', action='store_true', help="round 3's step: one library call per stage instead of tcr_round_dev")
+    ap.add_argument('--events', choices=('auto', 'on', 'off'), default='auto',
+                    help='HIP events around the table / integrator / post-processing of every batch INSIDE the timed region (they feed '
+                         'roofline.pipelined_events and gpu_active_s).  Free at 100 000 storms per batch (1.188 vs 1.186 ms), 6 %% of a '
+                         '12 500-storm step (0.233 vs 0.219 ms, round 6): auto = on when a rank integrates >= 50 000 storms per step.  The '
+                         'headline roofline figure does not need them: it comes from isolated batches after the timed region')
     ap.add_argument('--dup-seed', type=int, default=1, help=argparse.SUPPRESS)
     ap.add_argument('--dup-select', type=int, default=1, help=argparse.SUPPRESS)
     ap.add_argument('--basin', default='GL')
@@ -221,8 +226,9 @@ def main():
         if gather is not None:
             gather.drain()
 
+    events_on = args.events == 'on' or (args.events == 'auto' and B >= 50_000)
     for e in engs:
-        e.timing_enable(True)
+        e.timing_enable(events_on)
     w_eff = max(args.warmup, n_str)          # every stream runs the full step at least once untimed
     for k in range(w_eff):
         step(k)
@@ -231,7 +237,7 @@ def main():
     acc.zero_()
     D.barrier(); torch.cuda.synchronize()
     for e in engs:
-        e.timing_enable(True)        # resets the event record: only the K timed steps count
+        e.timing_enable(events_on)   # resets the event record: only the K timed steps count
         if args.stage_trace:
             e.stage_trace(True)
     if gather is not None:
@@ -429,6 +435,7 @@ def main():
                        'storms_per_gpu': storms_total / (args.steps * world), 'candidates_per_round': C, 'seed_pass_rate': p_pass,
                        'n_steps_out': ns, 'rounds_short_of_storms': None if strong else n_short, 'streams': n_str,
                        'hw_queues': int(os.environ.get('GPU_MAX_HW_QUEUES', '4')), 'storms_per_lane': args.storms_per_lane,
+                       'timed_region_events': bool(events_on),
                        'step_call': 'staged (one library call per stage)' if args.staged else ('tcr_round_dev, replayed from a hipGraph' if use_graph else 'tcr_round_dev, direct enqueue'),
                        'graph_replays': sum(p.graph_stats()['replays'] for p in pipes),
                        'stage_ms_under_load': stage_ms,
