@@ -1,5 +1,6 @@
-"""Parity distribution of ONE build of the library against the golden fixtures and the C oracle (GPU box):
-    python tools/parity_probe.py [LIB.so] [--n 10000]
+"""(test utility, not collected by pytest: lives under tests/ because it calls the oracle, which only tests may do)
+Parity distribution of ONE build of the library against the golden fixtures and the C oracle (GPU box):
+    python tests/parity_probe.py [LIB.so] [--n 10000]
 Prints, per set, the per-storm maximum |GPU - reference| over the hourly lon / lat / v / m of the decision-identical storms:
 counts above the tiers of oracle/parity.py (1e-9: allowed n // 100 + 1; 2e-11: n // 20 + 2; 1e-7: the floor), percentiles,
 and the number of decision-identical storms whose counters (status / n_valid / nfev / n_accept / n_reject) differ.
