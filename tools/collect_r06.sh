@@ -25,7 +25,7 @@ for s in 1 12; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats$s" -o s -- \
       python bench.py --steps 10 --warmup 2 --streams $s --no-cpu-baseline > /dev/null 2>&1
   cp "$(find "$OUT/stats$s" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_streams$s.csv"
-  [ $s = 12 ] && python tools/timeline.py "$(find "$OUT/stats$s" -name '*kernel_trace.csv' | head -1)" 8 > "$OUT/timeline_streams12.txt" 2>&1
+  [ $s = 12 ] && python tools/timeline.py "$(find "$OUT/stats$s" -name '*kernel_trace.csv' | head -1)" 6 5 > "$OUT/timeline_streams12.txt" 2>&1
   rm -rf "$OUT/stats$s"
 done
 # 5. HBM-side counters, one pass per counter group (single stream so dispatches do not overlap)

@@ -1,7 +1,7 @@
 """GPU timeline of a bench run from a rocprofv3 --kernel-trace csv: how busy was the chip during the timed steps?
-    python tools/timeline.py gpurun_out/r03e/t4/t_kernel_trace.csv [n_last_steps]
-Per queue the dispatches are serial; across queues they overlap.  Reports, over the window that holds the last N k_flags
-dispatches (one per step): wall time per step, union-busy fraction, mean number of kernels in flight, the integrator's
+    python tools/timeline.py gpurun_out/r03e/t4/t_kernel_trace.csv [n_steps] [skip_last]
+Per queue the dispatches are serial; across queues they overlap.  Reports, over the window that holds N k_flags dispatches
+(one per step) ending skip_last dispatches before the last one (bench.py ends with five isolated batches on one stream: skip 5): wall time per step, union-busy fraction, mean number of kernels in flight, the integrator's
 SIMD demand (sum over its dispatches of min(workgroups, SIMDs) x duration / (SIMDs x wall)), and per-kernel time shares."""
 import collections
 import csv
@@ -9,6 +9,7 @@ import sys
 
 fn = sys.argv[1]
 n_last = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 SIMDS = 1024
 rows = [r for r in csv.DictReader(open(fn))]
 for r in rows:
@@ -16,8 +17,8 @@ for r in rows:
     r['name'] = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('tcr::', '')
     r['wgs'] = (int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X']))) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z'])
 flags = sorted(r['e'] for r in rows if r['name'].startswith('k_flags'))
-t1 = flags[-1]
-t0 = flags[-1 - n_last]
+t1 = flags[-1 - skip]
+t0 = flags[-1 - skip - n_last]
 win = [r for r in rows if r['e'] > t0 and r['s'] < t1]
 wall = (t1 - t0) / 1e6
 ev = []

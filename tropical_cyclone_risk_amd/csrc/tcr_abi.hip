@@ -428,9 +428,13 @@ double ts_host(const tcr_params &P, int i)
 }
 
 constexpr size_t kQueueWords = 6 * kMaxPasses;     // heads, parked counts, 4 occupancy counters per pass
-unsigned park_final_waves(const tcr_ctx *ctx)               // a pass this small runs to the end
+// A pass this small runs to the end.  Default: one wave per CU (256 on MI355X) — for a chip-filling batch that is three passes
+// (1 024, 1 024 behind the table's second segment, 176 waves) instead of the five of rounds 2-5 (… 30, 5 waves; the default was
+// 8): the two tiny passes held 0.2 % of the SIMD time and each cost a dispatch in the chain.  Round 6, same box: exclusive
+// chain -4 %, one-stream step -5 %, 12-stream step -1…1.5 %, SIMD time +1 % (profiles/r06_dispatch_and_knobs.txt).
+unsigned park_final_waves(const tcr_ctx *ctx)
 {
-    return ctx->tune.park_final > 0 ? (unsigned)ctx->tune.park_final : 8u;
+    return ctx->tune.park_final > 0 ? (unsigned)ctx->tune.park_final : (unsigned)std::max(8, ctx->cu_count);
 }
 
 // The launch-shape knobs a context starts from: the environment, read ONCE (tcr_ctx_create); tcr_tune_set replaces them.
