@@ -477,6 +477,7 @@ int tcr_sync(tcr_ctx *ctx, void *stream);
  * the copy the process already holds, e.g. PyTorch's, when there is one): a single-GPU user never needs it.
  *   rank 0: tcr_comm_unique_id(id) -> the 128 bytes travel to the other ranks by any host channel (a file, MPI, a TCP store)
  *   all   : tcr_comm_create(ctx, id, rank, world, &comm)       collective: every rank of the job calls it
+ * A communicator borrows its context (error text, device, default stream): destroy it before the context.
  * Calls on one communicator are collective and must be issued in the same order on every rank; they are asynchronous on
  * `stream` (NULL: the context's).  Ragged contributions travel padded to a common row count (`cap`), each rank's real count
  * next to them (tcr_allgather_counts_dev); tcr_concat_rows_dev packs the received blocks in rank order — which is candidate

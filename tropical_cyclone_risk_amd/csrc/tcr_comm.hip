@@ -139,6 +139,7 @@ int tcr_allgather_dev(tcr_comm *c, const void *send_dev, void *recv_dev, int64_t
     tcr_ctx *ctx = c->ctx;
     if (bytes < 0 || (bytes > 0 && (!send_dev || !recv_dev))) return fail(ctx, "tcr_allgather_dev: bad argument");
     if (bytes == 0) return 0;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
     // fp64 elements where the size allows it (what the records are), bytes otherwise: the transport is the same
     const bool f64 = (bytes % 8) == 0 && (reinterpret_cast<uintptr_t>(send_dev) % 8) == 0 && (reinterpret_cast<uintptr_t>(recv_dev) % 8) == 0;
@@ -165,6 +166,7 @@ int tcr_allreduce_sum_i64_dev(tcr_comm *c, int64_t *buf_dev, int64_t n, void *st
     tcr_ctx *ctx = c->ctx;
     if (n < 0 || (n > 0 && !buf_dev)) return fail(ctx, "tcr_allreduce_sum_i64_dev: bad argument");
     if (n == 0) return 0;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
     const int rc = rccl()->AllReduce(buf_dev, buf_dev, (size_t)n, kNcclInt64, kNcclSum, c->nccl, st);
     if (rc != 0) return fail(ctx, "ncclAllReduce: ", rccl()->GetErrorString(rc));
@@ -176,6 +178,8 @@ int tcr_concat_rows_dev(tcr_ctx *ctx, int32_t n_blocks, const double *gathered_d
 {
     if (!ctx) return -1;
     if (n_blocks < 1 || cap < 0 || row_stride <= 0 || out_cap < 0 || !counts_dev) return fail(ctx, "tcr_concat_rows_dev: bad argument");
+    if (cap * (int64_t)n_blocks > 0x7fffffffLL) return fail(ctx, "tcr_concat_rows_dev: cap x n_blocks exceeds the grid limit");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
     if (cap == 0) {
         if (n_out_dev) HIPCHK(ctx, hipMemsetAsync(n_out_dev, 0, sizeof(int64_t), stream_ ? (hipStream_t)stream_ : ctx->stream));
         return 0;
