@@ -510,3 +510,17 @@ def test_rows_to_tuple_never_aliases_the_round_buffer():
         buf[:] = -1.0                                                             # the next year's round reuses the buffer
         assert np.array_equal(tup[5], want_env)
         assert np.array_equal(tup[0], np.arange(n * 9 * ns, dtype=np.float64).reshape(n, 9 * ns)[:, :ns])
+
+
+def test_design_cites_current_round_or_names_the_round():
+    """DESIGN.md states the current state — a sentence that cites a profile of rounds 1-4 must say which round it is
+    from, and every profile file it names exists."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, 'DESIGN.md')).read()
+    for ln, line in enumerate(text.splitlines(), 1):
+        if re.search(r'r0[1-4]_', line):
+            assert re.search(r'[Rr]ound', line), 'DESIGN.md:%d cites an old profile without naming its round' % ln
+    for name in set(re.findall(r'profiles/(r0\d_[A-Za-z0-9_.]+?\.(?:json|txt|csv))', text)):
+        assert os.path.exists(os.path.join(root, 'profiles', name)), name
+    assert os.path.exists(os.path.join(root, 'DESIGN_LOG.md'))
